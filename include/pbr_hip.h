@@ -1,0 +1,161 @@
+/*
+ * pbr_hip.h — C ABI of the MI355X path-tracing core (libpbrhip.so).
+ *
+ * Drop-in boundary: this library replaces what the reference reaches through its `CL`
+ * class (source/CL.h:20-83) as driven by `PathTracer` (source/PathTracer.cpp) — the OpenCL
+ * context, the device buffers, the JIT-compiled `pathTracing` kernel
+ * (source/opencl/pathtracing.cl:207-334) and the per-frame launch.  `CL` is not a stable
+ * plugin ABI (cl_mem / cl_kernel leak through every signature and kernel constants travel
+ * as source-text substitutions), so the entry points mirror the reference's CALL SEQUENCE;
+ * each one names the reference call it stands for.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative PBR_E* code otherwise;
+ *    pbr_last_error( ctx ) holds the message.  Nothing calls exit() (the reference does:
+ *    source/CL.cpp:78,210,349,442,524,541,565).
+ *  - inputs are borrowed for the duration of the call and copied to the device
+ *    (CL_MEM_COPY_HOST_PTR semantics, source/CL.h:26-33); outputs are copied into
+ *    caller-provided buffers (source/CL.cpp:581-594).
+ *  - one context = one HIP device + one stream; calls on a context are synchronous and not
+ *    re-entrant; separate contexts may be driven from separate threads / processes.
+ *  - there is NO CPU fallback: without a usable HIP device pbr_create fails.
+ */
+#ifndef PBR_HIP_H
+#define PBR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBR_OK 0
+#define PBR_EINVAL (-1)   /* bad argument / scene fails validation */
+#define PBR_EDEVICE (-2)  /* HIP error (message has the HIP error string) */
+#define PBR_ESTATE (-3)   /* call sequence violated (e.g. render before upload/configure) */
+
+typedef struct pbr_ctx pbr_ctx;
+
+/* ---- wire formats: the reference's host structs, bit for bit (source/PathTracer.h:25-73) */
+
+typedef struct { float x, y, z, w; } pbr_float4;
+typedef struct { uint32_t x, y, z, w; } pbr_uint4;
+
+/* camera_cl, PathTracer.h:25-32 (cl_float3 occupies 16 bytes) — 80 bytes */
+typedef struct {
+	pbr_float4 eye, w, u, v;
+	int32_t focusPoint[2];   /* (-1,-1): no depth of field */
+	float lense[2];          /* focal length, aperture */
+} pbr_camera;
+
+/* bvhNode_cl, PathTracer.h:69-72 — 32 bytes.  bbMin.w: first face index or -1 (inner);
+ * bbMax.w: second face index or -1 (leaf) / miss link or -1 (inner). */
+typedef struct { pbr_float4 bbMin, bbMax; } pbr_bvh_node;
+
+/* light_cl, PathTracer.h:39-43 — 48 bytes.  data.x: 1 point, 2 orb; data.y: orb radius */
+typedef struct { pbr_float4 pos, rgb, data; } pbr_light;
+
+/* material_schlick_rgb, PathTracer.h:45-54 — 48 bytes; data = d, Ni, p, rough */
+typedef struct { float data[4]; pbr_float4 rgbDiff, rgbSpec; } pbr_material_schlick;
+
+/* material_shirley_ashikhmin_rgb, PathTracer.h:56-65 — 64 bytes; data = d, Ni, nu, nv, Rs, Rd, -, - */
+typedef struct { float data[8]; pbr_float4 rgbDiff, rgbSpec; } pbr_material_sa;
+
+/* The seven arrays PathTracer::initOpenCLBuffers uploads (PathTracer.cpp:357-380 vertices /
+ * normals, :238-347 bvh / facesV / facesN, :435-519 materials, :387-428 lights). */
+typedef struct {
+	const pbr_bvh_node* bvh;      uint32_t num_nodes;       /* -> #BVH_NUM_NODES# */
+	const pbr_uint4* facesV;      /* {v0, v1, v2, material}, leaf order */
+	const pbr_uint4* facesN;      /* may be NULL (only Phong tessellation reads it) */
+	uint32_t num_faces;
+	const pbr_float4* vertices;   uint32_t num_vertices;
+	const pbr_float4* normals;    uint32_t num_normals;     /* may be NULL / 0 */
+	const void* materials;        uint32_t num_materials;   /* pbr_material_schlick[] if brdf == 0, pbr_material_sa[] if 1 */
+	uint32_t brdf;                /* which material layout `materials` uses */
+	const pbr_light* lights;      uint32_t num_lights;      /* -> #NUM_LIGHTS#; lights may be NULL when 0 */
+} pbr_scene_desc;
+
+/* The constants CL::setValues / setReplacement bake into the kernel source
+ * (source/CL.cpp:637-678, PathTracer.cpp:210,338,472,515). */
+typedef struct {
+	uint32_t width, height;       /* IMG_WIDTH, IMG_HEIGHT; multiples of 8 (opencl.localgroupsize) */
+	uint32_t brdf;                /* BRDF: 0 Schlick, 1 Shirley-Ashikhmin; must match the uploaded materials */
+	uint32_t shadow_rays;         /* SHADOW_RAYS */
+	uint32_t max_depth;           /* MAX_DEPTH */
+	uint32_t max_added_depth;     /* MAX_ADDED_DEPTH */
+	uint32_t samples;             /* SAMPLES (paths per pixel per frame) */
+	float anti_aliasing;          /* ANTI_ALIASING */
+	float phong_tessellation;     /* PHONGTESS_ALPHA; > 0 is rejected (not built, off in the reference's config) */
+	float sky_light[4];           /* SKY_LIGHT */
+	/* Tile sharding (not in the reference, which is single-device): this context renders the
+	 * 8x8-pixel tiles t with t % tile_world == tile_rank.  1 / 0 = everything. */
+	uint32_t tile_world, tile_rank;
+} pbr_config;
+
+/* Traversal counters (the reference's debugColor.y / .x, pt_bvh.cl:89,23, as exact integers,
+ * plus shaded hits and camera paths) summed over everything rendered since the last reset. */
+typedef struct { uint64_t nodes, tris, hits, paths; } pbr_counters;
+
+/* new CL() — platform / device / context / profiling queue (source/CL.cpp:10-24). */
+int pbr_create( int device, pbr_ctx** out );
+/* ~CL() (source/CL.cpp:30-52) */
+void pbr_destroy( pbr_ctx* ctx );
+const char* pbr_last_error( const pbr_ctx* ctx );
+
+/* CL::createBuffer x 7 (PathTracer.cpp:357-519).  Validates every index the kernel will
+ * follow (links, face, vertex and material indices — the reference reads out of bounds for
+ * material -1, ObjParser.cpp:140,192) and re-lays the arrays out for CDNA4. */
+int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* scene );
+
+/* CL::loadProgram + createKernel + initKernelArgs (PathTracer.cpp:225-229, :88-125) and
+ * initOpenCLBuffers_Textures (:525-533): selects the kernel variant, allocates the three
+ * W x H RGBA32F images and zero-fills the input image. */
+int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg );
+
+/* CL::updateImageReadOnly( imageIn ) (PathTracer.cpp:61): rgba = W*H*4 floats, row 0 = bottom. */
+int pbr_write_input( pbr_ctx* ctx, const float* rgba );
+/* Zero the input image and the counters (PathTracer::resetSampleCount + the zero-filled
+ * mTextureOut of initOpenCLBuffers_Textures). */
+int pbr_reset_accum( pbr_ctx* ctx );
+
+/* clPathTracing (PathTracer.cpp:43-52): set args 0 (seed), 1 (pixelWeight), 2 (pxDim),
+ * 3 (camera); CL::execute; CL::finish.  Reads imageIn, writes imageOut and imageDebug. */
+int pbr_render_frame( pbr_ctx* ctx, float seed, float pixelWeight, float pxDim, const pbr_camera* cam );
+
+/* Replaces the reference's readImageOutput -> host -> updateImageReadOnly round trip
+ * (PathTracer.cpp:61,66): imageOut becomes the next frame's imageIn, on the device. */
+int pbr_accumulate( pbr_ctx* ctx );
+
+/* n_frames x { pbr_render_frame( seeds[k], n/(n+1) with n = first_sample_count + k ) ;
+ * pbr_accumulate } in ONE launch with the accumulator in registers — bit-identical to the
+ * frame-by-frame sequence.  Needs cam->focusPoint < 0 (depth of field reads another pixel's
+ * previous-frame value, pathtracing.cl:58-65): returns PBR_EINVAL otherwise.  The result is
+ * left in imageOut AND imageIn (ready to continue). */
+int pbr_render( pbr_ctx* ctx, uint32_t first_sample_count, uint32_t n_frames, const float* seeds, float pxDim, const pbr_camera* cam );
+
+/* CL::readImageOutput( imageOut ) / ( imageDebug ) (PathTracer.cpp:66-67).  With tile sharding
+ * only this rank's tiles are meaningful (others read 0). */
+int pbr_read_output( pbr_ctx* ctx, float* rgba );
+int pbr_read_debug( pbr_ctx* ctx, float* rgba );
+
+int pbr_get_counters( pbr_ctx* ctx, pbr_counters* out );
+/* CL::getKernelTimes (source/CL.cpp:480-488): device time of the last launch, HIP events. */
+double pbr_last_kernel_ms( const pbr_ctx* ctx );
+
+/* ---- multi-GPU tile exchange (device pointers; the caller runs the RCCL all-gather) ---- */
+
+/* Bytes of this rank's compact tile buffer: ceil( tiles / tile_world ) * 1024. */
+uint64_t pbr_tile_bytes( const pbr_ctx* ctx );
+/* Copy this rank's tiles of imageOut (local tile j = global tile j * tile_world + tile_rank,
+ * 64 pixels x RGBA32F each) to d_dst on this context's stream and wait. */
+int pbr_export_tiles( pbr_ctx* ctx, void* d_dst );
+/* d_all = tile_world consecutive rank buffers (all-gather layout).  Scatters every tile into
+ * this context's full-frame buffer; the context's own sharding is unchanged. */
+int pbr_import_tiles( pbr_ctx* ctx, const void* d_all );
+/* The full frame assembled by the last pbr_import_tiles, row-major W x H RGBA32F. */
+int pbr_read_full( pbr_ctx* ctx, float* rgba );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+"""ctypes binding of the CPU oracle (oracle/pt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product never imports this module.  PARITY UNPINNED (see pt_oracle.h).
+
+The oracle's structs are layout-identical to the C ABI's wire formats (both are the
+reference's host structs, source/PathTracer.h:25-73), so a pbr_scene_desc / pbr_camera built
+by the host library is handed to the oracle by reinterpretation, never by conversion.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_SRC = [os.path.join(_HERE, "pt_oracle.c"), os.path.join(_HERE, "pt_oracle.h")]
+
+
+def build(force=False):
+    stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in _SRC)
+    if stale:
+        subprocess.check_call([
+            "gcc", "-O2", "-std=c11", "-ffp-contract=off", "-mfma", "-mavx2", "-fopenmp", "-fPIC", "-shared",
+            "-o", _LIB, _SRC[0], "-lm"])
+    return _LIB
+
+
+class OrcConfig(ctypes.Structure):
+    _fields_ = [
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("brdf", ctypes.c_int32),
+        ("shadow_rays", ctypes.c_int32), ("max_depth", ctypes.c_int32), ("max_added_depth", ctypes.c_int32),
+        ("samples", ctypes.c_int32), ("num_nodes", ctypes.c_int32), ("num_lights", ctypes.c_int32),
+        ("anti_aliasing", ctypes.c_float), ("sky_light", ctypes.c_float * 4),
+    ]
+
+
+class OrcScene(ctypes.Structure):
+    _fields_ = [
+        ("bvh", ctypes.c_void_p), ("facesV", ctypes.c_void_p), ("vertices", ctypes.c_void_p),
+        ("materials", ctypes.c_void_p), ("lights", ctypes.c_void_p),
+        ("num_faces", ctypes.c_uint32), ("num_vertices", ctypes.c_uint32), ("num_materials", ctypes.c_uint32),
+    ]
+
+
+class OrcCounters(ctypes.Structure):
+    _fields_ = [("nodes", ctypes.c_uint64), ("tris", ctypes.c_uint64), ("hits", ctypes.c_uint64), ("paths", ctypes.c_uint64)]
+
+
+_fp = ctypes.POINTER(ctypes.c_float)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        try:
+            _lib = ctypes.CDLL(_LIB)
+        except OSError:
+            build(force=True)
+            _lib = ctypes.CDLL(_LIB)
+        _lib.orc_render_frame.argtypes = [
+            ctypes.POINTER(OrcScene), ctypes.POINTER(OrcConfig), ctypes.c_void_p,
+            ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(OrcCounters)]
+        _lib.orc_render_frame.restype = None
+        _lib.orc_trace_rays.argtypes = [
+            ctypes.POINTER(OrcScene), ctypes.POINTER(OrcConfig), _fp, ctypes.c_int,
+            _fp, ctypes.POINTER(ctypes.c_int32), _fp, ctypes.POINTER(ctypes.c_uint32)]
+        _lib.orc_trace_rays.restype = None
+        _lib.orc_math.argtypes = [ctypes.c_int, _fp, _fp, ctypes.c_int, _fp]
+        _lib.orc_math.restype = None
+        _lib.orc_brdf_eval.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_int, _fp]
+        _lib.orc_brdf_eval.restype = None
+        _lib.orc_new_ray.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_int, _fp]
+        _lib.orc_new_ray.restype = None
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+MATH_OPS = {"sin": 0, "cos": 1, "tan": 2, "acos": 3, "atan": 4, "pow": 5, "randhash": 6}
+
+
+def math(op, x, y=None):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(x if y is None else y, np.float32)
+    out = np.empty_like(x)
+    lib().orc_math(MATH_OPS[op], _ptr(x), _ptr(y), x.size, _ptr(out))
+    return out
+
+
+def scene_and_config(desc, cfg):
+    """(OrcScene, OrcConfig) from a pbr_scene_desc and a pbr_config (any objects with those fields)."""
+    s = OrcScene()
+    s.bvh, s.facesV, s.vertices, s.materials, s.lights = desc.bvh, desc.facesV, desc.vertices, desc.materials, desc.lights
+    s.num_faces, s.num_vertices, s.num_materials = desc.num_faces, desc.num_vertices, desc.num_materials
+    c = OrcConfig()
+    c.width, c.height, c.brdf = cfg.width, cfg.height, cfg.brdf
+    c.shadow_rays, c.max_depth, c.max_added_depth, c.samples = cfg.shadow_rays, cfg.max_depth, cfg.max_added_depth, cfg.samples
+    c.num_nodes, c.num_lights = desc.num_nodes, desc.num_lights
+    c.anti_aliasing = cfg.anti_aliasing
+    for k in range(4):
+        c.sky_light[k] = cfg.sky_light[k]
+    return s, c
+
+
+class Renderer:
+    """Frame-by-frame driver with the reference's host ping-pong (PathTracer.cpp:59-71)."""
+
+    def __init__(self, desc, cfg, threads=1):
+        self.scene, self.cfg = scene_and_config(desc, cfg)
+        self._keep = (desc, cfg)
+        self.threads = threads
+        self.width, self.height = int(cfg.width), int(cfg.height)
+        self.image = np.zeros((self.height, self.width, 4), np.float32)
+        self.debug = np.zeros_like(self.image)
+        self.counters = OrcCounters()
+
+    def render_frame(self, seed, pixel_weight, px_dim, cam, rows=None):
+        out = np.zeros_like(self.image)
+        y0, y1 = rows if rows is not None else (0, self.height)
+        lib().orc_render_frame(
+            ctypes.byref(self.scene), ctypes.byref(self.cfg), ctypes.addressof(cam),
+            seed, pixel_weight, px_dim, _ptr(self.image), _ptr(out), _ptr(self.debug),
+            y0, y1, self.threads, ctypes.byref(self.counters))
+        return out
+
+    def render(self, first_sample_count, seeds, px_dim, cam):
+        """== pbr_render: accumulate len(seeds) frames starting at sample count n."""
+        for k, seed in enumerate(np.asarray(seeds, np.float32)):
+            n = first_sample_count + k
+            weight = np.float32(n) / np.float32(n + 1)
+            self.image = self.render_frame(float(seed), float(weight), px_dim, cam)
+        return self.image
+
+    def counter_dict(self):
+        c = self.counters
+        return {"nodes": int(c.nodes), "tris": int(c.tris), "hits": int(c.hits), "paths": int(c.paths)}
+
+
+def trace_rays(desc, cfg, rays):
+    s, c = scene_and_config(desc, cfg)
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    n = rays.shape[0]
+    t = np.empty(n, np.float32)
+    face = np.empty(n, np.int32)
+    normal = np.empty((n, 3), np.float32)
+    counts = np.empty((n, 2), np.uint32)
+    lib().orc_trace_rays(
+        ctypes.byref(s), ctypes.byref(c), _ptr(rays), n, _ptr(t),
+        face.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(normal),
+        counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    return t, face, normal, counts

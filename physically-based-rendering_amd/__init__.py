@@ -1,0 +1,369 @@
+"""MI355X path-tracing core behind the sebadorn/Physically-based-Rendering dispatch surface.
+
+Python here is harness glue only (ctypes): the product is
+
+  csrc/libpbrhip.so    hand-written HIP kernels for gfx950 + the C ABI of include/pbr_hip.h
+  host/libpbrhost.so   the C++ host side (loaders, BVH builder, buffer packing, PathTracer)
+
+The directory name is not an importable identifier; load it with `pbr_loader.load()` (repo
+root), which registers it as module `pbr_amd`.  There is no CPU fallback: if libpbrhip.so is
+missing and cannot be built, importing this package raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+PBR_OK = 0
+
+
+class Float4(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_float), ("y", ctypes.c_float), ("z", ctypes.c_float), ("w", ctypes.c_float)]
+
+
+class Camera(ctypes.Structure):
+    """pbr_camera / camera_cl (source/PathTracer.h:25-32), 80 bytes."""
+    _fields_ = [("eye", Float4), ("w", Float4), ("u", Float4), ("v", Float4),
+                ("focusPoint", ctypes.c_int32 * 2), ("lense", ctypes.c_float * 2)]
+
+
+class SceneDesc(ctypes.Structure):
+    """pbr_scene_desc"""
+    _fields_ = [
+        ("bvh", ctypes.c_void_p), ("num_nodes", ctypes.c_uint32),
+        ("facesV", ctypes.c_void_p), ("facesN", ctypes.c_void_p), ("num_faces", ctypes.c_uint32),
+        ("vertices", ctypes.c_void_p), ("num_vertices", ctypes.c_uint32),
+        ("normals", ctypes.c_void_p), ("num_normals", ctypes.c_uint32),
+        ("materials", ctypes.c_void_p), ("num_materials", ctypes.c_uint32),
+        ("brdf", ctypes.c_uint32),
+        ("lights", ctypes.c_void_p), ("num_lights", ctypes.c_uint32),
+    ]
+
+
+class Config(ctypes.Structure):
+    """pbr_config"""
+    _fields_ = [
+        ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("brdf", ctypes.c_uint32),
+        ("shadow_rays", ctypes.c_uint32), ("max_depth", ctypes.c_uint32), ("max_added_depth", ctypes.c_uint32),
+        ("samples", ctypes.c_uint32), ("anti_aliasing", ctypes.c_float), ("phong_tessellation", ctypes.c_float),
+        ("sky_light", ctypes.c_float * 4), ("tile_world", ctypes.c_uint32), ("tile_rank", ctypes.c_uint32),
+    ]
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [("nodes", ctypes.c_uint64), ("tris", ctypes.c_uint64), ("hits", ctypes.c_uint64), ("paths", ctypes.c_uint64)]
+
+
+def _load(path, builder):
+    if not os.path.exists(path):
+        builder()
+    try:
+        return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        builder(force=True)
+        return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
+try:
+    hip = _load(_build.HIP_LIB, _build.build_hip)
+    host = _load(_build.HOST_LIB, _build.build_host)
+except Exception as exc:  # no fallback by design
+    raise ImportError("the HIP core (csrc/libpbrhip.so) / host library could not be loaded or built: %s" % exc)
+
+_fp = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+
+hip.pbr_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
+hip.pbr_destroy.argtypes = [_vp]
+hip.pbr_destroy.restype = None
+hip.pbr_last_error.argtypes = [_vp]
+hip.pbr_last_error.restype = ctypes.c_char_p
+hip.pbr_upload_scene.argtypes = [_vp, ctypes.POINTER(SceneDesc)]
+hip.pbr_configure.argtypes = [_vp, ctypes.POINTER(Config)]
+hip.pbr_write_input.argtypes = [_vp, _fp]
+hip.pbr_reset_accum.argtypes = [_vp]
+hip.pbr_render_frame.argtypes = [_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.POINTER(Camera)]
+hip.pbr_accumulate.argtypes = [_vp]
+hip.pbr_render.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32, _fp, ctypes.c_float, ctypes.POINTER(Camera)]
+hip.pbr_read_output.argtypes = [_vp, _fp]
+hip.pbr_read_debug.argtypes = [_vp, _fp]
+hip.pbr_read_full.argtypes = [_vp, _fp]
+hip.pbr_get_counters.argtypes = [_vp, ctypes.POINTER(Counters)]
+hip.pbr_last_kernel_ms.argtypes = [_vp]
+hip.pbr_last_kernel_ms.restype = ctypes.c_double
+hip.pbr_tile_bytes.argtypes = [_vp]
+hip.pbr_tile_bytes.restype = ctypes.c_uint64
+hip.pbr_export_tiles.argtypes = [_vp, _vp]
+hip.pbr_import_tiles.argtypes = [_vp, _vp]
+
+host.pbrh_last_error.restype = ctypes.c_char_p
+host.pbrh_cfg_set.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+host.pbrh_cfg_get.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+host.pbrh_cfg_load.argtypes = [ctypes.c_char_p]
+host.pbrh_scene_load_obj.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+host.pbrh_scene_load_obj.restype = _vp
+host.pbrh_scene_generate.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32]
+host.pbrh_scene_generate.restype = _vp
+host.pbrh_scene_destroy.argtypes = [_vp]
+host.pbrh_scene_destroy.restype = None
+host.pbrh_scene_desc.argtypes = [_vp, ctypes.POINTER(SceneDesc)]
+host.pbrh_scene_info.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint32)]
+host.pbrh_scene_config.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Config)]
+host.pbrh_scene_camera.argtypes = [_vp, ctypes.POINTER(Camera)]
+host.pbrh_camera_lookat.argtypes = [_fp, _fp, ctypes.POINTER(Camera)]
+host.pbrh_pixel_dimension.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_float]
+host.pbrh_pixel_dimension.restype = ctypes.c_float
+host.pbrh_pt_create.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+host.pbrh_pt_create.restype = _vp
+host.pbrh_pt_destroy.argtypes = [_vp]
+host.pbrh_pt_destroy.restype = None
+host.pbrh_pt_init.argtypes = [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32]
+host.pbrh_pt_generate_image.argtypes = [_vp, _fp, _fp]
+host.pbrh_pt_generate_images.argtypes = [_vp, ctypes.c_uint32, _fp]
+host.pbrh_pt_set_focus.argtypes = [_vp, ctypes.c_int, ctypes.c_int]
+host.pbrh_pt_reset_sample_count.argtypes = [_vp]
+host.pbrh_pt_sample_count.argtypes = [_vp]
+host.pbrh_pt_sample_count.restype = ctypes.c_uint32
+host.pbrh_pt_context.argtypes = [_vp]
+host.pbrh_pt_context.restype = _vp
+host.pbrh_pt_camera.argtypes = [_vp, ctypes.POINTER(Camera)]
+
+
+class PbrError(RuntimeError):
+    pass
+
+
+def _as_fp(a):
+    return a.ctypes.data_as(_fp)
+
+
+# ----------------------------------------------------------------------------------------------
+# Cfg (source/Cfg.h) — keys as in the reference's config.json
+# ----------------------------------------------------------------------------------------------
+
+def cfg_reset():
+    host.pbrh_cfg_reset()
+
+
+def cfg_set(**kv):
+    """cfg_set(**{"render.max_depth": 4})"""
+    for k, v in kv.items():
+        if isinstance(v, bool):
+            v = "true" if v else "false"
+        host.pbrh_cfg_set(k.encode(), str(v).encode())
+
+
+def cfg_get(key):
+    buf = ctypes.create_string_buffer(256)
+    host.pbrh_cfg_get(key.encode(), buf, 256)
+    return buf.value.decode()
+
+
+def pixel_dimension(width, height, fov=45.0):
+    return float(host.pbrh_pixel_dimension(width, height, fov))
+
+
+# ----------------------------------------------------------------------------------------------
+# Host scene: loader / generator + BVH + packed buffers (GLWidget::loadModel without GL)
+# ----------------------------------------------------------------------------------------------
+
+class HostScene:
+    def __init__(self, handle):
+        if not handle:
+            raise PbrError(host.pbrh_last_error().decode())
+        self._h = handle
+        self.desc = SceneDesc()
+        host.pbrh_scene_desc(self._h, ctypes.byref(self.desc))
+        info = (ctypes.c_uint32 * 10)()
+        host.pbrh_scene_info(self._h, info)
+        keys = ("flat_nodes", "faces", "vertices", "materials", "lights", "tree_nodes", "leaves", "depth", "skipped", "objects")
+        self.info = dict(zip(keys, [int(v) for v in info]))
+
+    @classmethod
+    def load_obj(cls, directory, filename):
+        if not directory.endswith("/"):
+            directory += "/"
+        return cls(host.pbrh_scene_load_obj(directory.encode(), filename.encode()))
+
+    @classmethod
+    def generate(cls, kind, seed=1, triangles=0):
+        return cls(host.pbrh_scene_generate(kind.encode(), seed, triangles))
+
+    def close(self):
+        if self._h:
+            host.pbrh_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def config(self, width, height):
+        cfg = Config()
+        host.pbrh_scene_config(self._h, width, height, ctypes.byref(cfg))
+        return cfg
+
+    def camera(self):
+        cam = Camera()
+        host.pbrh_scene_camera(self._h, ctypes.byref(cam))
+        return cam
+
+    def _array(self, ptr, count, dtype, width):
+        if not ptr or count == 0:
+            return np.zeros((0, width), dtype)
+        n = count * width
+        buf = (ctypes.c_uint32 * n).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(count, width).copy()
+
+    def arrays(self):
+        """Copies of the flat wire-format arrays (for tests)."""
+        d = self.desc
+        mat_floats = 12 if d.brdf == 0 else 16
+        return {
+            "bvh": self._array(d.bvh, d.num_nodes, np.float32, 8),
+            "facesV": self._array(d.facesV, d.num_faces, np.uint32, 4),
+            "vertices": self._array(d.vertices, d.num_vertices, np.float32, 4),
+            "materials": self._array(d.materials, d.num_materials, np.float32, mat_floats),
+            "lights": self._array(d.lights, max(1, d.num_lights), np.float32, 12),
+        }
+
+
+# ----------------------------------------------------------------------------------------------
+# Device context: the C ABI of include/pbr_hip.h
+# ----------------------------------------------------------------------------------------------
+
+class Device:
+    def __init__(self, device=0):
+        self._ctx = _vp()
+        status = hip.pbr_create(device, ctypes.byref(self._ctx))
+        if status != PBR_OK:
+            msg = hip.pbr_last_error(self._ctx).decode() if self._ctx else "pbr_create failed"
+            if self._ctx:
+                hip.pbr_destroy(self._ctx)
+                self._ctx = None
+            raise PbrError(msg)
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            hip.pbr_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, status):
+        if status != PBR_OK:
+            raise PbrError("%d: %s" % (status, hip.pbr_last_error(self._ctx).decode()))
+
+    def upload_scene(self, desc):
+        self._check(hip.pbr_upload_scene(self._ctx, ctypes.byref(desc)))
+
+    def configure(self, cfg):
+        self._check(hip.pbr_configure(self._ctx, ctypes.byref(cfg)))
+        self.width, self.height = int(cfg.width), int(cfg.height)
+
+    def write_input(self, rgba):
+        rgba = np.ascontiguousarray(rgba, np.float32)
+        assert rgba.size == self.width * self.height * 4
+        self._check(hip.pbr_write_input(self._ctx, _as_fp(rgba)))
+
+    def reset_accum(self):
+        self._check(hip.pbr_reset_accum(self._ctx))
+
+    def render_frame(self, seed, pixel_weight, px_dim, cam):
+        self._check(hip.pbr_render_frame(self._ctx, seed, pixel_weight, px_dim, ctypes.byref(cam)))
+
+    def accumulate(self):
+        self._check(hip.pbr_accumulate(self._ctx))
+
+    def render(self, first_sample_count, seeds, px_dim, cam):
+        seeds = np.ascontiguousarray(seeds, np.float32)
+        self._check(hip.pbr_render(self._ctx, first_sample_count, len(seeds), _as_fp(seeds), px_dim, ctypes.byref(cam)))
+
+    def _read(self, fn):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(fn(self._ctx, _as_fp(out)))
+        return out
+
+    def read_output(self):
+        return self._read(hip.pbr_read_output)
+
+    def read_debug(self):
+        return self._read(hip.pbr_read_debug)
+
+    def read_full(self):
+        return self._read(hip.pbr_read_full)
+
+    def counters(self):
+        c = Counters()
+        self._check(hip.pbr_get_counters(self._ctx, ctypes.byref(c)))
+        return {"nodes": int(c.nodes), "tris": int(c.tris), "hits": int(c.hits), "paths": int(c.paths)}
+
+    def last_kernel_ms(self):
+        return float(hip.pbr_last_kernel_ms(self._ctx))
+
+    def tile_bytes(self):
+        return int(hip.pbr_tile_bytes(self._ctx))
+
+    def export_tiles(self, device_ptr):
+        self._check(hip.pbr_export_tiles(self._ctx, device_ptr))
+
+    def import_tiles(self, device_ptr):
+        self._check(hip.pbr_import_tiles(self._ctx, device_ptr))
+
+
+def frame_seeds(first_sample_count, n_frames, seed_step=0.0333):
+    """The fixed seed sequence that stands in for the reference's wall clock
+    (PathTracer.cpp:63,78-82): seed_k = step * (k + 1), evaluated in float32."""
+    k = np.arange(first_sample_count + 1, first_sample_count + n_frames + 1, dtype=np.float32)
+    return (np.float32(seed_step) * k).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# PathTracer driver (host/path_tracer.h), as the reference's GLWidget would use it
+# ----------------------------------------------------------------------------------------------
+
+class PathTracer:
+    def __init__(self, device, width, height):
+        self._h = host.pbrh_pt_create(device, width, height)
+        if not self._h:
+            raise PbrError(host.pbrh_last_error().decode())
+        self.width, self.height = width, height
+
+    def close(self):
+        if getattr(self, "_h", None):
+            host.pbrh_pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def initOpenCLBuffers(self, scene, tile_world=1, tile_rank=0):
+        if host.pbrh_pt_init(self._h, scene._h, tile_world, tile_rank) != 0:
+            raise PbrError(host.pbrh_last_error().decode())
+
+    def generateImage(self, with_debug=False):
+        img = np.empty((self.height, self.width, 4), np.float32)
+        dbg = np.empty_like(img) if with_debug else None
+        if host.pbrh_pt_generate_image(self._h, _as_fp(img), _as_fp(dbg) if with_debug else None) != 0:
+            raise PbrError(host.pbrh_last_error().decode())
+        return (img, dbg) if with_debug else img
+
+    def generateImages(self, frames):
+        img = np.empty((self.height, self.width, 4), np.float32)
+        if host.pbrh_pt_generate_images(self._h, frames, _as_fp(img)) != 0:
+            raise PbrError(host.pbrh_last_error().decode())
+        return img
+
+    def setFocus(self, x, y):
+        host.pbrh_pt_set_focus(self._h, x, y)
+
+    def resetSampleCount(self):
+        host.pbrh_pt_reset_sample_count(self._h)
+
+    def sampleCount(self):
+        return int(host.pbrh_pt_sample_count(self._h))

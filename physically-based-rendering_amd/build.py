@@ -1,0 +1,97 @@
+"""Builds the native parts in-tree.
+
+  csrc/libpbrhip.so   HIP core + C ABI (hipcc, gfx950)             -- the product
+  host/libpbrhost.so  C++ host side (BVH builder, loaders, driver) -- the product's caller side
+  ../oracle/liboracle.so  CPU oracle (gcc)                         -- test infrastructure
+
+Contraction is OFF everywhere (-ffp-contract=off): the path's arithmetic is defined
+operation by operation, and the HIP kernels must agree with the oracle bit for bit.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+INCLUDE = os.path.join(ROOT, "include")
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+ORACLE = os.path.join(ROOT, "oracle")
+
+HIP_LIB = os.path.join(CSRC, "libpbrhip.so")
+HOST_LIB = os.path.join(HOST, "libpbrhost.so")
+ORACLE_LIB = os.path.join(ORACLE, "liboracle.so")
+
+HOST_SOURCES = ["Cfg.cpp", "model_io.cpp", "bvh_builder.cpp", "scene_gen.cpp", "path_tracer.cpp", "host_capi.cpp"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return proc.stdout
+
+
+def build_hip(force=False, extra_flags=()):
+    sources = [os.path.join(CSRC, f) for f in ("pbr_hip.hip", "pt_kernel.hpp", "pt_math.hpp")] + [os.path.join(INCLUDE, "pbr_hip.h")]
+    if not force and not _stale(HIP_LIB, sources):
+        return HIP_LIB
+    cmd = [
+        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+        "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC, *extra_flags,
+        "-o", HIP_LIB, os.path.join(CSRC, "pbr_hip.hip"),
+    ]
+    _run(cmd)
+    return HIP_LIB
+
+
+def build_host(force=False):
+    sources = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".cpp", ".h"))] + [os.path.join(INCLUDE, "pbr_hip.h")]
+    build_hip()
+    if not force and not _stale(HOST_LIB, sources + [HIP_LIB]):
+        return HOST_LIB
+    cmd = [
+        "g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra",
+        "-I", INCLUDE, "-I", HOST,
+        *[os.path.join(HOST, f) for f in HOST_SOURCES],
+        "-o", HOST_LIB, "-L", CSRC, "-lpbrhip", "-Wl,-rpath,$ORIGIN/../csrc",
+    ]
+    _run(cmd)
+    return HOST_LIB
+
+
+def build_oracle(force=False):
+    sources = [os.path.join(ORACLE, f) for f in ("pt_oracle.c", "pt_oracle.h")]
+    if not force and not _stale(ORACLE_LIB, sources):
+        return ORACLE_LIB
+    cmd = [
+        "gcc", "-O2", "-std=c11", "-ffp-contract=off", "-mfma", "-mavx2", "-fopenmp", "-fPIC", "-shared",
+        "-o", ORACLE_LIB, os.path.join(ORACLE, "pt_oracle.c"), "-lm",
+    ]
+    _run(cmd)
+    return ORACLE_LIB
+
+
+def build_all(force=False):
+    return build_hip(force), build_host(force), build_oracle(force)
+
+
+if __name__ == "__main__":
+    for lib in build_all(force="--force" in sys.argv):
+        print(lib)

@@ -1,0 +1,639 @@
+// libpbrhip.so — implementation of include/pbr_hip.h: context, scene upload / re-layout,
+// configuration, launches, read-back and the multi-GPU tile exchange helpers.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pbr_hip.h"
+#include "pt_kernel.hpp"
+
+using ptk::DevParams;
+
+struct pbr_ctx {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	hipEvent_t evStart = nullptr, evStop = nullptr;
+	std::string error;
+	double lastKernelMs = 0.0;
+	int numCUs = 0;
+
+	// scene
+	bool hasScene = false;
+	float4* dNodes = nullptr;
+	float4* dTris = nullptr;
+	float4* dMats = nullptr;
+	float4* dLights = nullptr;
+	uint32_t numNodes = 0, numFaces = 0, numMaterials = 0, numLights = 0;
+	uint32_t sceneBrdf = 1;
+
+	// configuration + images
+	bool configured = false;
+	pbr_config cfg;
+	int tilesX = 0, tilesY = 0, numTiles = 0, numLocalTiles = 0;
+	float4* dImgIn = nullptr;
+	float4* dImgOut = nullptr;
+	float4* dImgDbg = nullptr;
+	float4* dRows = nullptr;       // W x H row-major staging for read-back / write_input
+	float4* dFull = nullptr;       // all tiles of the frame, filled by pbr_import_tiles
+	float* dSeeds = nullptr;
+	size_t seedCapacity = 0;
+	unsigned long long* dCounters = nullptr;
+	unsigned int* dWork = nullptr;
+};
+
+namespace {
+
+int fail( pbr_ctx* ctx, int code, const char* fmt, ... ) {
+	char buf[512];
+	va_list ap;
+	va_start( ap, fmt );
+	vsnprintf( buf, sizeof( buf ), fmt, ap );
+	va_end( ap );
+
+	if( ctx != nullptr ) {
+		ctx->error = buf;
+	}
+
+	return code;
+}
+
+#define HIP_TRY( ctx, call ) \
+	do { \
+		const hipError_t err__ = ( call ); \
+		if( err__ != hipSuccess ) { \
+			return fail( ctx, PBR_EDEVICE, "%s: %s", #call, hipGetErrorString( err__ ) ); \
+		} \
+	} while( 0 )
+
+void freeScene( pbr_ctx* ctx ) {
+	(void) hipFree( ctx->dNodes );
+	(void) hipFree( ctx->dTris );
+	(void) hipFree( ctx->dMats );
+	(void) hipFree( ctx->dLights );
+	ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dLights = nullptr;
+	ctx->hasScene = false;
+}
+
+void freeImages( pbr_ctx* ctx ) {
+	(void) hipFree( ctx->dImgIn );
+	(void) hipFree( ctx->dImgOut );
+	(void) hipFree( ctx->dImgDbg );
+	(void) hipFree( ctx->dRows );
+	(void) hipFree( ctx->dFull );
+	ctx->dImgIn = ctx->dImgOut = ctx->dImgDbg = ctx->dRows = ctx->dFull = nullptr;
+	ctx->configured = false;
+}
+
+// Is w an integer-valued float in [lo, hi]?
+bool integral( float w, double lo, double hi ) {
+	return ( w == std::floor( w ) ) && ( (double) w >= lo ) && ( (double) w <= hi );
+}
+
+typedef void ( *KernelFn )( const DevParams );
+
+KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights ) {
+	if( brdf == 0 ) {
+		if( lights ) {
+			return shadow ? ptk::pathTracing<0, true, true> : ptk::pathTracing<0, false, true>;
+		}
+		return ptk::pathTracing<0, false, false>;
+	}
+
+	if( lights ) {
+		return shadow ? ptk::pathTracing<1, true, true> : ptk::pathTracing<1, false, true>;
+	}
+	return ptk::pathTracing<1, false, false>;
+}
+
+int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* seeds,
+            bool explicitWeight, float weight, float pxDim, const pbr_camera* cam ) {
+	if( !ctx->hasScene || !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "render before pbr_upload_scene / pbr_configure" );
+	}
+	if( cam == nullptr || seeds == nullptr || nFrames == 0 ) {
+		return fail( ctx, PBR_EINVAL, "render: null camera / seeds or zero frames" );
+	}
+	if( ctx->cfg.brdf != ctx->sceneBrdf ) {
+		return fail( ctx, PBR_EINVAL, "configured BRDF %u does not match the uploaded materials (BRDF %u)", ctx->cfg.brdf, ctx->sceneBrdf );
+	}
+
+	const bool dof = ( cam->focusPoint[0] >= 0 && cam->focusPoint[1] >= 0 );
+
+	if( dof && nFrames > 1 ) {
+		return fail( ctx, PBR_EINVAL, "depth of field reads the previous frame of another pixel: render one frame per call" );
+	}
+	if( dof && ctx->cfg.tile_world > 1 ) {
+		return fail( ctx, PBR_EINVAL, "depth of field needs the focus pixel's tile on this device (tile_world must be 1)" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+
+	if( ctx->seedCapacity < nFrames ) {
+		(void) hipFree( ctx->dSeeds );
+		ctx->dSeeds = nullptr;
+		ctx->seedCapacity = 0;
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dSeeds, sizeof( float ) * nFrames ) );
+		ctx->seedCapacity = nFrames;
+	}
+
+	HIP_TRY( ctx, hipMemcpyAsync( ctx->dSeeds, seeds, sizeof( float ) * nFrames, hipMemcpyHostToDevice, ctx->stream ) );
+	HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, sizeof( unsigned int ), ctx->stream ) );
+
+	DevParams P;
+	std::memset( &P, 0, sizeof( P ) );
+	P.nodes = ctx->dNodes;
+	P.tris = ctx->dTris;
+	P.mats = ctx->dMats;
+	P.lights = ctx->dLights;
+	P.imgIn = ctx->dImgIn;
+	P.imgOut = ctx->dImgOut;
+	P.imgDbg = ctx->dImgDbg;
+	P.seeds = ctx->dSeeds;
+	P.counters = ctx->dCounters;
+	P.workCounter = ctx->dWork;
+
+	const float* src[4] = { &cam->eye.x, &cam->w.x, &cam->u.x, &cam->v.x };
+	float* dst[4] = { P.eye, P.cw, P.cu, P.cv };
+
+	for( int i = 0; i < 4; i++ ) {
+		for( int k = 0; k < 3; k++ ) {
+			dst[i][k] = src[i][k];
+		}
+	}
+
+	P.focusX = cam->focusPoint[0];
+	P.focusY = cam->focusPoint[1];
+	P.lenseFocal = cam->lense[0];
+	P.lenseAperture = cam->lense[1];
+	P.width = (int) ctx->cfg.width;
+	P.height = (int) ctx->cfg.height;
+	P.tilesX = ctx->tilesX;
+	P.numLocalTiles = ctx->numLocalTiles;
+	P.tileWorld = (int) ctx->cfg.tile_world;
+	P.tileRank = (int) ctx->cfg.tile_rank;
+	P.numNodes = (int) ctx->numNodes;
+	P.numLights = (int) ctx->numLights;
+	P.maxDepth = (int) ctx->cfg.max_depth;
+	P.maxAddedDepth = (int) ctx->cfg.max_added_depth;
+	P.samples = (int) ctx->cfg.samples;
+	P.nFrames = (int) nFrames;
+	P.firstCount = (int) firstCount;
+	P.useExplicitWeight = explicitWeight ? 1 : 0;
+	P.explicitWeight = weight;
+	P.pxDim = pxDim;
+	P.antiAliasing = ctx->cfg.anti_aliasing;
+	P.sky[0] = ctx->cfg.sky_light[0];
+	P.sky[1] = ctx->cfg.sky_light[1];
+	P.sky[2] = ctx->cfg.sky_light[2];
+
+	const bool lights = ( ctx->numLights > 0 );
+	const bool shadow = ( ctx->cfg.shadow_rays == 1 ) && lights;
+	const KernelFn kernel = pickKernel( ctx->cfg.brdf, shadow, lights );
+
+	// persistent grid: as many 4-wave blocks as stay resident, never more than there are tiles
+	int blocksPerCU = 0;
+	HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, 256, 0 ) );
+	blocksPerCU = ( blocksPerCU < 1 ) ? 1 : blocksPerCU;
+	int blocks = ctx->numCUs * blocksPerCU;
+	const int needed = ( ctx->numLocalTiles + 3 ) / 4;
+	blocks = ( blocks > needed ) ? needed : blocks;
+	blocks = ( blocks < 1 ) ? 1 : blocks;
+
+	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
+	hipLaunchKernelGGL( kernel, dim3( (unsigned) blocks ), dim3( 256 ), 0, ctx->stream, P );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+
+	float ms = 0.0f;
+	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
+	ctx->lastKernelMs = (double) ms;
+
+	return PBR_OK;
+}
+
+int readTiled( pbr_ctx* ctx, const float4* tiles, float* rgba, int tileWorld, int tileRank ) {
+	if( !ctx->configured || tiles == nullptr ) {
+		return fail( ctx, PBR_ESTATE, "read before pbr_configure (or before pbr_import_tiles)" );
+	}
+	if( rgba == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "read: null destination" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	const dim3 block( 64, 4 );
+	const dim3 grid( ( ctx->cfg.width + 63 ) / 64, ( ctx->cfg.height + 3 ) / 4 );
+	hipLaunchKernelGGL( ptk::untile, grid, block, 0, ctx->stream, tiles, ctx->dRows,
+		(int) ctx->cfg.width, (int) ctx->cfg.height, ctx->tilesX, tileWorld, tileRank );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipMemcpyAsync( rgba, ctx->dRows, sizeof( float4 ) * ctx->cfg.width * ctx->cfg.height, hipMemcpyDeviceToHost, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	return PBR_OK;
+}
+
+}  // namespace
+
+
+extern "C" {
+
+int pbr_create( int device, pbr_ctx** out ) {
+	if( out == nullptr ) {
+		return PBR_EINVAL;
+	}
+
+	pbr_ctx* ctx = new pbr_ctx();
+	*out = ctx;
+	ctx->device = device;
+
+	int count = 0;
+	hipError_t err = hipGetDeviceCount( &count );
+
+	if( err != hipSuccess || count <= 0 ) {
+		return fail( ctx, PBR_EDEVICE, "no HIP device available (%s); this library has no CPU path", hipGetErrorString( err ) );
+	}
+	if( device < 0 || device >= count ) {
+		return fail( ctx, PBR_EINVAL, "device %d out of range (%d devices)", device, count );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( device ) );
+	hipDeviceProp_t prop;
+	HIP_TRY( ctx, hipGetDeviceProperties( &prop, device ) );
+	ctx->numCUs = prop.multiProcessorCount;
+	HIP_TRY( ctx, hipStreamCreateWithFlags( &ctx->stream, hipStreamNonBlocking ) );
+	HIP_TRY( ctx, hipEventCreate( &ctx->evStart ) );
+	HIP_TRY( ctx, hipEventCreate( &ctx->evStop ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dCounters, sizeof( unsigned long long ) * 4 ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWork, sizeof( unsigned int ) ) );
+	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * 4 ) );
+
+	return PBR_OK;
+}
+
+void pbr_destroy( pbr_ctx* ctx ) {
+	if( ctx == nullptr ) {
+		return;
+	}
+
+	if( ctx->stream != nullptr ) {
+		(void) hipSetDevice( ctx->device );
+		(void) hipStreamSynchronize( ctx->stream );
+		freeScene( ctx );
+		freeImages( ctx );
+		(void) hipFree( ctx->dSeeds );
+		(void) hipFree( ctx->dCounters );
+		(void) hipFree( ctx->dWork );
+		(void) hipEventDestroy( ctx->evStart );
+		(void) hipEventDestroy( ctx->evStop );
+		(void) hipStreamDestroy( ctx->stream );
+	}
+
+	delete ctx;
+}
+
+const char* pbr_last_error( const pbr_ctx* ctx ) {
+	return ( ctx != nullptr ) ? ctx->error.c_str() : "null context";
+}
+
+int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
+	if( ctx == nullptr || ctx->stream == nullptr ) {
+		return fail( ctx, PBR_ESTATE, "context is not usable" );
+	}
+	if( s == nullptr || s->bvh == nullptr || s->facesV == nullptr || s->vertices == nullptr || s->materials == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "scene: null array" );
+	}
+	if( s->num_nodes < 2 || s->num_faces == 0 || s->num_vertices == 0 || s->num_materials == 0 ) {
+		return fail( ctx, PBR_EINVAL, "scene: needs >= 2 BVH nodes (the root is never tested, pt_bvh.cl:84), faces, vertices and materials" );
+	}
+	if( s->brdf > 1 ) {
+		return fail( ctx, PBR_EINVAL, "scene: brdf must be 0 or 1" );
+	}
+	if( s->num_lights > 0 && s->lights == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "scene: num_lights > 0 but lights is null" );
+	}
+	if( s->num_nodes > ( 1u << 24 ) || s->num_faces > ( 1u << 24 ) ) {
+		return fail( ctx, PBR_EINVAL, "scene: node / face indices are stored as floats and must stay below 2^24" );
+	}
+
+	// ---- nodes: validate every link the walk can follow, convert the float links to ints ----
+	std::vector<float4> nodes( (size_t) s->num_nodes * 2 );
+
+	for( uint32_t i = 0; i < s->num_nodes; i++ ) {
+		const pbr_bvh_node& n = s->bvh[i];
+		int face0, link;
+
+		if( n.bbMin.w == -1.0f ) {
+			// container node: miss link in [-1, N) (the walk stops outside (0, N), pt_bvh.cl:122)
+			if( !integral( n.bbMax.w, -1.0, (double) s->num_nodes - 1.0 ) ) {
+				return fail( ctx, PBR_EINVAL, "node %u: miss link %g is not an index", i, (double) n.bbMax.w );
+			}
+
+			face0 = -1;
+			link = (int) n.bbMax.w;
+		}
+		else if( integral( n.bbMin.w, 0.0, (double) s->num_faces - 1.0 ) ) {
+			if( !( n.bbMax.w == -1.0f || integral( n.bbMax.w, 0.0, (double) s->num_faces - 1.0 ) ) ) {
+				return fail( ctx, PBR_EINVAL, "node %u: second face %g is not an index", i, (double) n.bbMax.w );
+			}
+
+			face0 = (int) n.bbMin.w;
+			link = (int) n.bbMax.w;
+		}
+		else {
+			return fail( ctx, PBR_EINVAL, "node %u: bbMin.w = %g is neither -1 nor a face index", i, (double) n.bbMin.w );
+		}
+
+		nodes[(size_t) i * 2 + 0] = make_float4( n.bbMin.x, n.bbMin.y, n.bbMin.z, __builtin_bit_cast( float, face0 ) );
+		nodes[(size_t) i * 2 + 1] = make_float4( n.bbMax.x, n.bbMax.y, n.bbMax.z, __builtin_bit_cast( float, link ) );
+	}
+
+	// ---- faces: gather the corners; store a, b - a, c - a (what pt_intersect.cl:98-99 computes) ----
+	std::vector<float4> tris( (size_t) s->num_faces * 3 );
+
+	for( uint32_t f = 0; f < s->num_faces; f++ ) {
+		const pbr_uint4& fv = s->facesV[f];
+
+		if( fv.x >= s->num_vertices || fv.y >= s->num_vertices || fv.z >= s->num_vertices ) {
+			return fail( ctx, PBR_EINVAL, "face %u: vertex index out of range", f );
+		}
+		if( fv.w >= s->num_materials ) {
+			return fail( ctx, PBR_EINVAL, "face %u: material index %u out of range (faces without usemtl carry -1)", f, fv.w );
+		}
+
+		const pbr_float4& a = s->vertices[fv.x];
+		const pbr_float4& b = s->vertices[fv.y];
+		const pbr_float4& c = s->vertices[fv.z];
+		const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+		const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+		const int material = (int) fv.w;
+
+		tris[(size_t) f * 3 + 0] = make_float4( a.x, a.y, a.z, e1x );
+		tris[(size_t) f * 3 + 1] = make_float4( e1y, e1z, e2x, e2y );
+		tris[(size_t) f * 3 + 2] = make_float4( e2z, __builtin_bit_cast( float, material ), 0.0f, 0.0f );
+	}
+
+	// ---- materials: one 64-byte shape for both BRDFs ----
+	std::vector<float4> mats( (size_t) s->num_materials * 4 );
+
+	for( uint32_t i = 0; i < s->num_materials; i++ ) {
+		if( s->brdf == 0 ) {
+			const pbr_material_schlick& m = ( (const pbr_material_schlick*) s->materials )[i];
+			mats[(size_t) i * 4 + 0] = make_float4( m.data[0], m.data[1], m.data[2], m.data[3] );
+			mats[(size_t) i * 4 + 1] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+			mats[(size_t) i * 4 + 2] = make_float4( m.rgbDiff.x, m.rgbDiff.y, m.rgbDiff.z, 0.0f );
+			mats[(size_t) i * 4 + 3] = make_float4( m.rgbSpec.x, m.rgbSpec.y, m.rgbSpec.z, 0.0f );
+		}
+		else {
+			const pbr_material_sa& m = ( (const pbr_material_sa*) s->materials )[i];
+			mats[(size_t) i * 4 + 0] = make_float4( m.data[0], m.data[1], m.data[2], m.data[3] );
+			mats[(size_t) i * 4 + 1] = make_float4( m.data[4], m.data[5], 0.0f, 0.0f );
+			mats[(size_t) i * 4 + 2] = make_float4( m.rgbDiff.x, m.rgbDiff.y, m.rgbDiff.z, 0.0f );
+			mats[(size_t) i * 4 + 3] = make_float4( m.rgbSpec.x, m.rgbSpec.y, m.rgbSpec.z, 0.0f );
+		}
+	}
+
+	const uint32_t lightSlots = ( s->num_lights > 0 ) ? s->num_lights : 1;
+	std::vector<float4> lights( (size_t) lightSlots * 3, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );
+
+	for( uint32_t i = 0; i < s->num_lights; i++ ) {
+		const pbr_light& l = s->lights[i];
+		lights[(size_t) i * 3 + 0] = make_float4( l.pos.x, l.pos.y, l.pos.z, l.pos.w );
+		lights[(size_t) i * 3 + 1] = make_float4( l.rgb.x, l.rgb.y, l.rgb.z, l.rgb.w );
+		lights[(size_t) i * 3 + 2] = make_float4( l.data.x, l.data.y, l.data.z, l.data.w );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	freeScene( ctx );
+
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dNodes, sizeof( float4 ) * nodes.size() ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dTris, sizeof( float4 ) * tris.size() ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dMats, sizeof( float4 ) * mats.size() ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dLights, sizeof( float4 ) * lights.size() ) );
+	HIP_TRY( ctx, hipMemcpy( ctx->dNodes, nodes.data(), sizeof( float4 ) * nodes.size(), hipMemcpyHostToDevice ) );
+	HIP_TRY( ctx, hipMemcpy( ctx->dTris, tris.data(), sizeof( float4 ) * tris.size(), hipMemcpyHostToDevice ) );
+	HIP_TRY( ctx, hipMemcpy( ctx->dMats, mats.data(), sizeof( float4 ) * mats.size(), hipMemcpyHostToDevice ) );
+	HIP_TRY( ctx, hipMemcpy( ctx->dLights, lights.data(), sizeof( float4 ) * lights.size(), hipMemcpyHostToDevice ) );
+
+	ctx->numNodes = s->num_nodes;
+	ctx->numFaces = s->num_faces;
+	ctx->numMaterials = s->num_materials;
+	ctx->numLights = s->num_lights;
+	ctx->sceneBrdf = s->brdf;
+	ctx->hasScene = true;
+
+	return PBR_OK;
+}
+
+int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
+	if( ctx == nullptr || ctx->stream == nullptr ) {
+		return fail( ctx, PBR_ESTATE, "context is not usable" );
+	}
+	if( cfg == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "configure: null config" );
+	}
+	if( cfg->width == 0 || cfg->height == 0 || ( cfg->width & 7u ) || ( cfg->height & 7u ) ) {
+		return fail( ctx, PBR_EINVAL, "width / height must be non-zero multiples of 8 (opencl.localgroupsize, config.json:85)" );
+	}
+	if( cfg->brdf > 1 || cfg->shadow_rays > 1 ) {
+		return fail( ctx, PBR_EINVAL, "brdf and shadow_rays must be 0 or 1" );
+	}
+	if( cfg->max_depth == 0 || cfg->samples == 0 ) {
+		return fail( ctx, PBR_EINVAL, "max_depth and samples must be >= 1" );
+	}
+	if( cfg->phong_tessellation > 0.0f ) {
+		return fail( ctx, PBR_EINVAL, "Phong tessellation (pt_phongtess.cl) is not built" );
+	}
+	if( cfg->tile_world == 0 || cfg->tile_rank >= cfg->tile_world ) {
+		return fail( ctx, PBR_EINVAL, "tile_rank must be < tile_world, tile_world >= 1" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	freeImages( ctx );
+
+	ctx->cfg = *cfg;
+	ctx->tilesX = (int) ( cfg->width / 8 );
+	ctx->tilesY = (int) ( cfg->height / 8 );
+	ctx->numTiles = ctx->tilesX * ctx->tilesY;
+	// tiles t = j * world + rank, j = 0 .. : count those below numTiles
+	ctx->numLocalTiles = ( ctx->numTiles - (int) cfg->tile_rank + (int) cfg->tile_world - 1 ) / (int) cfg->tile_world;
+
+	// Every context can hold the full image (import_tiles scatters all ranks' tiles into imgOut).
+	const size_t fullBytes = sizeof( float4 ) * 64 * (size_t) ctx->numTiles;
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dImgIn, fullBytes ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dImgOut, fullBytes ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dImgDbg, fullBytes ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dRows, fullBytes ) );
+	HIP_TRY( ctx, hipMemset( ctx->dImgIn, 0, fullBytes ) );
+	HIP_TRY( ctx, hipMemset( ctx->dImgOut, 0, fullBytes ) );
+	HIP_TRY( ctx, hipMemset( ctx->dImgDbg, 0, fullBytes ) );
+	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * 4 ) );
+	ctx->configured = true;
+
+	return PBR_OK;
+}
+
+int pbr_write_input( pbr_ctx* ctx, const float* rgba ) {
+	if( ctx == nullptr || !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "write_input before pbr_configure" );
+	}
+	if( rgba == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "write_input: null source" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	HIP_TRY( ctx, hipMemcpyAsync( ctx->dRows, rgba, sizeof( float4 ) * ctx->cfg.width * ctx->cfg.height, hipMemcpyHostToDevice, ctx->stream ) );
+	const size_t n = (size_t) ctx->numLocalTiles * 64;
+	hipLaunchKernelGGL( ptk::retile, dim3( (unsigned) ( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, ctx->stream,
+		ctx->dRows, ctx->dImgIn, (int) ctx->cfg.width, ctx->numLocalTiles, ctx->tilesX, (int) ctx->cfg.tile_world, (int) ctx->cfg.tile_rank );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	return PBR_OK;
+}
+
+int pbr_reset_accum( pbr_ctx* ctx ) {
+	if( ctx == nullptr || !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "reset_accum before pbr_configure" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	const size_t fullBytes = sizeof( float4 ) * 64 * (size_t) ctx->numTiles;
+	HIP_TRY( ctx, hipMemsetAsync( ctx->dImgIn, 0, fullBytes, ctx->stream ) );
+	HIP_TRY( ctx, hipMemsetAsync( ctx->dCounters, 0, sizeof( unsigned long long ) * 4, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	return PBR_OK;
+}
+
+int pbr_render_frame( pbr_ctx* ctx, float seed, float pixelWeight, float pxDim, const pbr_camera* cam ) {
+	if( ctx == nullptr ) {
+		return PBR_EINVAL;
+	}
+
+	return launch( ctx, 0, 1, &seed, true, pixelWeight, pxDim, cam );
+}
+
+int pbr_accumulate( pbr_ctx* ctx ) {
+	if( ctx == nullptr || !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "accumulate before pbr_configure" );
+	}
+
+	float4* tmp = ctx->dImgIn;
+	ctx->dImgIn = ctx->dImgOut;
+	ctx->dImgOut = tmp;
+	return PBR_OK;
+}
+
+int pbr_render( pbr_ctx* ctx, uint32_t first_sample_count, uint32_t n_frames, const float* seeds, float pxDim, const pbr_camera* cam ) {
+	if( ctx == nullptr ) {
+		return PBR_EINVAL;
+	}
+	if( cam != nullptr && cam->focusPoint[0] >= 0 && cam->focusPoint[1] >= 0 ) {
+		return fail( ctx, PBR_EINVAL, "pbr_render needs focusPoint < 0; with depth of field call pbr_render_frame + pbr_accumulate per frame" );
+	}
+
+	const int status = launch( ctx, first_sample_count, n_frames, seeds, false, 0.0f, pxDim, cam );
+
+	if( status != PBR_OK ) {
+		return status;
+	}
+
+	// result in imageOut AND imageIn
+	const size_t bytes = sizeof( float4 ) * 64 * (size_t) ctx->numLocalTiles;
+	HIP_TRY( ctx, hipMemcpyAsync( ctx->dImgIn, ctx->dImgOut, bytes, hipMemcpyDeviceToDevice, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	return PBR_OK;
+}
+
+int pbr_read_output( pbr_ctx* ctx, float* rgba ) {
+	if( ctx == nullptr ) {
+		return PBR_EINVAL;
+	}
+	return readTiled( ctx, ctx->dImgOut, rgba, (int) ctx->cfg.tile_world, (int) ctx->cfg.tile_rank );
+}
+
+int pbr_read_debug( pbr_ctx* ctx, float* rgba ) {
+	if( ctx == nullptr ) {
+		return PBR_EINVAL;
+	}
+	return readTiled( ctx, ctx->dImgDbg, rgba, (int) ctx->cfg.tile_world, (int) ctx->cfg.tile_rank );
+}
+
+int pbr_get_counters( pbr_ctx* ctx, pbr_counters* out ) {
+	if( ctx == nullptr || out == nullptr || ctx->stream == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "get_counters: null argument" );
+	}
+
+	unsigned long long host[4] = { 0, 0, 0, 0 };
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	HIP_TRY( ctx, hipMemcpy( host, ctx->dCounters, sizeof( host ), hipMemcpyDeviceToHost ) );
+	out->nodes = host[0];
+	out->tris = host[1];
+	out->hits = host[2];
+	out->paths = host[3];
+	return PBR_OK;
+}
+
+double pbr_last_kernel_ms( const pbr_ctx* ctx ) {
+	return ( ctx != nullptr ) ? ctx->lastKernelMs : 0.0;
+}
+
+uint64_t pbr_tile_bytes( const pbr_ctx* ctx ) {
+	if( ctx == nullptr || !ctx->configured ) {
+		return 0;
+	}
+
+	const uint64_t perRank = (uint64_t) ( ( ctx->numTiles + (int) ctx->cfg.tile_world - 1 ) / (int) ctx->cfg.tile_world );
+	return perRank * 1024u;
+}
+
+int pbr_export_tiles( pbr_ctx* ctx, void* d_dst ) {
+	if( ctx == nullptr || !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "export_tiles before pbr_configure" );
+	}
+	if( d_dst == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "export_tiles: null destination" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	const size_t bytes = sizeof( float4 ) * 64 * (size_t) ctx->numLocalTiles;
+	HIP_TRY( ctx, hipMemsetAsync( d_dst, 0, (size_t) pbr_tile_bytes( ctx ), ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpyAsync( d_dst, ctx->dImgOut, bytes, hipMemcpyDeviceToDevice, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	return PBR_OK;
+}
+
+int pbr_import_tiles( pbr_ctx* ctx, const void* d_all ) {
+	if( ctx == nullptr || !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "import_tiles before pbr_configure" );
+	}
+	if( d_all == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "import_tiles: null source" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+
+	if( ctx->dFull == nullptr ) {
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dFull, sizeof( float4 ) * 64 * (size_t) ctx->numTiles ) );
+	}
+
+	const int perRank = ( ctx->numTiles + (int) ctx->cfg.tile_world - 1 ) / (int) ctx->cfg.tile_world;
+	const size_t n = (size_t) ctx->numTiles * 64;
+	hipLaunchKernelGGL( ptk::scatterGathered, dim3( (unsigned) ( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, ctx->stream,
+		(const float4*) d_all, ctx->dFull, ctx->numTiles, perRank, (int) ctx->cfg.tile_world );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	return PBR_OK;
+}
+
+int pbr_read_full( pbr_ctx* ctx, float* rgba ) {
+	if( ctx == nullptr ) {
+		return PBR_EINVAL;
+	}
+	return readTiled( ctx, ctx->dFull, rgba, 1, 0 );
+}
+
+}  // extern "C"

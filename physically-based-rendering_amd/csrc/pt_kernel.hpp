@@ -1,0 +1,998 @@
+// The path-tracing megakernel for gfx950.
+//
+// Replaces source/opencl/pathtracing.cl + pt_*.cl (one OpenCL work-item per pixel, one launch
+// per frame, accumulation through the host).  Here:
+//   * a wave64 owns one 8x8-pixel tile at a time, taken from a device-wide work counter
+//     (persistent waves: the grid is sized to the chip, not to the image);
+//   * each lane walks its pixel through ALL requested frames; a lane whose path ends starts its
+//     next path immediately (lane-local regeneration), so a wave iteration = one traversal +
+//     one shading step for 64 live paths regardless of how long individual paths are;
+//   * the running mean (pt_rgb.cl:9-21) stays in registers across frames; the framebuffer is
+//     tile-major (64 px x RGBA32F = 1 KiB per tile), so a wave reads / writes its tile with one
+//     fully coalesced 16 B-per-lane access;
+//   * BVH nodes stay 32 B (one node = two adjacent dwordx4 loads, links pre-converted to int);
+//     triangles are pre-gathered per face as {a, b-a, c-a, material} = 48 B, removing the
+//     facesV -> vertices indirection of pt_intersect.cl:146-149.
+// Per-pixel results are bit-identical to the per-frame reference schedule: a pixel's value
+// depends only on (seed_k, scene, its own previous value), pathtracing.cl:28,255,332.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pt_math.hpp"
+
+namespace ptk {
+
+using namespace ptm;
+
+#define EPSILON5 0.00001f
+#define NI_AIR 1.00028f
+#define PI_X2 6.28318530718f
+#define M_PI_D 0x1.921fb54442d18p+1
+#define M_PI_2_D 0x1.921fb54442d18p+0
+#define M_1_PI_D 0x1.45f306dc9c883p-2
+
+struct DevParams {
+	const float4* nodes;    // 2 x float4 per node: {min.xyz, face0|-1}, {max.xyz, face1|-1 or miss link|-1} (w = int bits)
+	const float4* tris;     // 3 x float4 per face: {a.xyz, e1.x}, {e1.y, e1.z, e2.x, e2.y}, {e2.z, material(int bits), 0, 0}
+	const float4* mats;     // 4 x float4 per material: {d, Ni, p|nu, rough|nv}, {Rs, Rd, 0, 0}, Kd, Ks
+	const float4* lights;   // 3 x float4 per light: pos, rgb, {type, radius, 0, 0}
+	const float4* imgIn;    // tile-major, local tiles
+	float4* imgOut;
+	float4* imgDbg;
+	const float* seeds;     // one per frame
+	unsigned long long* counters;  // nodes, tris, hits, paths
+	unsigned int* workCounter;
+
+	float eye[3], cw[3], cu[3], cv[3];
+	int focusX, focusY;
+	float lenseFocal, lenseAperture;
+
+	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
+	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
+	int nFrames, firstCount;
+	int useExplicitWeight;
+	float explicitWeight;
+	float pxDim, antiAliasing;
+	float sky[3];
+};
+
+struct Ray {
+	f3 origin, dir;
+};
+
+struct Material {
+	float d, Ni, p2, p3;  // p2 = p | nu, p3 = rough | nv
+	float Rs, Rd;
+	f3 Kd, Ks;
+};
+
+struct Hit {
+	float t;
+	int face;      // >= 0 face index; < 0: light -(i+1) (only with t == INF)
+};
+
+PT_DEV f3 ld3( const float* p ) { return mk3( p[0], p[1], p[2] ); }
+
+// rand, pt_utils.cl:39-44
+PT_DEV float rnd( float& seed ) {
+	seed += 1.0f;
+	return fract( sin1( seed ) * 43758.5453123f );
+}
+
+// fresnel, pt_utils.cl:53-56
+PT_DEV float fresnel( float u, float c ) {
+	const float v = 1.0f - u;
+	return c + ( 1.0f - c ) * v * v * v * v * v;
+}
+
+// jitter, pt_utils.cl:306-318
+PT_DEV f3 jitter( f3 nl, float phi, float sina, float cosa ) {
+	const f3 u = normalize( cross( yzx( nl ), nl ) );
+	const f3 v = normalize( cross( nl, u ) );
+	float sp, cp;
+	sincos( phi, &sp, &cp );
+	const f3 w = normalize( u * cp + v * sp );
+	return normalize( w * sina + nl * cosa );
+}
+
+PT_DEV Material loadMaterial( const DevParams& P, int index ) {
+	const float4 a = P.mats[index * 4 + 0];
+	const float4 b = P.mats[index * 4 + 1];
+	const float4 kd = P.mats[index * 4 + 2];
+	const float4 ks = P.mats[index * 4 + 3];
+	Material m;
+	m.d = a.x; m.Ni = a.y; m.p2 = a.z; m.p3 = a.w;
+	m.Rs = b.x; m.Rd = b.y;
+	m.Kd = mk3( kd.x, kd.y, kd.z );
+	m.Ks = mk3( ks.x, ks.y, ks.z );
+	return m;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Traversal
+// ---------------------------------------------------------------------------------------
+
+// intersectSphere, pt_intersect.cl:37-77 (d2 is compared with r, not r*r, as in the reference)
+PT_DEV bool intersectSphere( const Ray& ray, f3 pos, float r, float* tNear ) {
+	const f3 L = pos - ray.origin;
+	const float tca = dot( L, ray.dir );
+
+	if( tca < 0.0f ) {
+		return false;
+	}
+
+	const float d2 = dot( L, L ) - tca * tca;
+
+	if( d2 > r ) {
+		return false;
+	}
+
+	const float thc = sqrt1( r - d2 );
+	float t0 = tca - thc;
+	float t1 = tca + thc;
+
+	if( t0 > t1 ) {
+		const float tmp = t0; t0 = t1; t1 = tmp;
+	}
+
+	if( t0 < 0.0f ) {
+		t0 = t1;
+
+		if( t0 < 0.0f ) {
+			return false;
+		}
+	}
+
+	*tNear = t0;
+	return true;
+}
+
+// traverseLights, pt_bvh.cl:54-74
+PT_DEV void traverseLights( const DevParams& P, const Ray& ray, Hit& hit ) {
+	for( int i = 0; i < P.numLights; i++ ) {
+		const float4 pos = P.lights[i * 3 + 0];
+		const float4 data = P.lights[i * 3 + 2];
+
+		if( data.x == 2.0f ) {
+			float tNear = 0.0f;
+
+			if( intersectSphere( ray, mk3( pos.x, pos.y, pos.z ), data.y, &tNear ) && tNear < hit.t ) {
+				hit.t = inff();
+				hit.face = -( i + 1 );
+			}
+		}
+	}
+}
+
+// flatTriAndRayIntersect, pt_intersect.cl:92-129, on the pre-gathered record.  Returns t or INF.
+PT_DEV float triangleT( const DevParams& P, int face, const Ray& ray, float rayT, float tNear ) {
+	const float4 r0 = P.tris[face * 3 + 0];
+	const float4 r1 = P.tris[face * 3 + 1];
+	const float4 r2 = P.tris[face * 3 + 2];
+	const f3 a = mk3( r0.x, r0.y, r0.z );
+	const f3 edge1 = mk3( r0.w, r1.x, r1.y );
+	const f3 edge2 = mk3( r1.z, r1.w, r2.x );
+
+	const float f = fmax1( 0.0f, tNear - 0.001f );
+	const f3 closeOrigin = fma3( f, ray.dir, ray.origin );
+	const f3 tVec = closeOrigin - a;
+	const f3 pVec = cross( ray.dir, edge2 );
+	const f3 qVec = cross( tVec, edge1 );
+	const float invDet = 1.0f / dot( edge1, pVec );
+
+	float t = dot( edge2, qVec ) * invDet;
+
+	if( t >= rayT || t < EPSILON5 ) {
+		return inff();
+	}
+
+	const float u = dot( tVec, pVec ) * invDet;
+	const float v = dot( ray.dir, qVec ) * invDet;
+
+	if( u + v > 1.0f || fmin1( u, v ) < 0.0f ) {
+		return inff();
+	}
+
+	return t + f;
+}
+
+// traverse (pt_bvh.cl:82-123) / traverseShadows (:133-177).  ANYHIT: the shadow variant —
+// no `ray.t > tNear` cull, stops at the first face hit nearer than the light.
+template<bool ANYHIT, bool LIGHTS>
+PT_DEV void traverse( const DevParams& P, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
+	const f3 invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
+	const float tLight = hit.t;
+	const int numNodes = P.numNodes;
+	int index = 1;
+
+	if( LIGHTS ) {
+		traverseLights( P, ray, hit );
+	}
+
+	do {
+		if( !ANYHIT ) {
+			nodeVisits++;
+		}
+
+		const float4 lo = P.nodes[index * 2 + 0];
+		const float4 hi = P.nodes[index * 2 + 1];
+		const int face0 = __float_as_int( lo.w );
+		const int link = __float_as_int( hi.w );
+		const int current = index;
+
+		index = ( face0 < 0 ) ? link : current + 1;
+
+		// intersectBox, pt_intersect.cl:11-25
+		const float t1x = ( lo.x - ray.origin.x ) * invDir.x;
+		const float t1y = ( lo.y - ray.origin.y ) * invDir.y;
+		const float t1z = ( lo.z - ray.origin.z ) * invDir.z;
+		const float t2x = ( hi.x - ray.origin.x ) * invDir.x;
+		const float t2y = ( hi.y - ray.origin.y ) * invDir.y;
+		const float t2z = ( hi.z - ray.origin.z ) * invDir.z;
+		const float tNear = fmax1( fmax1( fmin1( t1x, t2x ), fmin1( t1y, t2y ) ), fmin1( t1z, t2z ) );
+		const float tFar = fmin1( fmin1( fmax1( t1x, t2x ), fmax1( t1y, t2y ) ), fmin1( fmax1( t1z, t2z ), inff() ) );
+
+		bool isNodeHit = ( tNear <= tFar ) && ( tFar > EPSILON5 );
+
+		if( !ANYHIT ) {
+			isNodeHit = isNodeHit && ( hit.t > tNear );
+		}
+
+		if( !isNodeHit ) {
+			continue;
+		}
+
+		index = current + 1;
+
+		if( face0 >= 0 ) {
+			// intersectFaces / intersectFace, pt_bvh.cl:10-46
+			float t = triangleT( P, face0, ray, hit.t, tNear );
+			faceTests++;
+
+			if( hit.t > t ) {
+				hit.t = t;
+				hit.face = face0;
+			}
+
+			if( link != -1 ) {
+				t = triangleT( P, link, ray, hit.t, tNear );
+				faceTests++;
+
+				if( hit.t > t ) {
+					hit.t = t;
+					hit.face = link;
+				}
+			}
+
+			if( ANYHIT && hit.t < tLight ) {
+				break;
+			}
+		}
+	} while( index > 0 && index < numNodes );
+}
+
+// Geometric normal of a face: fast_normalize( cross( edge1, edge2 ) ), pt_intersect.cl:122
+PT_DEV f3 faceNormal( const DevParams& P, int face, int* material ) {
+	const float4 r0 = P.tris[face * 3 + 0];
+	const float4 r1 = P.tris[face * 3 + 1];
+	const float4 r2 = P.tris[face * 3 + 2];
+	*material = __float_as_int( r2.y );
+	return normalize( cross( mk3( r0.w, r1.x, r1.y ), mk3( r1.z, r1.w, r2.x ) ) );
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Camera rays
+// ---------------------------------------------------------------------------------------
+
+// initRay + antiAliasing + depthOfField, pathtracing.cl:25-48, pt_utils.cl:327-373
+PT_DEV Ray initRay( const DevParams& P, int px, int py, float& seed, float tFocus, float tObject ) {
+	const f3 cu = ld3( P.cu );
+	const f3 cv = ld3( P.cv );
+	const float W = (float) P.width;
+	const float H = (float) P.height;
+	const float fx = 2.0f * (float) px;
+	const float fy = 2.0f * (float) py;
+
+	f3 inner = cu - cu * W;
+	inner = inner + cu * fx;
+	inner = inner + cv;
+	inner = inner - cv * H;
+	inner = inner + cv * fy;
+
+	const float s = P.pxDim * 0.5f;
+	const f3 initial = ld3( P.cw ) + inner * s;
+
+	Ray ray;
+	ray.origin = ld3( P.eye );
+	ray.dir = normalize( initial );
+
+	// antiAliasing
+	const float r = rnd( seed );
+	const float phi = PI_X2 * rnd( seed );
+	const f3 aaDir = jitter( ray.dir, phi, sqrt1( r ), sqrt1( 1.0f - r ) );
+	ray.dir = normalize( ray.dir + ( aaDir * P.pxDim ) * P.antiAliasing );
+
+	if( tFocus >= 0.0f && tObject >= 0.0f ) {
+		if( tObject == inff() ) {
+			tObject = 1000.0f;
+		}
+		if( tFocus == inff() ) {
+			tFocus = 1000.0f;
+		}
+
+		if( tObject > 0.0f ) {
+			const float aperture = P.lenseFocal / P.lenseAperture;
+			const float radius = rnd( seed ) * aperture * 0.5f;
+			const float angle = PI_X2 * rnd( seed );
+			float sa, ca;
+			sincos( angle, &sa, &ca );
+			const float x = radius * ca;
+			const float y = radius * sa;
+
+			ray.origin = ( ray.origin + cu * x ) + cv * y;
+
+			const f3 hitFocalPlane = fma3( tFocus, ray.dir, ld3( P.eye ) );
+			ray.dir = normalize( hitFocalPlane - ray.origin );
+		}
+	}
+
+	return ray;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// BRDF 0 — Schlick (pt_brdf.cl:2-209)
+// ---------------------------------------------------------------------------------------
+
+PT_DEV float schZ( float t, float r ) {
+	const float x = 1.0f + r * t * t - t * t;
+	return ( x == 0.0f ) ? 0.0f : r / ( x * x );
+}
+
+PT_DEV float schA( float w, float p ) {
+	const float p2 = p * p;
+	const float w2 = w * w;
+	const float x = p2 - p2 * w2 + w2;
+	return ( x == 0.0f ) ? 0.0f : sqrt1( p / x );
+}
+
+PT_DEV float schG( float v, float r ) {
+	const float x = r - r * v + v;
+	return ( x == 0.0f ) ? 0.0f : v / x;
+}
+
+// brdfSchlick, pt_brdf.cl:125-150 with D / B2 (:71-112) inlined
+PT_DEV float brdfSchlick( const Material& mtl, f3 outDir, f3 inDir, f3 normal, float* u, float* pdf ) {
+	const f3 vOutV = -outDir;
+	const f3 un = normalize( cross( yzx( normal ), normal ) );
+	const f3 h = normalize( vOutV + inDir );
+	const float t = dot( h, normal );
+	const float vIn = dot( inDir, normal );
+	const float vOut = dot( vOutV, normal );
+	const f3 hp = normalize( cross( cross( h, normal ), normal ) );
+	const float w = dot( un, hp );
+
+	*u = dot( h, vOutV );
+	*pdf = t / (float) ( (double) 4.0f * M_PI_D * (double) dot( vOutV, h ) );
+
+	const float r = mtl.p3;  // rough
+	const float p = mtl.p2;  // isotropy
+	const float b = 4.0f * r * ( 1.0f - r );
+	const float a = ( r < 0.5f ) ? 0.0f : 1.0f - b;
+	const float c = ( r < 0.5f ) ? 1.0f - b : 0.0f;
+	const float d = (float) ( (double) 4.0f * M_PI_D * (double) vOut * (double) vIn );
+	const float lam = (float) ( (double) a * M_1_PI_D );
+	float ani = 0.0f;
+
+	if( !( b == 0.0f || d == 0.0f ) ) {
+		const float gp = schG( vOut, r ) * schG( vIn, r );
+		const float obstructed = gp * schZ( t, r ) * schA( w, p );
+		const float reemission = 1.0f - gp;
+		ani = ( b / d ) * ( obstructed + reemission );
+	}
+
+	const float fres = ( vIn == 0.0f ) ? 0.0f : c / vIn;
+
+	return lam + ani + fres;
+}
+
+// newRaySchlick, pt_brdf.cl:160-208
+PT_DEV f3 newRaySchlick( f3 dir, f3 normal, const Material& mtl, float& seed ) {
+	const float rough = mtl.p3;
+	const float iso = mtl.p2;
+
+	if( rough == 0.0f ) {
+		return reflect( dir, normal );
+	}
+
+	const float a = rnd( seed );
+	float b = rnd( seed );
+	const float iso2 = iso * iso;
+	const float alpha = acos1( sqrt1( a / ( rough - a * rough + a ) ) );
+	float edge, base;
+	int mode;
+
+	if( b < 0.25f ) { edge = 0.25f; mode = 0; }
+	else if( b < 0.5f ) { edge = 0.5f; mode = 1; }
+	else if( b < 0.75f ) { edge = 0.75f; mode = 2; }
+	else { edge = 1.0f; mode = 3; }
+
+	b = 1.0f - 4.0f * ( edge - b );
+	const float b2 = b * b;
+	base = (float) ( M_PI_2_D * (double) sqrt1( ( iso2 * b2 ) / ( 1.0f - b2 + b2 * iso2 ) ) );
+
+	float phi = base;
+
+	if( mode == 1 ) { phi = (float) ( M_PI_D - (double) base ); }
+	else if( mode == 2 ) { phi = (float) ( M_PI_D + (double) base ); }
+	else if( mode == 3 ) { phi = (float) ( (double) 2.0f * M_PI_D - (double) base ); }
+
+	if( iso < 1.0f ) {
+		phi = (float) ( (double) phi + M_PI_2_D );
+	}
+
+	float sa, ca;
+	sincos( alpha, &sa, &ca );
+	const f3 H = jitter( normal, phi, sa, ca );
+	f3 out = reflect( dir, H );
+
+	if( dot( out, normal ) <= 0.0f ) {
+		out = jitter( normal, PI_X2 * rnd( seed ), sqrt1( a ), sqrt1( 1.0f - a ) );
+	}
+
+	return out;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// BRDF 1 — Shirley-Ashikhmin (pt_brdf.cl:211-331)
+// ---------------------------------------------------------------------------------------
+
+// brdfShirleyAshikhmin, pt_brdf.cl:228-268
+PT_DEV void brdfSA(
+	const Material& mtl, f3 outDir, f3 inDir, f3 normal,
+	float* brdfSpec, float* brdfDiff, float* dotHK1, float* pdf
+) {
+	const float nu = mtl.p2, nv = mtl.p3;
+	const f3 un = normalize( cross( yzx( normal ), normal ) );
+	const f3 vn = normalize( cross( normal, un ) );
+	const f3 k1 = inDir;
+	const f3 k2 = -outDir;
+	const f3 h = normalize( k1 + k2 );
+
+	const float dotHU = dot( h, un );
+	const float dotHV = dot( h, vn );
+	const float dotHN = dot( h, normal );
+	const float dotNK1 = dot( normal, k1 );
+	const float dotNK2 = dot( normal, k2 );
+	const float hk1 = dot( h, k1 );
+	*dotHK1 = hk1;
+
+	float ps_e = nu * dotHU * dotHU + nv * dotHV * dotHV;
+	ps_e = ( dotHN == 1.0f ) ? 0.0f : ps_e / ( 1.0f - dotHN * dotHN );
+	const float ps0 = (float) ( (double) ( sqrt1( ( nu + 1.0f ) * ( nv + 1.0f ) ) * 0.125f ) * M_1_PI_D );
+	const float ps1_num = pow1( dotHN, ps_e );
+	const float ps1 = ps1_num / ( hk1 * fmax1( dotNK1, dotNK2 ) );
+
+	float pd = mtl.Rd * 0.38750768752f;
+	const float a = 1.0f - dotNK1 * 0.5f;
+	const float b = 1.0f - dotNK2 * 0.5f;
+	pd *= 1.0f - a * a * a * a * a;
+	pd *= 1.0f - b * b * b * b * b;
+
+	*brdfSpec = ps0 * ps1;
+	*brdfDiff = pd;
+	*pdf = ( ps0 * ps1_num ) / hk1;
+}
+
+// newRayShirleyAshikhmin, pt_brdf.cl:278-330
+PT_DEV f3 newRaySA( f3 dir, f3 rayNormal, const Material& mtl, float& seed ) {
+	const float nu = mtl.p2, nv = mtl.p3;
+	float a = rnd( seed );
+	const float b = rnd( seed );
+	float phi_flip = (float) M_PI_D;
+	float phi_flipf = 1.0f;
+	float aMax = 1.0f;
+
+	if( a < 0.25f ) {
+		aMax = 0.25f;
+		phi_flip = 0.0f;
+	}
+	else if( a < 0.5f ) {
+		aMax = 0.5f;
+		phi_flipf = -1.0f;
+	}
+	else if( a < 0.75f ) {
+		aMax = 0.75f;
+	}
+	else {
+		phi_flip = (float) ( (double) 2.0f * M_PI_D );
+		phi_flipf = -1.0f;
+	}
+
+	a = 1.0f - 4.0f * ( aMax - a );
+
+	const float phi = atan1( sqrt1( ( nu + 1.0f ) / ( nv + 1.0f ) ) * tan1( (float) ( M_PI_2_D * (double) a ) ) );
+	const float phi_full = phi_flip + phi_flipf * phi;
+
+	float sinphi, cosphi;
+	sincos( phi, &sinphi, &cosphi );
+	const float theta_e = 1.0f / ( nu * cosphi * cosphi + nv * sinphi * sinphi + 1.0f );
+	const float theta = acos1( pow1( 1.0f - b, theta_e ) );
+
+	const f3 normal = ( mtl.d < 1.0f || dot( rayNormal, -dir ) >= 0.0f ) ? rayNormal : -rayNormal;
+
+	float st, ct;
+	sincos( theta, &st, &ct );
+	const f3 h = jitter( normal, phi_full, st, ct );
+	const f3 spec = reflect( dir, h );
+	const f3 diff = jitter( normal, PI_X2 * rnd( seed ), sqrt1( b ), sqrt1( 1.0f - b ) );
+
+	return ( dot( spec, normal ) <= 0.0f ) ? diff : spec;
+}
+
+// refract, pt_utils.cl:436-465
+PT_DEV f3 refract( f3 dir, f3 normal, const Material& mtl, float& seed ) {
+	const bool into = ( dot( normal, -dir ) > 0.0f );
+	const f3 nl = into ? normal : -normal;
+	const float m1 = into ? NI_AIR : mtl.Ni;
+	const float m2 = into ? mtl.Ni : NI_AIR;
+	const float m = m1 / m2;
+	const float cosI = -dot( nl, dir );
+	const float sinT2 = m * m * ( 1.0f - cosI * cosI );
+
+	if( sinT2 >= 1.0f ) {
+		return reflect( dir, nl );
+	}
+
+	const float sqrtCosT = sqrt1( 1.0f - sinT2 );
+	const float r0 = ( m1 - m2 ) / ( m1 + m2 );
+	const float c = ( m1 > m2 ) ? sqrtCosT : cosI;
+	const float reflectance = fresnel( c, r0 * r0 );
+
+	if( reflectance < rnd( seed ) ) {
+		const float k = m * cosI - sqrtCosT;
+		return dir * m + nl * k;
+	}
+
+	return reflect( dir, nl );
+}
+
+// getNewRay, pt_brdf.cl:344-378 (direction only; the origin is fma( t, dir, origin ))
+template<int BRDF>
+PT_DEV f3 newRayDir( f3 dir, f3 normal, const Material& mtl, float& seed, bool& addDepth ) {
+	// && short-circuits: the random number is drawn only when d < 1
+	bool doTransRefr = false;
+
+	if( mtl.d < 1.0f ) {
+		doTransRefr = ( mtl.d <= rnd( seed ) );
+	}
+
+	addDepth = addDepth || doTransRefr;
+
+	if( doTransRefr ) {
+		return refract( dir, normal, mtl, seed );
+	}
+
+	return ( BRDF == 0 ) ? newRaySchlick( dir, normal, mtl, seed ) : newRaySA( dir, normal, mtl, seed );
+}
+
+// The factor updateColor multiplies `color` by (pathtracing.cl:98-124 Schlick, :127-177 S-A).
+template<int BRDF>
+PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal ) {
+	const float d = mtl.d;
+
+	if( BRDF == 0 ) {
+		float u, pdf;
+		float brdf = brdfSchlick( mtl, outDir, inDir, normal, &u, &pdf );
+		brdf *= fmax1( dot( normal, inDir ), 0.0f );
+		brdf = brdf / pdf;
+
+		const f3 f4 = mk3( fresnel( u, mtl.Ks.x ), fresnel( u, mtl.Ks.y ), fresnel( u, mtl.Ks.z ) );
+		const f3 k = mk3( f4.x * brdf * d + ( 1.0f - d ), f4.y * brdf * d + ( 1.0f - d ), f4.z * brdf * d + ( 1.0f - d ) );
+		return mtl.Kd * k;
+	}
+
+	float spec, diff, dotHK1, pdf;
+	brdfSA( mtl, outDir, inDir, normal, &spec, &diff, &dotHK1, &pdf );
+	spec = spec / pdf;
+	diff = diff / pdf;
+
+	const float fr = fresnel( dotHK1, mtl.Rs );
+	const f3 brdf_s = ( mtl.Ks * spec ) * fr;
+	const f3 brdf_d = ( mtl.Kd * diff ) * ( 1.0f - mtl.Rs );
+	f3 bc = brdf_s + brdf_d;
+	bc = mk3( bc.x * d + ( 1.0f - d ), bc.y * d + ( 1.0f - d ), bc.z * d + ( 1.0f - d ) );
+	const float maxRGB = max_cl( 1.0f, max_cl( bc.x, max_cl( bc.y, bc.z ) ) );
+	bc = mk3( bc.x / maxRGB, bc.y / maxRGB, bc.z / maxRGB );
+
+	return mk3( clamp01( bc.x ), clamp01( bc.y ), clamp01( bc.z ) );
+}
+
+// The shadow-ray contribution to finalColor (pathtracing.cl:102-115 Schlick, :133-154 S-A).
+// Returns false when |pdf| <= 1e-5 (no contribution, secondaryPaths unchanged).
+template<int BRDF>
+PT_DEV bool shadowContribution(
+	const Material& mtl, f3 outDir, f3 lightDir, f3 normal, f3 color, f3 lightRgb, f3* add
+) {
+	const float d = mtl.d;
+
+	if( BRDF == 0 ) {
+		float u, pdf;
+		float brdf = brdfSchlick( mtl, outDir, lightDir, normal, &u, &pdf );
+
+		if( !( __builtin_fabsf( pdf ) > 0.00001f ) ) {
+			return false;
+		}
+
+		brdf *= fmax1( dot( normal, lightDir ), 0.0f );
+		brdf = brdf / pdf;
+
+		const f3 f4 = mk3( fresnel( u, mtl.Ks.x ), fresnel( u, mtl.Ks.y ), fresnel( u, mtl.Ks.z ) );
+		const f3 k = mk3( f4.x * brdf * d + ( 1.0f - d ), f4.y * brdf * d + ( 1.0f - d ), f4.z * brdf * d + ( 1.0f - d ) );
+		*add = ( ( color * lightRgb ) * mtl.Kd ) * k;
+		return true;
+	}
+
+	float spec, diff, dotHK1, pdf;
+	brdfSA( mtl, outDir, lightDir, normal, &spec, &diff, &dotHK1, &pdf );
+
+	if( !( __builtin_fabsf( pdf ) > 0.00001f ) ) {
+		return false;
+	}
+
+	spec = spec / pdf;
+	diff = diff / pdf;
+
+	const float fr = fresnel( dotHK1, mtl.Rs );
+	const f3 brdf_s = ( mtl.Ks * spec ) * fr;
+	const f3 brdf_d = ( mtl.Kd * diff ) * ( 1.0f - mtl.Rs );
+	f3 bc = brdf_s + brdf_d;
+	bc = mk3( bc.x * d + ( 1.0f - d ), bc.y * d + ( 1.0f - d ), bc.z * d + ( 1.0f - d ) );
+	const float maxRGB = max_cl( 1.0f, max_cl( bc.x, max_cl( bc.y, bc.z ) ) );
+	bc = mk3( bc.x / maxRGB, bc.y / maxRGB, bc.z / maxRGB );
+
+	const f3 cl = mk3( clamp01( bc.x ), clamp01( bc.y ), clamp01( bc.z ) );
+	*add = mk3(
+		cl.x * lightRgb.x * d + ( 1.0f - d ),
+		cl.y * lightRgb.y * d + ( 1.0f - d ),
+		cl.z * lightRgb.z * d + ( 1.0f - d )
+	);
+	return true;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// The kernel
+// ---------------------------------------------------------------------------------------
+
+PT_DEV unsigned waveSum( unsigned v ) {
+	for( int off = 32; off > 0; off >>= 1 ) {
+		v += __shfl_xor( v, off, 64 );
+	}
+	return v;
+}
+
+template<int BRDF, bool SHADOW, bool LIGHTS>
+__global__ __launch_bounds__( 256 ) void pathTracing( const DevParams P ) {
+	const int lane = (int) ( threadIdx.x & 63u );
+	const int lx = lane & 7;
+	const int ly = lane >> 3;
+
+	for( ;; ) {
+		// one tile per wave from the device-wide queue
+		unsigned tileLocal = 0;
+
+		if( lane == 0 ) {
+			tileLocal = atomicAdd( P.workCounter, 1u );
+		}
+
+		tileLocal = (unsigned) __builtin_amdgcn_readfirstlane( (int) tileLocal );
+
+		if( tileLocal >= (unsigned) P.numLocalTiles ) {
+			break;
+		}
+
+		const int tileGlobal = (int) tileLocal * P.tileWorld + P.tileRank;
+		const int px = ( tileGlobal % P.tilesX ) * 8 + lx;
+		const int py = ( tileGlobal / P.tilesX ) * 8 + ly;
+		const size_t pixel = (size_t) tileLocal * 64 + (size_t) lane;
+
+		const float4 prev = P.imgIn[pixel];
+		f3 acc = mk3( prev.x, prev.y, prev.z );
+		float accW = prev.w;
+
+		// getPreviousFocus, pathtracing.cl:58-65 (single-frame launches only; CLAMP_TO_EDGE)
+		float tFocus = -1.0f, tObject = -1.0f;
+
+		if( P.focusX >= 0 && P.focusY >= 0 ) {
+			const int fx = ( P.focusX > P.width - 1 ) ? P.width - 1 : P.focusX;
+			const int fy = ( P.focusY > P.height - 1 ) ? P.height - 1 : P.focusY;
+			const int ft = ( fy >> 3 ) * P.tilesX + ( fx >> 3 );
+			tObject = prev.w;
+			tFocus = P.imgIn[(size_t) ft * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) )].w;
+		}
+
+		unsigned totNodes = 0, totTris = 0, totHits = 0, totPaths = 0;
+		unsigned dbgNodes = 0, dbgTris = 0;
+
+		// per-frame state
+		int frame = 0;
+		int sample = 0;
+		f3 finalColor = mk3( 0.0f, 0.0f, 0.0f );
+		unsigned secondaryPaths = 1;
+		float focus = 0.0f;
+		float seed = ( P.nFrames > 0 ) ? P.seeds[0] : 0.0f;
+
+		// per-path state
+		bool alive = ( P.nFrames > 0 );
+		f3 color = mk3( 1.0f, 1.0f, 1.0f );
+		int depth = 0;
+		int depthAdded = 0;
+		Ray ray;
+		ray.origin = mk3( 0.0f, 0.0f, 0.0f );
+		ray.dir = mk3( 0.0f, 0.0f, 1.0f );
+
+		if( alive ) {
+			ray = initRay( P, px, py, seed, tFocus, tObject );
+			totPaths++;
+		}
+
+		while( alive ) {
+			// ---- traverse (pathtracing.cl:259) ----
+			Hit hit;
+			hit.t = inff();
+			hit.face = 0;
+			traverse<false, LIGHTS>( P, ray, hit, dbgNodes, dbgTris );
+
+			focus = ( sample + depth == 0 ) ? hit.t : focus;
+
+			bool pathDone = false;
+			f3 light = mk3( -1.0f, -1.0f, -1.0f );
+
+			if( hit.t == inff() ) {
+				// pathtracing.cl:263-266
+				if( LIGHTS && hit.face < 0 ) {
+					const float4 rgb = P.lights[( -( hit.face + 1 ) ) * 3 + 1];
+					light = mk3( rgb.x, rgb.y, rgb.z );
+				}
+				else {
+					light = ld3( P.sky );
+				}
+
+				pathDone = true;
+			}
+			else {
+				int mtlIndex;
+				f3 normal = faceNormal( P, hit.face, &mtlIndex );
+				const Material mtl = loadMaterial( P, mtlIndex );
+				totHits++;
+
+				// extendDepth, pt_utils.cl:89-96
+				bool addDepth;
+
+				if( BRDF == 1 ) {
+					addDepth = ( fmax1( mtl.p2, mtl.p3 ) >= 50.0f );
+				}
+				else {
+					addDepth = ( mtl.p3 < rnd( seed ) );
+				}
+
+				if( mtl.d == 1.0f && !addDepth && depth == P.maxDepth + depthAdded - 1 ) {
+					pathDone = true;  // pathtracing.cl:274-276: ends with no contribution
+				}
+				else {
+					seed += hit.t;
+
+					const f3 hitPoint = fma3( hit.t, ray.dir, ray.origin );
+
+					// shadowRayTest, pathtracing.cl:188-199, :284-290
+					bool lit = false;
+					f3 lightDir = mk3( 0.0f, 0.0f, 0.0f );
+					f3 lightRgb = mk3( -1.0f, -1.0f, -1.0f );
+
+					if( SHADOW && LIGHTS ) {
+						if( mtl.d > 0.0f ) {
+							const float4 lpos4 = P.lights[0];
+							const f3 lpos = mk3( lpos4.x, lpos4.y, lpos4.z );
+							Ray lightRay;
+							lightRay.origin = hitPoint;
+							lightRay.dir = normalize( lpos - hitPoint );
+							const f3 dl = lpos - hitPoint;
+							const float tLight = sqrt1( dot( dl, dl ) );
+							Hit lh;
+							lh.t = tLight;
+							lh.face = 0;
+							unsigned unusedNodes = 0;
+							traverse<true, LIGHTS>( P, lightRay, lh, unusedNodes, dbgTris );
+							lightDir = lightRay.dir;
+
+							if( lh.t >= tLight ) {
+								const float4 rgb = P.lights[1];
+								lightRgb = mk3( rgb.x, rgb.y, rgb.z );
+								lit = ( lightRgb.x >= 0.0f );
+							}
+						}
+					}
+
+					// getNewRay, pt_brdf.cl:344-378 — uses the UNflipped normal
+					const f3 newDir = newRayDir<BRDF>( ray.dir, normal, mtl, seed, addDepth );
+
+					// pathtracing.cl:298-300
+					if( dot( normal, -ray.dir ) <= 0.0f ) {
+						normal = -normal;
+					}
+
+					// updateColor, pathtracing.cl:89-178
+					if( SHADOW && LIGHTS ) {
+						if( lit ) {
+							f3 add;
+
+							if( shadowContribution<BRDF>( mtl, ray.dir, lightDir, normal, color, lightRgb, &add ) ) {
+								finalColor = finalColor + add;
+								secondaryPaths += 1;
+							}
+						}
+					}
+
+					color = color * throughput<BRDF>( mtl, ray.dir, newDir, normal );
+
+					depthAdded += ( addDepth && depthAdded < P.maxAddedDepth ) ? 1 : 0;
+
+					// russianRoulette, pt_utils.cl:385-387: rand drawn only if the first clause holds
+					const float maxValColor = fmax1( color.x, fmax1( color.y, color.z ) );
+					bool terminate = false;
+
+					if( depth > 2 + depthAdded ) {
+						terminate = ( maxValColor < rnd( seed ) );
+					}
+
+					if( terminate ) {
+						pathDone = true;
+					}
+					else {
+						ray.origin = hitPoint;
+						ray.dir = newDir;
+						depth++;
+						pathDone = !( depth < P.maxDepth + depthAdded );
+					}
+				}
+			}
+
+			if( pathDone ) {
+				// pathtracing.cl:320-323
+				if( light.x > -1.0f ) {
+					finalColor = finalColor + color * light;
+				}
+
+				sample++;
+
+				if( sample == P.samples ) {
+					// pathtracing.cl:326-333 + setColors, pt_rgb.cl:9-21
+					const float sp = (float) secondaryPaths;
+					finalColor = mk3( finalColor.x / sp, finalColor.y / sp, finalColor.z / sp );
+
+					if( P.samples > 1 ) {
+						const float ns = (float) P.samples;
+						finalColor = mk3( finalColor.x / ns, finalColor.y / ns, finalColor.z / ns );
+					}
+
+					const unsigned n = (unsigned) ( P.firstCount + frame );
+					const float w = P.useExplicitWeight ? P.explicitWeight : ( (float) n / (float) ( n + 1u ) );
+					acc = mk3(
+						finalColor.x + ( acc.x - finalColor.x ) * w,
+						finalColor.y + ( acc.y - finalColor.y ) * w,
+						finalColor.z + ( acc.z - finalColor.z ) * w
+					);
+					accW = focus;
+
+					totNodes += dbgNodes;
+					totTris += dbgTris;
+					frame++;
+
+					if( frame == P.nFrames ) {
+						alive = false;
+					}
+					else {
+						sample = 0;
+						finalColor = mk3( 0.0f, 0.0f, 0.0f );
+						secondaryPaths = 1;
+						focus = 0.0f;
+						dbgNodes = 0;
+						dbgTris = 0;
+						seed = P.seeds[frame];
+					}
+				}
+
+				if( alive ) {
+					color = mk3( 1.0f, 1.0f, 1.0f );
+					depth = 0;
+					depthAdded = 0;
+					ray = initRay( P, px, py, seed, tFocus, tObject );
+					totPaths++;
+				}
+			}
+		}
+
+		P.imgOut[pixel] = make_float4( acc.x, acc.y, acc.z, accW );
+
+		// writeDebugImage, pathtracing.cl:73-78 (counters of the LAST frame of this launch)
+		if( P.imgDbg != nullptr ) {
+			P.imgDbg[pixel] = make_float4( (float) dbgTris / 1082.0f, (float) dbgNodes / 1265.0f, 0.0f, 0.0f );
+		}
+
+		// one set of atomics per wave and tile
+		const unsigned long long sumNodes = waveSum( totNodes );
+		const unsigned long long sumTris = waveSum( totTris );
+		const unsigned long long sumHits = waveSum( totHits );
+		const unsigned long long sumPaths = waveSum( totPaths );
+
+		if( lane == 0 ) {
+			atomicAdd( &P.counters[0], sumNodes );
+			atomicAdd( &P.counters[1], sumTris );
+			atomicAdd( &P.counters[2], sumHits );
+			atomicAdd( &P.counters[3], sumPaths );
+		}
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Framebuffer layout helpers
+// ---------------------------------------------------------------------------------------
+
+// tile-major (local tiles of this rank) -> row-major W x H; pixels of other ranks' tiles = 0
+__global__ void untile( const float4* tiles, float4* rows, int width, int height, int tilesX, int tileWorld, int tileRank ) {
+	const int x = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
+	const int y = (int) ( blockIdx.y * blockDim.y + threadIdx.y );
+
+	if( x >= width || y >= height ) {
+		return;
+	}
+
+	const int tileGlobal = ( y >> 3 ) * tilesX + ( x >> 3 );
+	float4 v = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+
+	if( tileGlobal % tileWorld == tileRank ) {
+		const int tileLocal = tileGlobal / tileWorld;
+		v = tiles[(size_t) tileLocal * 64 + (size_t) ( ( y & 7 ) * 8 + ( x & 7 ) )];
+	}
+
+	rows[(size_t) y * (size_t) width + (size_t) x] = v;
+}
+
+// row-major W x H -> tile-major local tiles
+__global__ void retile( const float4* rows, float4* tiles, int width, int numLocalTiles, int tilesX, int tileWorld, int tileRank ) {
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( i >= (size_t) numLocalTiles * 64 ) {
+		return;
+	}
+
+	const int tileLocal = (int) ( i >> 6 );
+	const int lane = (int) ( i & 63 );
+	const int tileGlobal = tileLocal * tileWorld + tileRank;
+	const int x = ( tileGlobal % tilesX ) * 8 + ( lane & 7 );
+	const int y = ( tileGlobal / tilesX ) * 8 + ( lane >> 3 );
+	tiles[i] = rows[(size_t) y * (size_t) width + (size_t) x];
+}
+
+// all-gather layout (tileWorld rank buffers of `perRank` tiles each) -> this context's full tile-major image
+__global__ void scatterGathered( const float4* all, float4* tiles, int numTiles, int perRank, int tileWorld ) {
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( i >= (size_t) numTiles * 64 ) {
+		return;
+	}
+
+	const int tileGlobal = (int) ( i >> 6 );
+	const int lane = (int) ( i & 63 );
+	const int rank = tileGlobal % tileWorld;
+	const int local = tileGlobal / tileWorld;
+	tiles[i] = all[( (size_t) rank * perRank + local ) * 64 + lane];
+}
+
+}  // namespace ptk

@@ -1,0 +1,269 @@
+// extern "C" surface of libpbrhost.so for the Python test / bench harness (ctypes).
+// It exposes the host half of the path — config, scene load / generation, BVH build,
+// buffer packing, camera, PathTracer driver — with plain pointers, so the harness can hand the
+// SAME flat arrays to the HIP core (libpbrhip.so) and to the CPU oracle.
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <string>
+
+#include "Cfg.h"
+#include "bvh_builder.h"
+#include "model_io.h"
+#include "path_tracer.h"
+#include "scene_gen.h"
+
+using namespace pbr;
+
+namespace {
+
+struct HostScene {
+	ModelLoader loader;
+	std::unique_ptr<BVH> bvh;
+	SceneBuffers buffers;
+	float eye[3] = { 0.0f, 1.0f, 3.0f };
+	float center[3] = { 0.0f, 0.0f, 1.0f };
+	bool hasCamera = false;
+};
+
+thread_local std::string gError;
+
+void finishScene( HostScene* s ) {
+	const SceneModel& m = s->loader.getObjParser()->model();
+	s->bvh.reset( new BVH( m.objects, m.vertices, m.normals ) );
+	s->buffers.build( &s->loader, s->bvh.get() );
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pbrh_last_error() {
+	return gError.c_str();
+}
+
+// ---- Cfg -------------------------------------------------------------------------------
+
+void pbrh_cfg_reset() {
+	Cfg::get().resetDefaults();
+}
+
+void pbrh_cfg_set( const char* key, const char* value ) {
+	Cfg::get().value<std::string>( key, std::string( value ) );
+}
+
+int pbrh_cfg_get( const char* key, char* out, int len ) {
+	const std::string v = Cfg::get().value<std::string>( key );
+	snprintf( out, (size_t) len, "%s", v.c_str() );
+	return (int) v.size();
+}
+
+int pbrh_cfg_load( const char* path ) {
+	return Cfg::get().loadConfigFile( path ) ? 0 : -1;
+}
+
+// ---- scenes ----------------------------------------------------------------------------
+
+// ModelLoader::loadModel + new BVH + the buffer packing of PathTracer::initOpenCLBuffers,
+// i.e. GLWidget::loadModel (source/qt/GLWidget.cpp:339-387) without the GL parts.
+void* pbrh_scene_load_obj( const char* dir, const char* file ) {
+	try {
+		std::unique_ptr<HostScene> s( new HostScene() );
+		s->loader.loadModel( dir, file );
+
+		if( s->loader.getObjParser()->model().facesV.empty() ) {
+			gError = std::string( "no faces loaded from " ) + dir + file;
+			return nullptr;
+		}
+
+		finishScene( s.get() );
+		return s.release();
+	}
+	catch( const std::exception& e ) {
+		gError = e.what();
+		return nullptr;
+	}
+}
+
+void* pbrh_scene_generate( const char* kind, uint32_t seed, uint32_t triangles ) {
+	try {
+		std::unique_ptr<HostScene> s( new HostScene() );
+		GeneratedScene g = generateScene( kind, seed, triangles );
+		s->loader.getObjParser()->adopt( g.model );
+		std::memcpy( s->eye, g.eye, sizeof( g.eye ) );
+		std::memcpy( s->center, g.center, sizeof( g.center ) );
+		s->hasCamera = true;
+		finishScene( s.get() );
+		return s.release();
+	}
+	catch( const std::exception& e ) {
+		gError = e.what();
+		return nullptr;
+	}
+}
+
+void pbrh_scene_destroy( void* scene ) {
+	delete static_cast<HostScene*>( scene );
+}
+
+void pbrh_scene_desc( void* scene, pbr_scene_desc* out ) {
+	*out = static_cast<HostScene*>( scene )->buffers.desc();
+}
+
+// out[0..7] = flat nodes, faces, vertices, materials, lights, tree nodes before skip-ahead
+// deletion, leaves, max depth; out[8] = skip-ahead marks; out[9] = objects
+void pbrh_scene_info( void* scene, uint32_t* out ) {
+	HostScene* s = static_cast<HostScene*>( scene );
+	const pbr_scene_desc d = s->buffers.desc();
+	out[0] = d.num_nodes;
+	out[1] = d.num_faces;
+	out[2] = d.num_vertices;
+	out[3] = d.num_materials;
+	out[4] = d.num_lights;
+	out[5] = (uint32_t) s->bvh->nodes().size();
+	out[6] = (uint32_t) s->bvh->getLeafNodes().size();
+	out[7] = s->bvh->getDepth();
+	out[8] = s->bvh->numSkipped();
+	out[9] = (uint32_t) s->loader.getObjParser()->model().objects.size();
+}
+
+void pbrh_scene_config( void* scene, uint32_t width, uint32_t height, pbr_config* out ) {
+	*out = PathTracer::makeConfig( static_cast<HostScene*>( scene )->buffers, width, height );
+}
+
+// Camera for the scene: the generator's suggestion, else the Cfg default pose
+// (config.json:3-18); focal length / aperture from Cfg; no focus point.
+void pbrh_scene_camera( void* scene, pbr_camera* out ) {
+	HostScene* s = static_cast<HostScene*>( scene );
+	Camera cam;
+
+	if( s->hasCamera ) {
+		cam.setEye( s->eye[0], s->eye[1], s->eye[2] );
+		cam.setCenter( s->center[0], s->center[1], s->center[2] );
+	}
+
+	*out = pbr_camera();
+	PathTracer::fillCameraBasis( cam, out );
+	out->focusPoint[0] = -1;
+	out->focusPoint[1] = -1;
+	out->lense[0] = Cfg::get().value<float>( Cfg::CAM_LENSE_FOCALLENGTH );
+	out->lense[1] = Cfg::get().value<float>( Cfg::CAM_LENSE_APERTURE );
+}
+
+void pbrh_camera_lookat( const float* eye, const float* center, pbr_camera* out ) {
+	Camera cam;
+	cam.setEye( eye[0], eye[1], eye[2] );
+	cam.setCenter( center[0], center[1], center[2] );
+	*out = pbr_camera();
+	PathTracer::fillCameraBasis( cam, out );
+	out->focusPoint[0] = -1;
+	out->focusPoint[1] = -1;
+	out->lense[0] = Cfg::get().value<float>( Cfg::CAM_LENSE_FOCALLENGTH );
+	out->lense[1] = Cfg::get().value<float>( Cfg::CAM_LENSE_APERTURE );
+}
+
+float pbrh_pixel_dimension( uint32_t width, uint32_t height, float fov ) {
+	return PathTracer::pixelDimension( width, height, fov );
+}
+
+// ---- PathTracer driver -----------------------------------------------------------------
+
+struct HostTracer {
+	PathTracer pt;
+	Camera cam;
+	explicit HostTracer( int device ) : pt( device ) {}
+};
+
+void* pbrh_pt_create( int device, uint32_t width, uint32_t height ) {
+	try {
+		HostTracer* t = new HostTracer( device );
+		t->pt.setWidthAndHeight( width, height );
+		t->pt.setCamera( &t->cam );
+		return t;
+	}
+	catch( const std::exception& e ) {
+		gError = e.what();
+		return nullptr;
+	}
+}
+
+void pbrh_pt_destroy( void* tracer ) {
+	delete static_cast<HostTracer*>( tracer );
+}
+
+int pbrh_pt_init( void* tracer, void* scene, uint32_t tileWorld, uint32_t tileRank ) {
+	HostTracer* t = static_cast<HostTracer*>( tracer );
+	HostScene* s = static_cast<HostScene*>( scene );
+
+	try {
+		if( s->hasCamera ) {
+			t->cam.setEye( s->eye[0], s->eye[1], s->eye[2] );
+			t->cam.setCenter( s->center[0], s->center[1], s->center[2] );
+		}
+
+		const SceneModel& m = s->loader.getObjParser()->model();
+		t->pt.setTiles( tileWorld, tileRank );
+		t->pt.initOpenCLBuffers( m.vertices, m.facesV, m.normals, &s->loader, s->bvh.get() );
+		return 0;
+	}
+	catch( const std::exception& e ) {
+		gError = e.what();
+		return -1;
+	}
+}
+
+int pbrh_pt_generate_image( void* tracer, float* image, float* debug ) {
+	HostTracer* t = static_cast<HostTracer*>( tracer );
+
+	try {
+		std::vector<float> dbg;
+		const std::vector<float> img = t->pt.generateImage( debug ? &dbg : nullptr );
+		std::memcpy( image, img.data(), img.size() * sizeof( float ) );
+
+		if( debug ) {
+			std::memcpy( debug, dbg.data(), dbg.size() * sizeof( float ) );
+		}
+
+		return 0;
+	}
+	catch( const std::exception& e ) {
+		gError = e.what();
+		return -1;
+	}
+}
+
+int pbrh_pt_generate_images( void* tracer, uint32_t frames, float* image ) {
+	HostTracer* t = static_cast<HostTracer*>( tracer );
+
+	try {
+		const std::vector<float> img = t->pt.generateImages( frames );
+		std::memcpy( image, img.data(), img.size() * sizeof( float ) );
+		return 0;
+	}
+	catch( const std::exception& e ) {
+		gError = e.what();
+		return -1;
+	}
+}
+
+void pbrh_pt_set_focus( void* tracer, int x, int y ) {
+	static_cast<HostTracer*>( tracer )->pt.setFocus( x, y );
+}
+
+void pbrh_pt_reset_sample_count( void* tracer ) {
+	static_cast<HostTracer*>( tracer )->pt.resetSampleCount();
+}
+
+uint32_t pbrh_pt_sample_count( void* tracer ) {
+	return static_cast<HostTracer*>( tracer )->pt.getSampleCount();
+}
+
+void* pbrh_pt_context( void* tracer ) {
+	return static_cast<HostTracer*>( tracer )->pt.context();
+}
+
+void pbrh_pt_camera( void* tracer, pbr_camera* out ) {
+	*out = static_cast<HostTracer*>( tracer )->pt.camera();
+}
+
+}  // extern "C"
