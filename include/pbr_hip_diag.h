@@ -1,0 +1,41 @@
+/*
+ * pbr_hip_diag.h — diagnostic entry points of libpbrhip.so.
+ *
+ * Not part of the drop-in boundary (the reference has nothing comparable): they expose single
+ * stages of the device path — the math layer, closest-hit traversal, BRDF evaluation, new-ray
+ * sampling — so the parity tests can compare each stage with the oracle's hook of the same
+ * shape (oracle/pt_oracle.h: orc_math, orc_trace_rays, orc_brdf_eval, orc_new_ray) instead of
+ * only whole images.  Host pointers in, host pointers out; synchronous.
+ */
+#ifndef PBR_HIP_DIAG_H
+#define PBR_HIP_DIAG_H
+
+#include "pbr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* op: 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 pow( x, y ), 6 fract( sin( x ) * 43758.5453123 ) */
+int pbr_diag_math( pbr_ctx* ctx, int op, const float* x, const float* y, int n, float* out );
+
+/* Closest-hit traversal (pt_bvh.cl:82-123) of n rays {origin, dir} against the uploaded scene.
+ * out_t[n], out_face[n], out_normal[3n] (0 on a miss), out_counts[2n] = {node visits, face tests}. */
+int pbr_diag_trace( pbr_ctx* ctx, const float* rays, int n, float* out_t, int32_t* out_face, float* out_normal, uint32_t* out_counts );
+
+/* BRDF evaluation with material 0 of the uploaded scene.  in: n x 16 {out_dir[3], in_dir[3],
+ * normal[3], pad[7]}; out: n x 4 — BRDF 0 {brdf, u, pdf, 0}, BRDF 1 {spec, diff, dotHK1, pdf}. */
+int pbr_diag_brdf( pbr_ctx* ctx, const float* in, int n, float* out );
+
+/* getNewRay (pt_brdf.cl:344-378) with material 0.  in: n x 12 {origin[3], dir[3], normal[3], t,
+ * seed, pad}; out: n x 8 {origin[3], dir[3], seed after, addDepth}. */
+int pbr_diag_new_ray( pbr_ctx* ctx, const float* in, int n, float* out );
+
+/* Loop-bound trips recorded by a PBR_GUARD build ([0] tile loop, [1] path loop, [2] traversal);
+ * all zero in a normal build. */
+int pbr_diag_guard_trips( pbr_ctx* ctx, uint32_t out[3] );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

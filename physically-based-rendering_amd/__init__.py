@@ -15,6 +15,7 @@ import os
 import numpy as np
 
 from . import build as _build
+from . import tiles  # noqa: F401  (layout helpers for the multi-GPU path)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -69,7 +70,12 @@ def _load(path, builder):
 
 
 try:
-    hip = _load(_build.HIP_LIB, _build.build_hip)
+    if os.environ.get("PBR_HIP_LIB"):          # debugging aid: an alternative build of the same source
+        hip = ctypes.CDLL(os.environ["PBR_HIP_LIB"], mode=ctypes.RTLD_GLOBAL)
+    elif os.environ.get("PBR_GUARD") == "1":   # debugging aid: every device loop bounded (build.py)
+        hip = _load(_build.HIP_GUARD_LIB, lambda force=False: _build.build_hip(force, guard=True))
+    else:
+        hip = _load(_build.HIP_LIB, _build.build_hip)
     host = _load(_build.HOST_LIB, _build.build_host)
 except Exception as exc:  # no fallback by design
     raise ImportError("the HIP core (csrc/libpbrhip.so) / host library could not be loaded or built: %s" % exc)
@@ -99,6 +105,13 @@ hip.pbr_tile_bytes.argtypes = [_vp]
 hip.pbr_tile_bytes.restype = ctypes.c_uint64
 hip.pbr_export_tiles.argtypes = [_vp, _vp]
 hip.pbr_import_tiles.argtypes = [_vp, _vp]
+_ip = ctypes.POINTER(ctypes.c_int32)
+_up = ctypes.POINTER(ctypes.c_uint32)
+hip.pbr_diag_math.argtypes = [_vp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp]
+hip.pbr_diag_trace.argtypes = [_vp, _fp, ctypes.c_int, _fp, _ip, _fp, _up]
+hip.pbr_diag_brdf.argtypes = [_vp, _fp, ctypes.c_int, _fp]
+hip.pbr_diag_new_ray.argtypes = [_vp, _fp, ctypes.c_int, _fp]
+hip.pbr_diag_guard_trips.argtypes = [_vp, _up]
 
 host.pbrh_last_error.restype = ctypes.c_char_p
 host.pbrh_cfg_set.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
@@ -173,9 +186,9 @@ def pixel_dimension(width, height, fov=45.0):
 
 class HostScene:
     def __init__(self, handle):
+        self._h = handle
         if not handle:
             raise PbrError(host.pbrh_last_error().decode())
-        self._h = handle
         self.desc = SceneDesc()
         host.pbrh_scene_desc(self._h, ctypes.byref(self.desc))
         info = (ctypes.c_uint32 * 10)()
@@ -194,7 +207,7 @@ class HostScene:
         return cls(host.pbrh_scene_generate(kind.encode(), seed, triangles))
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             host.pbrh_scene_destroy(self._h)
             self._h = None
 
@@ -308,6 +321,45 @@ class Device:
 
     def tile_bytes(self):
         return int(hip.pbr_tile_bytes(self._ctx))
+
+    # ---- diagnostic stages (include/pbr_hip_diag.h) ----
+
+    MATH_OPS = {"sin": 0, "cos": 1, "tan": 2, "acos": 3, "atan": 4, "pow": 5, "randhash": 6}
+
+    def diag_math(self, op, x, y=None):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(x if y is None else y, np.float32)
+        out = np.empty_like(x)
+        self._check(hip.pbr_diag_math(self._ctx, self.MATH_OPS[op], _as_fp(x), _as_fp(y), x.size, _as_fp(out)))
+        return out
+
+    def diag_trace(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        t = np.empty(n, np.float32)
+        face = np.empty(n, np.int32)
+        normal = np.empty((n, 3), np.float32)
+        counts = np.empty((n, 2), np.uint32)
+        self._check(hip.pbr_diag_trace(self._ctx, _as_fp(rays), n, _as_fp(t), face.ctypes.data_as(_ip),
+                                       _as_fp(normal), counts.ctypes.data_as(_up)))
+        return t, face, normal, counts
+
+    def diag_brdf(self, items):
+        items = np.ascontiguousarray(items, np.float32).reshape(-1, 16)
+        out = np.empty((items.shape[0], 4), np.float32)
+        self._check(hip.pbr_diag_brdf(self._ctx, _as_fp(items), items.shape[0], _as_fp(out)))
+        return out
+
+    def diag_new_ray(self, items):
+        items = np.ascontiguousarray(items, np.float32).reshape(-1, 12)
+        out = np.empty((items.shape[0], 8), np.float32)
+        self._check(hip.pbr_diag_new_ray(self._ctx, _as_fp(items), items.shape[0], _as_fp(out)))
+        return out
+
+    def guard_trips(self):
+        out = (ctypes.c_uint32 * 3)()
+        self._check(hip.pbr_diag_guard_trips(self._ctx, out))
+        return [int(v) for v in out]
 
     def export_tiles(self, device_ptr):
         self._check(hip.pbr_export_tiles(self._ctx, device_ptr))

@@ -2,10 +2,9 @@
 
   csrc/libpbrhip.so   HIP core + C ABI (hipcc, gfx950)             -- the product
   host/libpbrhost.so  C++ host side (BVH builder, loaders, driver) -- the product's caller side
-  ../oracle/liboracle.so  CPU oracle (gcc)                         -- test infrastructure
 
 Contraction is OFF everywhere (-ffp-contract=off): the path's arithmetic is defined
-operation by operation, and the HIP kernels must agree with the oracle bit for bit.
+operation by operation, and the HIP kernels must reproduce it bit for bit.
 """
 import os
 import shutil
@@ -17,11 +16,10 @@ ROOT = os.path.dirname(HERE)
 INCLUDE = os.path.join(ROOT, "include")
 CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
-ORACLE = os.path.join(ROOT, "oracle")
 
 HIP_LIB = os.path.join(CSRC, "libpbrhip.so")
+HIP_GUARD_LIB = os.path.join(CSRC, "libpbrhip_guard.so")   # same source, -DPBR_GUARD: every device loop bounded
 HOST_LIB = os.path.join(HOST, "libpbrhost.so")
-ORACLE_LIB = os.path.join(ORACLE, "liboracle.so")
 
 HOST_SOURCES = ["Cfg.cpp", "model_io.cpp", "bvh_builder.cpp", "scene_gen.cpp", "path_tracer.cpp", "host_capi.cpp"]
 
@@ -48,17 +46,19 @@ def _run(cmd):
     return proc.stdout
 
 
-def build_hip(force=False, extra_flags=()):
-    sources = [os.path.join(CSRC, f) for f in ("pbr_hip.hip", "pt_kernel.hpp", "pt_math.hpp")] + [os.path.join(INCLUDE, "pbr_hip.h")]
-    if not force and not _stale(HIP_LIB, sources):
-        return HIP_LIB
+def build_hip(force=False, guard=False):
+    sources = [os.path.join(CSRC, f) for f in ("pbr_hip.hip", "pt_kernel.hpp", "pt_math.hpp")]
+    sources += [os.path.join(INCLUDE, f) for f in ("pbr_hip.h", "pbr_hip_diag.h")]
+    target = HIP_GUARD_LIB if guard else HIP_LIB
+    if not force and not _stale(target, sources):
+        return target
     cmd = [
         _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-        "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC, *extra_flags,
-        "-o", HIP_LIB, os.path.join(CSRC, "pbr_hip.hip"),
+        "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC, *(["-DPBR_GUARD=1"] if guard else []),
+        "-o", target, os.path.join(CSRC, "pbr_hip.hip"),
     ]
     _run(cmd)
-    return HIP_LIB
+    return target
 
 
 def build_host(force=False):
@@ -76,20 +76,8 @@ def build_host(force=False):
     return HOST_LIB
 
 
-def build_oracle(force=False):
-    sources = [os.path.join(ORACLE, f) for f in ("pt_oracle.c", "pt_oracle.h")]
-    if not force and not _stale(ORACLE_LIB, sources):
-        return ORACLE_LIB
-    cmd = [
-        "gcc", "-O2", "-std=c11", "-ffp-contract=off", "-mfma", "-mavx2", "-fopenmp", "-fPIC", "-shared",
-        "-o", ORACLE_LIB, os.path.join(ORACLE, "pt_oracle.c"), "-lm",
-    ]
-    _run(cmd)
-    return ORACLE_LIB
-
-
 def build_all(force=False):
-    return build_hip(force), build_host(force), build_oracle(force)
+    return build_hip(force), build_host(force)
 
 
 if __name__ == "__main__":

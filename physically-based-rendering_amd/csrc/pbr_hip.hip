@@ -6,11 +6,13 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "pbr_hip.h"
+#include "pbr_hip_diag.h"
 #include "pt_kernel.hpp"
 
 using ptk::DevParams;
@@ -45,6 +47,7 @@ struct pbr_ctx {
 	size_t seedCapacity = 0;
 	unsigned long long* dCounters = nullptr;
 	unsigned int* dWork = nullptr;
+	unsigned int* dGuard = nullptr;
 };
 
 namespace {
@@ -97,18 +100,27 @@ bool integral( float w, double lo, double hi ) {
 
 typedef void ( *KernelFn )( const DevParams );
 
-KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights ) {
+template<bool REFILL>
+KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 	if( brdf == 0 ) {
 		if( lights ) {
-			return shadow ? ptk::pathTracing<0, true, true> : ptk::pathTracing<0, false, true>;
+			return shadow ? ptk::pathTracing<0, true, true, REFILL> : ptk::pathTracing<0, false, true, REFILL>;
 		}
-		return ptk::pathTracing<0, false, false>;
+		return ptk::pathTracing<0, false, false, REFILL>;
 	}
 
 	if( lights ) {
-		return shadow ? ptk::pathTracing<1, true, true> : ptk::pathTracing<1, false, true>;
+		return shadow ? ptk::pathTracing<1, true, true, REFILL> : ptk::pathTracing<1, false, true, REFILL>;
 	}
-	return ptk::pathTracing<1, false, false>;
+	return ptk::pathTracing<1, false, false, REFILL>;
+}
+
+// Lane-level refill pays one (wave-aggregated) atomic per finished pixel; below this many
+// frames per launch the tile-synchronous schedule is used instead (pt_kernel.hpp).
+const uint32_t kRefillMinFrames = 4;
+
+KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights, bool refill ) {
+	return refill ? pickKernelMode<true>( brdf, shadow, lights ) : pickKernelMode<false>( brdf, shadow, lights );
 }
 
 int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* seeds,
@@ -157,6 +169,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	P.seeds = ctx->dSeeds;
 	P.counters = ctx->dCounters;
 	P.workCounter = ctx->dWork;
+	P.guard = ctx->dGuard;
 
 	const float* src[4] = { &cam->eye.x, &cam->w.x, &cam->u.x, &cam->v.x };
 	float* dst[4] = { P.eye, P.cw, P.cu, P.cv };
@@ -194,7 +207,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	const bool lights = ( ctx->numLights > 0 );
 	const bool shadow = ( ctx->cfg.shadow_rays == 1 ) && lights;
-	const KernelFn kernel = pickKernel( ctx->cfg.brdf, shadow, lights );
+	const char* force = std::getenv( "PBR_SCHEDULE" );   // "tile" / "refill": override, for A/B measurements
+	bool refill = ( nFrames * ctx->cfg.samples >= kRefillMinFrames );
+
+	if( force != nullptr ) {
+		refill = ( std::strcmp( force, "refill" ) == 0 ) ? true : ( std::strcmp( force, "tile" ) == 0 ) ? false : refill;
+	}
+
+	const KernelFn kernel = pickKernel( ctx->cfg.brdf, shadow, lights, refill );
 
 	// persistent grid: as many 4-wave blocks as stay resident, never more than there are tiles
 	int blocksPerCU = 0;
@@ -270,6 +290,9 @@ int pbr_create( int device, pbr_ctx** out ) {
 	HIP_TRY( ctx, hipEventCreate( &ctx->evStop ) );
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dCounters, sizeof( unsigned long long ) * 4 ) );
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWork, sizeof( unsigned int ) ) );
+	// host-visible so that it can be read while a kernel is still running
+	HIP_TRY( ctx, hipHostMalloc( (void**) &ctx->dGuard, sizeof( unsigned int ) * 4, hipHostMallocMapped ) );
+	std::memset( ctx->dGuard, 0, sizeof( unsigned int ) * 4 );
 	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * 4 ) );
 
 	return PBR_OK;
@@ -288,6 +311,7 @@ void pbr_destroy( pbr_ctx* ctx ) {
 		(void) hipFree( ctx->dSeeds );
 		(void) hipFree( ctx->dCounters );
 		(void) hipFree( ctx->dWork );
+		(void) hipHostFree( ctx->dGuard );
 		(void) hipEventDestroy( ctx->evStart );
 		(void) hipEventDestroy( ctx->evStop );
 		(void) hipStreamDestroy( ctx->stream );
@@ -472,6 +496,7 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	HIP_TRY( ctx, hipMemset( ctx->dImgOut, 0, fullBytes ) );
 	HIP_TRY( ctx, hipMemset( ctx->dImgDbg, 0, fullBytes ) );
 	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * 4 ) );
+	HIP_TRY( ctx, hipDeviceSynchronize() );   // the memsets ran on the null stream; launches use ctx->stream
 	ctx->configured = true;
 
 	return PBR_OK;
@@ -634,6 +659,155 @@ int pbr_read_full( pbr_ctx* ctx, float* rgba ) {
 		return PBR_EINVAL;
 	}
 	return readTiled( ctx, ctx->dFull, rgba, 1, 0 );
+}
+
+
+// ---- diagnostic entry points (include/pbr_hip_diag.h) -----------------------------------
+
+namespace {
+
+struct DevBuf {
+	void* p = nullptr;
+	~DevBuf() { (void) hipFree( p ); }
+	hipError_t alloc( size_t bytes ) { return hipMalloc( &p, bytes ? bytes : 4 ); }
+};
+
+DevParams sceneParams( pbr_ctx* ctx ) {
+	DevParams P;
+	std::memset( &P, 0, sizeof( P ) );
+	P.nodes = ctx->dNodes;
+	P.tris = ctx->dTris;
+	P.mats = ctx->dMats;
+	P.lights = ctx->dLights;
+	P.guard = ctx->dGuard;
+	P.numNodes = (int) ctx->numNodes;
+	P.numLights = (int) ctx->numLights;
+	return P;
+}
+
+}  // namespace
+
+int pbr_diag_math( pbr_ctx* ctx, int op, const float* x, const float* y, int n, float* out ) {
+	if( ctx == nullptr || ctx->stream == nullptr || x == nullptr || out == nullptr || n <= 0 ) {
+		return fail( ctx, PBR_EINVAL, "diag_math: bad argument" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	DevBuf dx, dy, dout;
+	const size_t bytes = sizeof( float ) * (size_t) n;
+	HIP_TRY( ctx, dx.alloc( bytes ) );
+	HIP_TRY( ctx, dy.alloc( bytes ) );
+	HIP_TRY( ctx, dout.alloc( bytes ) );
+	HIP_TRY( ctx, hipMemcpy( dx.p, x, bytes, hipMemcpyHostToDevice ) );
+	HIP_TRY( ctx, hipMemcpy( dy.p, ( y != nullptr ) ? y : x, bytes, hipMemcpyHostToDevice ) );
+	hipLaunchKernelGGL( ptk::diagMath, dim3( (unsigned) ( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, ctx->stream,
+		op, (const float*) dx.p, (const float*) dy.p, n, (float*) dout.p );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpy( out, dout.p, bytes, hipMemcpyDeviceToHost ) );
+	return PBR_OK;
+}
+
+int pbr_diag_trace( pbr_ctx* ctx, const float* rays, int n, float* out_t, int32_t* out_face, float* out_normal, uint32_t* out_counts ) {
+	if( ctx == nullptr || !ctx->hasScene ) {
+		return fail( ctx, PBR_ESTATE, "diag_trace before pbr_upload_scene" );
+	}
+	if( rays == nullptr || n <= 0 || out_t == nullptr || out_face == nullptr || out_normal == nullptr || out_counts == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "diag_trace: bad argument" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	DevBuf dRays, dT, dFace, dNormal, dCounts;
+	HIP_TRY( ctx, dRays.alloc( sizeof( float ) * 6 * (size_t) n ) );
+	HIP_TRY( ctx, dT.alloc( sizeof( float ) * (size_t) n ) );
+	HIP_TRY( ctx, dFace.alloc( sizeof( int ) * (size_t) n ) );
+	HIP_TRY( ctx, dNormal.alloc( sizeof( float ) * 3 * (size_t) n ) );
+	HIP_TRY( ctx, dCounts.alloc( sizeof( unsigned ) * 2 * (size_t) n ) );
+	HIP_TRY( ctx, hipMemcpy( dRays.p, rays, sizeof( float ) * 6 * (size_t) n, hipMemcpyHostToDevice ) );
+
+	const DevParams P = sceneParams( ctx );
+	const dim3 grid( (unsigned) ( ( n + 63 ) / 64 ) ), block( 64 );
+
+	if( ctx->numLights > 0 ) {
+		hipLaunchKernelGGL( ptk::diagTrace<true>, grid, block, 0, ctx->stream, P, (const float*) dRays.p, n,
+			(float*) dT.p, (int*) dFace.p, (float*) dNormal.p, (unsigned*) dCounts.p );
+	}
+	else {
+		hipLaunchKernelGGL( ptk::diagTrace<false>, grid, block, 0, ctx->stream, P, (const float*) dRays.p, n,
+			(float*) dT.p, (int*) dFace.p, (float*) dNormal.p, (unsigned*) dCounts.p );
+	}
+
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpy( out_t, dT.p, sizeof( float ) * (size_t) n, hipMemcpyDeviceToHost ) );
+	HIP_TRY( ctx, hipMemcpy( out_face, dFace.p, sizeof( int ) * (size_t) n, hipMemcpyDeviceToHost ) );
+	HIP_TRY( ctx, hipMemcpy( out_normal, dNormal.p, sizeof( float ) * 3 * (size_t) n, hipMemcpyDeviceToHost ) );
+	HIP_TRY( ctx, hipMemcpy( out_counts, dCounts.p, sizeof( unsigned ) * 2 * (size_t) n, hipMemcpyDeviceToHost ) );
+	return PBR_OK;
+}
+
+namespace {
+
+int diagPerItem( pbr_ctx* ctx, const float* in, int n, float* out, int inWidth, int outWidth, bool newRay ) {
+	if( ctx == nullptr || !ctx->hasScene ) {
+		return fail( ctx, PBR_ESTATE, "diag before pbr_upload_scene" );
+	}
+	if( in == nullptr || out == nullptr || n <= 0 ) {
+		return fail( ctx, PBR_EINVAL, "diag: bad argument" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	DevBuf dIn, dOut;
+	HIP_TRY( ctx, dIn.alloc( sizeof( float ) * inWidth * (size_t) n ) );
+	HIP_TRY( ctx, dOut.alloc( sizeof( float ) * outWidth * (size_t) n ) );
+	HIP_TRY( ctx, hipMemcpy( dIn.p, in, sizeof( float ) * inWidth * (size_t) n, hipMemcpyHostToDevice ) );
+
+	const DevParams P = sceneParams( ctx );
+	const dim3 grid( (unsigned) ( ( n + 63 ) / 64 ) ), block( 64 );
+
+	if( newRay ) {
+		if( ctx->sceneBrdf == 0 ) {
+			hipLaunchKernelGGL( ptk::diagNewRay<0>, grid, block, 0, ctx->stream, P, (const float*) dIn.p, n, (float*) dOut.p );
+		}
+		else {
+			hipLaunchKernelGGL( ptk::diagNewRay<1>, grid, block, 0, ctx->stream, P, (const float*) dIn.p, n, (float*) dOut.p );
+		}
+	}
+	else {
+		if( ctx->sceneBrdf == 0 ) {
+			hipLaunchKernelGGL( ptk::diagBrdf<0>, grid, block, 0, ctx->stream, P, (const float*) dIn.p, n, (float*) dOut.p );
+		}
+		else {
+			hipLaunchKernelGGL( ptk::diagBrdf<1>, grid, block, 0, ctx->stream, P, (const float*) dIn.p, n, (float*) dOut.p );
+		}
+	}
+
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpy( out, dOut.p, sizeof( float ) * outWidth * (size_t) n, hipMemcpyDeviceToHost ) );
+	return PBR_OK;
+}
+
+}  // namespace
+
+int pbr_diag_brdf( pbr_ctx* ctx, const float* in, int n, float* out ) {
+	return diagPerItem( ctx, in, n, out, 16, 4, false );
+}
+
+int pbr_diag_new_ray( pbr_ctx* ctx, const float* in, int n, float* out ) {
+	return diagPerItem( ctx, in, n, out, 12, 8, true );
+}
+
+int pbr_diag_guard_trips( pbr_ctx* ctx, uint32_t out[3] ) {
+	if( ctx == nullptr || ctx->stream == nullptr || out == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "diag_guard_trips: bad argument" );
+	}
+
+	const volatile unsigned* host = ctx->dGuard;
+	out[0] = host[0];
+	out[1] = host[1];
+	out[2] = host[2];
+	return PBR_OK;
 }
 
 }  // extern "C"

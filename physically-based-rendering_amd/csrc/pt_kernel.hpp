@@ -21,6 +21,12 @@
 
 #include "pt_math.hpp"
 
+#ifdef PBR_GUARD
+#define PBR_GUARD_TILES 1
+#define PBR_GUARD_PATH 1
+#define PBR_GUARD_TRAV 1
+#endif
+
 namespace ptk {
 
 using namespace ptm;
@@ -43,6 +49,7 @@ struct DevParams {
 	const float* seeds;     // one per frame
 	unsigned long long* counters;  // nodes, tris, hits, paths
 	unsigned int* workCounter;
+	unsigned int* guard;    // [0] tile-loop, [1] path-loop, [2] traversal trips (PBR_GUARD builds only)
 
 	float eye[3], cw[3], cu[3], cv[3];
 	int focusX, focusY;
@@ -206,12 +213,22 @@ PT_DEV void traverse( const DevParams& P, const Ray& ray, Hit& hit, unsigned& no
 	const float tLight = hit.t;
 	const int numNodes = P.numNodes;
 	int index = 1;
+#ifdef PBR_GUARD_TRAV
+	int guardSteps = 0;
+#endif
 
 	if( LIGHTS ) {
 		traverseLights( P, ray, hit );
 	}
 
 	do {
+#ifdef PBR_GUARD_TRAV
+		// a forward-only walk visits each node at most once
+		if( ++guardSteps > numNodes ) {
+			atomicAdd( &P.guard[2], 1u );
+			break;
+		}
+#endif
 		if( !ANYHIT ) {
 			nodeVisits++;
 		}
@@ -676,267 +693,380 @@ PT_DEV unsigned waveSum( unsigned v ) {
 	return v;
 }
 
+// Everything a lane carries for the pixel it is working on.
+struct PixelState {
+	unsigned slot;           // tile-major pixel slot: tile = slot >> 6, position in tile = slot & 63
+	int px, py;
+	f3 acc;                  // running mean over the frames done so far (imageIn -> imageOut)
+	float accW;
+	float tFocus, tObject;   // depth of field inputs (previous frame), -1 = off
+	// frame
+	int frame, sample;
+	f3 finalColor;
+	unsigned secondaryPaths;
+	float focus;
+	float seed;
+	unsigned dbgNodes, dbgTris;
+	// path
+	f3 color;
+	int depth, depthAdded;
+	Ray ray;
+};
+
+struct LaneCounters {
+	unsigned nodes, tris, hits, paths;
+};
+
+PT_DEV void flushCounters( const DevParams& P, LaneCounters& c ) {
+	atomicAdd( &P.counters[0], (unsigned long long) c.nodes );
+	atomicAdd( &P.counters[1], (unsigned long long) c.tris );
+	atomicAdd( &P.counters[2], (unsigned long long) c.hits );
+	atomicAdd( &P.counters[3], (unsigned long long) c.paths );
+	c.nodes = c.tris = c.hits = c.paths = 0;
+}
+
+// Take up pixel `slot`: load the accumulated value and start frame 0's first path.
+PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneCounters& cnt ) {
+	const int tileGlobal = (int) ( slot >> 6 ) * P.tileWorld + P.tileRank;
+	const int inTile = (int) ( slot & 63u );
+	st.slot = slot;
+	st.px = ( tileGlobal % P.tilesX ) * 8 + ( inTile & 7 );
+	st.py = ( tileGlobal / P.tilesX ) * 8 + ( inTile >> 3 );
+
+	const float4 prev = P.imgIn[slot];
+	st.acc = mk3( prev.x, prev.y, prev.z );
+	st.accW = prev.w;
+
+	// getPreviousFocus, pathtracing.cl:58-65 (single-frame launches only; CLAMP_TO_EDGE)
+	st.tFocus = -1.0f;
+	st.tObject = -1.0f;
+
+	if( P.focusX >= 0 && P.focusY >= 0 ) {
+		const int fx = ( P.focusX > P.width - 1 ) ? P.width - 1 : P.focusX;
+		const int fy = ( P.focusY > P.height - 1 ) ? P.height - 1 : P.focusY;
+		const int ft = ( fy >> 3 ) * P.tilesX + ( fx >> 3 );
+		st.tObject = prev.w;
+		st.tFocus = P.imgIn[(size_t) ft * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) )].w;
+	}
+
+	st.frame = 0;
+	st.sample = 0;
+	st.finalColor = mk3( 0.0f, 0.0f, 0.0f );
+	st.secondaryPaths = 1;
+	st.focus = 0.0f;
+	st.seed = P.seeds[0];
+	st.dbgNodes = 0;
+	st.dbgTris = 0;
+
+	st.color = mk3( 1.0f, 1.0f, 1.0f );
+	st.depth = 0;
+	st.depthAdded = 0;
+	st.ray = initRay( P, st.px, st.py, st.seed, st.tFocus, st.tObject );
+	cnt.paths++;
+}
+
+// Store the finished pixel (all frames of this launch accumulated).
+PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
+	P.imgOut[st.slot] = make_float4( st.acc.x, st.acc.y, st.acc.z, st.accW );
+
+	// writeDebugImage, pathtracing.cl:73-78 (counters of the LAST frame of this launch)
+	if( P.imgDbg != nullptr ) {
+		P.imgDbg[st.slot] = make_float4( (float) st.dbgTris / 1082.0f, (float) st.dbgNodes / 1265.0f, 0.0f, 0.0f );
+	}
+}
+
+// One bounce of the lane's current path: traverse, shade, and — when the path / frame ends —
+// fold it into the running mean and start the next path.  Returns true when the pixel has had
+// all P.nFrames frames.
 template<int BRDF, bool SHADOW, bool LIGHTS>
-__global__ __launch_bounds__( 256 ) void pathTracing( const DevParams P ) {
-	const int lane = (int) ( threadIdx.x & 63u );
-	const int lx = lane & 7;
-	const int ly = lane >> 3;
+PT_DEV bool stepPixel( const DevParams& P, PixelState& st, LaneCounters& cnt ) {
+	// references keep the shading code below in the reference's vocabulary
+	Ray& ray = st.ray;
+	f3& color = st.color;
+	f3& finalColor = st.finalColor;
+	unsigned& secondaryPaths = st.secondaryPaths;
+	float& seed = st.seed;
+	int& depth = st.depth;
+	int& depthAdded = st.depthAdded;
+	unsigned& dbgTris = st.dbgTris;
+	unsigned& totHits = cnt.hits;
 
-	for( ;; ) {
-		// one tile per wave from the device-wide queue
-		unsigned tileLocal = 0;
+	// ---- traverse (pathtracing.cl:259) ----
+	Hit hit;
+	hit.t = inff();
+	hit.face = 0;
+	traverse<false, LIGHTS>( P, ray, hit, st.dbgNodes, dbgTris );
 
-		if( lane == 0 ) {
-			tileLocal = atomicAdd( P.workCounter, 1u );
-		}
+	st.focus = ( st.sample + depth == 0 ) ? hit.t : st.focus;
 
-		tileLocal = (unsigned) __builtin_amdgcn_readfirstlane( (int) tileLocal );
+		bool pathDone = false;
+		f3 light = mk3( -1.0f, -1.0f, -1.0f );
 
-		if( tileLocal >= (unsigned) P.numLocalTiles ) {
-			break;
-		}
-
-		const int tileGlobal = (int) tileLocal * P.tileWorld + P.tileRank;
-		const int px = ( tileGlobal % P.tilesX ) * 8 + lx;
-		const int py = ( tileGlobal / P.tilesX ) * 8 + ly;
-		const size_t pixel = (size_t) tileLocal * 64 + (size_t) lane;
-
-		const float4 prev = P.imgIn[pixel];
-		f3 acc = mk3( prev.x, prev.y, prev.z );
-		float accW = prev.w;
-
-		// getPreviousFocus, pathtracing.cl:58-65 (single-frame launches only; CLAMP_TO_EDGE)
-		float tFocus = -1.0f, tObject = -1.0f;
-
-		if( P.focusX >= 0 && P.focusY >= 0 ) {
-			const int fx = ( P.focusX > P.width - 1 ) ? P.width - 1 : P.focusX;
-			const int fy = ( P.focusY > P.height - 1 ) ? P.height - 1 : P.focusY;
-			const int ft = ( fy >> 3 ) * P.tilesX + ( fx >> 3 );
-			tObject = prev.w;
-			tFocus = P.imgIn[(size_t) ft * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) )].w;
-		}
-
-		unsigned totNodes = 0, totTris = 0, totHits = 0, totPaths = 0;
-		unsigned dbgNodes = 0, dbgTris = 0;
-
-		// per-frame state
-		int frame = 0;
-		int sample = 0;
-		f3 finalColor = mk3( 0.0f, 0.0f, 0.0f );
-		unsigned secondaryPaths = 1;
-		float focus = 0.0f;
-		float seed = ( P.nFrames > 0 ) ? P.seeds[0] : 0.0f;
-
-		// per-path state
-		bool alive = ( P.nFrames > 0 );
-		f3 color = mk3( 1.0f, 1.0f, 1.0f );
-		int depth = 0;
-		int depthAdded = 0;
-		Ray ray;
-		ray.origin = mk3( 0.0f, 0.0f, 0.0f );
-		ray.dir = mk3( 0.0f, 0.0f, 1.0f );
-
-		if( alive ) {
-			ray = initRay( P, px, py, seed, tFocus, tObject );
-			totPaths++;
-		}
-
-		while( alive ) {
-			// ---- traverse (pathtracing.cl:259) ----
-			Hit hit;
-			hit.t = inff();
-			hit.face = 0;
-			traverse<false, LIGHTS>( P, ray, hit, dbgNodes, dbgTris );
-
-			focus = ( sample + depth == 0 ) ? hit.t : focus;
-
-			bool pathDone = false;
-			f3 light = mk3( -1.0f, -1.0f, -1.0f );
-
-			if( hit.t == inff() ) {
-				// pathtracing.cl:263-266
-				if( LIGHTS && hit.face < 0 ) {
-					const float4 rgb = P.lights[( -( hit.face + 1 ) ) * 3 + 1];
-					light = mk3( rgb.x, rgb.y, rgb.z );
-				}
-				else {
-					light = ld3( P.sky );
-				}
-
-				pathDone = true;
+		if( hit.t == inff() ) {
+			// pathtracing.cl:263-266
+			if( LIGHTS && hit.face < 0 ) {
+				const float4 rgb = P.lights[( -( hit.face + 1 ) ) * 3 + 1];
+				light = mk3( rgb.x, rgb.y, rgb.z );
 			}
 			else {
-				int mtlIndex;
-				f3 normal = faceNormal( P, hit.face, &mtlIndex );
-				const Material mtl = loadMaterial( P, mtlIndex );
-				totHits++;
-
-				// extendDepth, pt_utils.cl:89-96
-				bool addDepth;
-
-				if( BRDF == 1 ) {
-					addDepth = ( fmax1( mtl.p2, mtl.p3 ) >= 50.0f );
-				}
-				else {
-					addDepth = ( mtl.p3 < rnd( seed ) );
-				}
-
-				if( mtl.d == 1.0f && !addDepth && depth == P.maxDepth + depthAdded - 1 ) {
-					pathDone = true;  // pathtracing.cl:274-276: ends with no contribution
-				}
-				else {
-					seed += hit.t;
-
-					const f3 hitPoint = fma3( hit.t, ray.dir, ray.origin );
-
-					// shadowRayTest, pathtracing.cl:188-199, :284-290
-					bool lit = false;
-					f3 lightDir = mk3( 0.0f, 0.0f, 0.0f );
-					f3 lightRgb = mk3( -1.0f, -1.0f, -1.0f );
-
-					if( SHADOW && LIGHTS ) {
-						if( mtl.d > 0.0f ) {
-							const float4 lpos4 = P.lights[0];
-							const f3 lpos = mk3( lpos4.x, lpos4.y, lpos4.z );
-							Ray lightRay;
-							lightRay.origin = hitPoint;
-							lightRay.dir = normalize( lpos - hitPoint );
-							const f3 dl = lpos - hitPoint;
-							const float tLight = sqrt1( dot( dl, dl ) );
-							Hit lh;
-							lh.t = tLight;
-							lh.face = 0;
-							unsigned unusedNodes = 0;
-							traverse<true, LIGHTS>( P, lightRay, lh, unusedNodes, dbgTris );
-							lightDir = lightRay.dir;
-
-							if( lh.t >= tLight ) {
-								const float4 rgb = P.lights[1];
-								lightRgb = mk3( rgb.x, rgb.y, rgb.z );
-								lit = ( lightRgb.x >= 0.0f );
-							}
-						}
-					}
-
-					// getNewRay, pt_brdf.cl:344-378 — uses the UNflipped normal
-					const f3 newDir = newRayDir<BRDF>( ray.dir, normal, mtl, seed, addDepth );
-
-					// pathtracing.cl:298-300
-					if( dot( normal, -ray.dir ) <= 0.0f ) {
-						normal = -normal;
-					}
-
-					// updateColor, pathtracing.cl:89-178
-					if( SHADOW && LIGHTS ) {
-						if( lit ) {
-							f3 add;
-
-							if( shadowContribution<BRDF>( mtl, ray.dir, lightDir, normal, color, lightRgb, &add ) ) {
-								finalColor = finalColor + add;
-								secondaryPaths += 1;
-							}
-						}
-					}
-
-					color = color * throughput<BRDF>( mtl, ray.dir, newDir, normal );
-
-					depthAdded += ( addDepth && depthAdded < P.maxAddedDepth ) ? 1 : 0;
-
-					// russianRoulette, pt_utils.cl:385-387: rand drawn only if the first clause holds
-					const float maxValColor = fmax1( color.x, fmax1( color.y, color.z ) );
-					bool terminate = false;
-
-					if( depth > 2 + depthAdded ) {
-						terminate = ( maxValColor < rnd( seed ) );
-					}
-
-					if( terminate ) {
-						pathDone = true;
-					}
-					else {
-						ray.origin = hitPoint;
-						ray.dir = newDir;
-						depth++;
-						pathDone = !( depth < P.maxDepth + depthAdded );
-					}
-				}
+				light = ld3( P.sky );
 			}
 
-			if( pathDone ) {
-				// pathtracing.cl:320-323
-				if( light.x > -1.0f ) {
-					finalColor = finalColor + color * light;
+			pathDone = true;
+		}
+		else {
+			int mtlIndex;
+			f3 normal = faceNormal( P, hit.face, &mtlIndex );
+			const Material mtl = loadMaterial( P, mtlIndex );
+			totHits++;
+
+			// extendDepth, pt_utils.cl:89-96
+			bool addDepth;
+
+			if( BRDF == 1 ) {
+				addDepth = ( fmax1( mtl.p2, mtl.p3 ) >= 50.0f );
+			}
+			else {
+				addDepth = ( mtl.p3 < rnd( seed ) );
+			}
+
+			if( mtl.d == 1.0f && !addDepth && depth == P.maxDepth + depthAdded - 1 ) {
+				pathDone = true;  // pathtracing.cl:274-276: ends with no contribution
+			}
+			else {
+				seed += hit.t;
+
+				const f3 hitPoint = fma3( hit.t, ray.dir, ray.origin );
+
+				// shadowRayTest, pathtracing.cl:188-199, :284-290
+				bool lit = false;
+				f3 lightDir = mk3( 0.0f, 0.0f, 0.0f );
+				f3 lightRgb = mk3( -1.0f, -1.0f, -1.0f );
+
+				if( SHADOW && LIGHTS ) {
+					if( mtl.d > 0.0f ) {
+						const float4 lpos4 = P.lights[0];
+						const f3 lpos = mk3( lpos4.x, lpos4.y, lpos4.z );
+						Ray lightRay;
+						lightRay.origin = hitPoint;
+						lightRay.dir = normalize( lpos - hitPoint );
+						const f3 dl = lpos - hitPoint;
+						const float tLight = sqrt1( dot( dl, dl ) );
+						Hit lh;
+						lh.t = tLight;
+						lh.face = 0;
+						unsigned unusedNodes = 0;
+						traverse<true, LIGHTS>( P, lightRay, lh, unusedNodes, dbgTris );
+						lightDir = lightRay.dir;
+
+						if( lh.t >= tLight ) {
+							const float4 rgb = P.lights[1];
+							lightRgb = mk3( rgb.x, rgb.y, rgb.z );
+							lit = ( lightRgb.x >= 0.0f );
+						}
+					}
 				}
 
-				sample++;
+				// getNewRay, pt_brdf.cl:344-378 — uses the UNflipped normal
+				const f3 newDir = newRayDir<BRDF>( ray.dir, normal, mtl, seed, addDepth );
 
-				if( sample == P.samples ) {
-					// pathtracing.cl:326-333 + setColors, pt_rgb.cl:9-21
-					const float sp = (float) secondaryPaths;
-					finalColor = mk3( finalColor.x / sp, finalColor.y / sp, finalColor.z / sp );
+				// pathtracing.cl:298-300
+				if( dot( normal, -ray.dir ) <= 0.0f ) {
+					normal = -normal;
+				}
 
-					if( P.samples > 1 ) {
-						const float ns = (float) P.samples;
-						finalColor = mk3( finalColor.x / ns, finalColor.y / ns, finalColor.z / ns );
-					}
+				// updateColor, pathtracing.cl:89-178
+				if( SHADOW && LIGHTS ) {
+					if( lit ) {
+						f3 add;
 
-					const unsigned n = (unsigned) ( P.firstCount + frame );
-					const float w = P.useExplicitWeight ? P.explicitWeight : ( (float) n / (float) ( n + 1u ) );
-					acc = mk3(
-						finalColor.x + ( acc.x - finalColor.x ) * w,
-						finalColor.y + ( acc.y - finalColor.y ) * w,
-						finalColor.z + ( acc.z - finalColor.z ) * w
-					);
-					accW = focus;
-
-					totNodes += dbgNodes;
-					totTris += dbgTris;
-					frame++;
-
-					if( frame == P.nFrames ) {
-						alive = false;
-					}
-					else {
-						sample = 0;
-						finalColor = mk3( 0.0f, 0.0f, 0.0f );
-						secondaryPaths = 1;
-						focus = 0.0f;
-						dbgNodes = 0;
-						dbgTris = 0;
-						seed = P.seeds[frame];
+						if( shadowContribution<BRDF>( mtl, ray.dir, lightDir, normal, color, lightRgb, &add ) ) {
+							finalColor = finalColor + add;
+							secondaryPaths += 1;
+						}
 					}
 				}
 
-				if( alive ) {
-					color = mk3( 1.0f, 1.0f, 1.0f );
-					depth = 0;
-					depthAdded = 0;
-					ray = initRay( P, px, py, seed, tFocus, tObject );
-					totPaths++;
+				color = color * throughput<BRDF>( mtl, ray.dir, newDir, normal );
+
+				depthAdded += ( addDepth && depthAdded < P.maxAddedDepth ) ? 1 : 0;
+
+				// russianRoulette, pt_utils.cl:385-387: rand drawn only if the first clause holds
+				const float maxValColor = fmax1( color.x, fmax1( color.y, color.z ) );
+				bool terminate = false;
+
+				if( depth > 2 + depthAdded ) {
+					terminate = ( maxValColor < rnd( seed ) );
+				}
+
+				if( terminate ) {
+					pathDone = true;
+				}
+				else {
+					ray.origin = hitPoint;
+					ray.dir = newDir;
+					depth++;
+					pathDone = !( depth < P.maxDepth + depthAdded );
 				}
 			}
 		}
 
-		P.imgOut[pixel] = make_float4( acc.x, acc.y, acc.z, accW );
 
-		// writeDebugImage, pathtracing.cl:73-78 (counters of the LAST frame of this launch)
-		if( P.imgDbg != nullptr ) {
-			P.imgDbg[pixel] = make_float4( (float) dbgTris / 1082.0f, (float) dbgNodes / 1265.0f, 0.0f, 0.0f );
+	if( !pathDone ) {
+		return false;
+	}
+
+	// pathtracing.cl:320-323
+	if( light.x > -1.0f ) {
+		finalColor = finalColor + color * light;
+	}
+
+	st.sample++;
+
+	if( st.sample == P.samples ) {
+		// pathtracing.cl:326-333 + setColors, pt_rgb.cl:9-21
+		const float sp = (float) secondaryPaths;
+		finalColor = mk3( finalColor.x / sp, finalColor.y / sp, finalColor.z / sp );
+
+		if( P.samples > 1 ) {
+			const float ns = (float) P.samples;
+			finalColor = mk3( finalColor.x / ns, finalColor.y / ns, finalColor.z / ns );
 		}
 
-		// one set of atomics per wave and tile
-		const unsigned long long sumNodes = waveSum( totNodes );
-		const unsigned long long sumTris = waveSum( totTris );
-		const unsigned long long sumHits = waveSum( totHits );
-		const unsigned long long sumPaths = waveSum( totPaths );
+		const unsigned n = (unsigned) ( P.firstCount + st.frame );
+		const float w = P.useExplicitWeight ? P.explicitWeight : ( (float) n / (float) ( n + 1u ) );
+		st.acc = mk3(
+			finalColor.x + ( st.acc.x - finalColor.x ) * w,
+			finalColor.y + ( st.acc.y - finalColor.y ) * w,
+			finalColor.z + ( st.acc.z - finalColor.z ) * w
+		);
+		st.accW = st.focus;
 
-		if( lane == 0 ) {
-			atomicAdd( &P.counters[0], sumNodes );
-			atomicAdd( &P.counters[1], sumTris );
-			atomicAdd( &P.counters[2], sumHits );
-			atomicAdd( &P.counters[3], sumPaths );
+		cnt.nodes += st.dbgNodes;
+		cnt.tris += st.dbgTris;
+		st.frame++;
+
+		if( st.frame == P.nFrames ) {
+			return true;
+		}
+
+		st.sample = 0;
+		finalColor = mk3( 0.0f, 0.0f, 0.0f );
+		secondaryPaths = 1;
+		st.focus = 0.0f;
+		st.dbgNodes = 0;
+		st.dbgTris = 0;
+		seed = P.seeds[st.frame];
+	}
+
+	color = mk3( 1.0f, 1.0f, 1.0f );
+	depth = 0;
+	depthAdded = 0;
+	ray = initRay( P, st.px, st.py, seed, st.tFocus, st.tObject );
+	cnt.paths++;
+
+	return false;
+}
+
+// Work distribution.  EVERY lane draws pixel slots from one device-wide counter with a plain
+// per-lane atomicAdd( counter, 1 ); hipcc folds the adds of the lanes that are active at that
+// point into one wave-level add (v_mbcnt + s_bcnt1 + a single global_atomic_add) and hands
+// each lane base + its rank — the ballot / prefix-sum refill, done by the compiler.  Slots are
+// tile-major, so lanes that fetch together work on neighbouring pixels and their framebuffer
+// accesses coalesce; correctness does not depend on it (slot -> pixel is a bijection).
+//
+//   REFILL = true   one merged per-lane loop: a lane whose pixel is finished (all frames) takes
+//                   the next slot at once while its neighbours keep tracing — no lane waits for
+//                   the slowest pixel of a tile.  For launches of many frames.
+//   REFILL = false  nested loops: the lanes of a wave reconverge after each pixel, i.e. a wave
+//                   walks whole 8x8 tiles like an OpenCL work-group of the reference does
+//                   (one atomic per tile).  For single-frame launches, where a per-path refill
+//                   would cost one atomic per path.
+//
+// (A lane-0 atomic + readfirstlane + wave-uniform `break` formulation of this loop was
+// miscompiled by ROCm 7.2 hipcc into an endless re-run of tile 0 on gfx950 — DESIGN.md,
+// "Toolchain notes" — hence the deliberately per-lane control flow.)
+template<int BRDF, bool SHADOW, bool LIGHTS, bool REFILL>
+__global__ __launch_bounds__( 256 ) void pathTracing( const DevParams P ) {
+	const unsigned total = (unsigned) P.numLocalTiles * 64u;
+	LaneCounters cnt;
+	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
+	PixelState st;
+
+	unsigned slot = atomicAdd( P.workCounter, 1u );
+
+	if( REFILL ) {
+		bool have = ( slot < total );
+#ifdef PBR_GUARD_PATH
+		long long guardSteps = 0;
+		const long long guardMax = ( (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1 ) * ( (long long) total + 1 );
+#endif
+
+		if( have ) {
+			beginPixel( P, st, slot, cnt );
+		}
+
+		while( have ) {
+#ifdef PBR_GUARD_PATH
+			if( ++guardSteps > guardMax ) {
+				atomicAdd( &P.guard[1], 1u );
+				break;
+			}
+#endif
+			if( stepPixel<BRDF, SHADOW, LIGHTS>( P, st, cnt ) ) {
+				finishPixel( P, st );
+
+				if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
+					flushCounters( P, cnt );
+				}
+
+				slot = atomicAdd( P.workCounter, 1u );
+				have = ( slot < total );
+
+				if( have ) {
+					beginPixel( P, st, slot, cnt );
+				}
+			}
 		}
 	}
+	else {
+#ifdef PBR_GUARD_TILES
+		int guardTiles = 0;
+#endif
+
+		while( slot < total ) {
+#ifdef PBR_GUARD_TILES
+			if( ++guardTiles > P.numLocalTiles + 1 ) {
+				atomicAdd( &P.guard[0], 1u );
+				break;
+			}
+#endif
+			beginPixel( P, st, slot, cnt );
+#ifdef PBR_GUARD_PATH
+			long long guardSteps = 0;
+			const long long guardMax = (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1;
+#endif
+
+			while( !stepPixel<BRDF, SHADOW, LIGHTS>( P, st, cnt ) ) {
+#ifdef PBR_GUARD_PATH
+				if( ++guardSteps > guardMax ) {
+					atomicAdd( &P.guard[1], 1u );
+					break;
+				}
+#endif
+			}
+
+			finishPixel( P, st );
+
+			if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
+				flushCounters( P, cnt );
+			}
+
+			slot = atomicAdd( P.workCounter, 1u );
+		}
+	}
+
+	flushCounters( P, cnt );
 }
 
 
@@ -993,6 +1123,120 @@ __global__ void scatterGathered( const float4* all, float4* tiles, int numTiles,
 	const int rank = tileGlobal % tileWorld;
 	const int local = tileGlobal / tileWorld;
 	tiles[i] = all[( (size_t) rank * perRank + local ) * 64 + lane];
+}
+
+
+
+// ---------------------------------------------------------------------------------------
+// Diagnostic kernels (include/pbr_hip_diag.h): one thread per item, for stage-by-stage parity
+// ---------------------------------------------------------------------------------------
+
+__global__ void diagMath( int op, const float* x, const float* y, int n, float* out ) {
+	const int i = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
+
+	if( i >= n ) {
+		return;
+	}
+
+	float s, c;
+
+	switch( op ) {
+		case 0: sincos( x[i], &s, &c ); out[i] = s; break;
+		case 1: sincos( x[i], &s, &c ); out[i] = c; break;
+		case 2: out[i] = tan1( x[i] ); break;
+		case 3: out[i] = acos1( x[i] ); break;
+		case 4: out[i] = atan1( x[i] ); break;
+		case 5: out[i] = pow1( x[i], y[i] ); break;
+		case 6: out[i] = fract( sin1( x[i] ) * 43758.5453123f ); break;
+		default: out[i] = 0.0f; break;
+	}
+}
+
+// rays: n x {origin, dir}; outputs as orc_trace_rays
+template<bool LIGHTS>
+__global__ void diagTrace( const DevParams P, const float* rays, int n, float* outT, int* outFace, float* outNormal, unsigned* outCounts ) {
+	const int i = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
+
+	if( i >= n ) {
+		return;
+	}
+
+	Ray ray;
+	ray.origin = mk3( rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2] );
+	ray.dir = mk3( rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5] );
+	Hit hit;
+	hit.t = inff();
+	hit.face = 0;
+	unsigned nodes = 0, tris = 0;
+	traverse<false, LIGHTS>( P, ray, hit, nodes, tris );
+
+	f3 normal = mk3( 0.0f, 0.0f, 0.0f );
+
+	if( hit.t != inff() ) {
+		int material;
+		normal = faceNormal( P, hit.face, &material );
+	}
+
+	outT[i] = hit.t;
+	outFace[i] = hit.face;
+	outNormal[i * 3 + 0] = normal.x;
+	outNormal[i * 3 + 1] = normal.y;
+	outNormal[i * 3 + 2] = normal.z;
+	outCounts[i * 2 + 0] = nodes;
+	outCounts[i * 2 + 1] = tris;
+}
+
+// in: n x 16 {out_dir, in_dir, normal, pad}; out: n x 4 (as orc_brdf_eval); material 0 of P.mats
+template<int BRDF>
+__global__ void diagBrdf( const DevParams P, const float* in, int n, float* out ) {
+	const int i = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
+
+	if( i >= n ) {
+		return;
+	}
+
+	const float* p = in + (size_t) i * 16;
+	const Material mtl = loadMaterial( P, 0 );
+	const f3 outDir = mk3( p[0], p[1], p[2] );
+	const f3 inDir = mk3( p[3], p[4], p[5] );
+	const f3 normal = mk3( p[6], p[7], p[8] );
+	float* o = out + (size_t) i * 4;
+
+	if( BRDF == 0 ) {
+		float u, pdf;
+		const float b = brdfSchlick( mtl, outDir, inDir, normal, &u, &pdf );
+		o[0] = b; o[1] = u; o[2] = pdf; o[3] = 0.0f;
+	}
+	else {
+		float spec, diff, dotHK1, pdf;
+		brdfSA( mtl, outDir, inDir, normal, &spec, &diff, &dotHK1, &pdf );
+		o[0] = spec; o[1] = diff; o[2] = dotHK1; o[3] = pdf;
+	}
+}
+
+// in: n x 12 {origin, dir, normal, t, seed, pad}; out: n x 8 (as orc_new_ray); material 0
+template<int BRDF>
+__global__ void diagNewRay( const DevParams P, const float* in, int n, float* out ) {
+	const int i = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
+
+	if( i >= n ) {
+		return;
+	}
+
+	const float* p = in + (size_t) i * 12;
+	const Material mtl = loadMaterial( P, 0 );
+	const f3 origin = mk3( p[0], p[1], p[2] );
+	const f3 dir = mk3( p[3], p[4], p[5] );
+	const f3 normal = mk3( p[6], p[7], p[8] );
+	float seed = p[10];
+	bool addDepth = false;
+	const f3 newOrigin = fma3( p[9], dir, origin );
+	const f3 newDir = newRayDir<BRDF>( dir, normal, mtl, seed, addDepth );
+	float* o = out + (size_t) i * 8;
+	o[0] = newOrigin.x; o[1] = newOrigin.y; o[2] = newOrigin.z;
+	o[3] = newDir.x; o[4] = newDir.y; o[5] = newDir.z;
+	o[6] = seed;
+	o[7] = addDepth ? 1.0f : 0.0f;
 }
 
 }  // namespace ptk

@@ -1,0 +1,188 @@
+"""Scene I/O stand-ins and buffer packing: the parsing quirks of source/ObjParser.cpp,
+MtlParser.cpp, LightParser.cpp and the wire formats of PathTracer::initOpenCLBuffers_*.
+CPU only; every input is written by the test (plus the reference's own assets when present)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE_MODELS
+
+OBJ = """# a comment
+mtllib whatever.mtl
+o First
+v 0 0 0
+v 1 0 0
+v 0 1 0
+v 0 0 1
+vn 0 0 1
+vt 0.5 0.5
+usemtl Red
+f 1//1 2//1 3//1
+f 1/1/1 3/1/1 4/1/1
+usemtl Missing
+f 1 2 4
+o Second
+usemtl Glass
+f 2/1 3/1 4/1
+"""
+
+MTL = """# materials
+newmtl Red
+Kd 0.8 0.1 0.1
+Ni 1.0
+d 1.0
+Tr 0.75
+nu 10
+nv 20
+Rs 0.25
+Rd 0.5
+rough 0.3
+p 0.9
+
+newmtl Glass
+Tr 0.4
+d 0.1
+Ni 1.5
+
+newmtl sky_light
+Kd 0.1234567 0.5 0.9999999
+"""
+
+LIGHTS = """newlight orb0
+type 2
+pos 0.1 1.3 1.2
+rgb 0.846 0.933 0.949
+radius 0.1
+newlight p1
+type 1
+pos 1 2 3
+"""
+
+
+@pytest.fixture()
+def model_dir(tmp_path):
+    (tmp_path / "m.obj").write_text(OBJ)
+    (tmp_path / "m.mtl").write_text(MTL)
+    (tmp_path / "m.lights").write_text(LIGHTS)
+    return str(tmp_path) + "/"
+
+
+def test_obj_quirks_and_packing(cfg_defaults, model_dir):
+    pbr = cfg_defaults
+    sc = pbr.HostScene.load_obj(model_dir, "m.obj")
+    arr, info = sc.arrays(), sc.info
+    assert info["objects"] == 2 and info["faces"] == 4 and info["vertices"] == 4 and info["materials"] == 3
+    assert info["lights"] == 0                                   # shadow_rays = 0: .lights is not even read
+
+    # faces travel in leaf order with the material id in .w; the face after `usemtl Missing` has -1
+    mats = sorted(arr["facesV"][:, 3].tolist())
+    assert mats == [0, 0, 1, 0xFFFFFFFF]
+    tri = {tuple(sorted(f[:3].tolist())) for f in arr["facesV"]}
+    assert tri == {(0, 1, 2), (0, 2, 3), (0, 1, 3), (1, 2, 3)}      # 1-based -> 0-based; "v/vt" read as v//vn keeps v
+
+    # vec3 -> float4 with w = 0
+    assert np.array_equal(arr["vertices"], np.array([[0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32))
+
+    # Shirley-Ashikhmin layout {d, Ni, nu, nv, Rs, Rd, -, -}, Kd, Ks; `Tr` ignored once any `d` was seen
+    m = arr["materials"]
+    assert m.shape == (3, 16)
+    assert np.allclose(m[0, :6], [1.0, 1.0, 10, 20, 0.25, 0.5]) and np.allclose(m[0, 8:11], [0.8, 0.1, 0.1])
+    assert np.allclose(m[1, :2], [0.1, 1.5])                      # Glass: Tr came BEFORE d in its block but after Red's d -> ignored
+    assert np.allclose(m[2, 8:11], [0.1234567, 0.5, 0.9999999])
+
+    # SKY_LIGHT goes through "%f": rounded to 6 decimals (PathTracer.cpp:470-472)
+    cfg = sc.config(64, 64)
+    assert list(cfg.sky_light)[:3] == [np.float32(0.123457), np.float32(0.5), np.float32(1.0)]
+    assert (cfg.brdf, cfg.max_depth, cfg.max_added_depth, cfg.samples, cfg.shadow_rays) == (1, 3, 5, 1, 0)
+    assert cfg.anti_aliasing == np.float32(0.7)
+
+
+def test_schlick_material_layout(cfg_defaults, model_dir):
+    pbr = cfg_defaults
+    pbr.cfg_set(**{"render.brdf": 0})
+    m = pbr.HostScene.load_obj(model_dir, "m.obj").arrays()["materials"]
+    assert m.shape == (3, 12)
+    assert np.allclose(m[0, :4], [1.0, 1.0, 0.9, 0.3])            # d, Ni, p, rough
+    assert np.allclose(m[0, 4:7], [0.8, 0.1, 0.1]) and np.allclose(m[0, 8:11], [1, 1, 1])
+
+
+def test_lights_only_with_shadow_rays(cfg_defaults, model_dir):
+    pbr = cfg_defaults
+    pbr.cfg_set(**{"render.shadow_rays": 1})
+    sc = pbr.HostScene.load_obj(model_dir, "m.obj")
+    assert sc.info["lights"] == 2
+    lights = sc.arrays()["lights"]
+    assert np.allclose(lights[0], [0.1, 1.3, 1.2, 0, 0.846, 0.933, 0.949, 0, 2, 0.1, 0, 0])
+    assert np.allclose(lights[1], [1, 2, 3, 0, 1, 1, 1, 0, 1, 0, 0, 0])
+    assert sc.config(8, 8).shadow_rays == 1
+
+
+def test_missing_lights_file_switches_shadow_rays_off(cfg_defaults, model_dir):
+    """LightParser.cpp:119-121: a .lights file without lights resets render.shadow_rays to 0."""
+    pbr = cfg_defaults
+    pbr.cfg_set(**{"render.shadow_rays": 1})
+    open(model_dir + "m.lights", "w").write("# nothing here\n")
+    sc = pbr.HostScene.load_obj(model_dir, "m.obj")
+    assert sc.info["lights"] == 0
+    assert pbr.cfg_get("render.shadow_rays") == "0"
+    assert sc.config(8, 8).shadow_rays == 0
+
+
+def test_missing_file_is_an_error_not_a_crash(cfg_defaults, tmp_path):
+    pbr = cfg_defaults
+    with pytest.raises(pbr.PbrError):
+        pbr.HostScene.load_obj(str(tmp_path), "nope.obj")
+
+
+def test_cfg_defaults_match_reference_config_json(cfg_defaults):
+    pbr = cfg_defaults
+    expect = {
+        "accel_struct": "0", "bvh.max_faces": "2", "bvh.sah_faces_limit": "100000", "bvh.skip_ahead": "true",
+        "bvh.skip_ahead_compare": "0.7", "render.antialiasing": "0.7", "render.brdf": "1",
+        "render.max_added_depth": "5", "render.max_depth": "3", "render.phong_tessellation": "0.0",
+        "render.samples": "1", "render.shadow_rays": "0", "window.width": "800", "window.height": "600",
+        "camera.eye.y": "1.0", "camera.eye.z": "3.0", "camera.perspective.fov": "45.0",
+        "camera.thin_lense.aperture": "1.8", "camera.thin_lense.focal_length": "0.035",
+    }
+    for key, value in expect.items():
+        assert pbr.cfg_get(key) == value, key
+
+
+def test_cfg_reads_json_with_comments(cfg_defaults, tmp_path):
+    pbr = cfg_defaults
+    path = tmp_path / "config.json"
+    path.write_text('{\n // comment\n "render": { "max_depth": 7, // trailing\n "brdf": 0 },\n "bvh": { "skip_ahead": false },\n "import_path": "/a b/" }\n')
+    assert pbr.host.pbrh_cfg_load(str(path).encode()) == 0
+    assert pbr.cfg_get("render.max_depth") == "7" and pbr.cfg_get("render.brdf") == "0"
+    assert pbr.cfg_get("bvh.skip_ahead") == "false" and pbr.cfg_get("import_path") == "/a b/"
+    assert pbr.cfg_get("render.samples") == "1"                  # untouched keys keep their defaults
+
+
+def test_default_camera_and_pixel_size(cfg_defaults):
+    """updateEyeBuffer (PathTracer.cpp:628-652) on the default pose (config.json:3-18): eye (0,1,3)
+    looking down -Z; initKernelArgs' pixel size (PathTracer.cpp:89-91)."""
+    pbr = cfg_defaults
+    sc = pbr.HostScene.generate("cornell")
+    cam = sc.camera()
+    assert (cam.eye.x, cam.eye.y, cam.eye.z) == (0.0, 1.0, 3.0)
+    assert (cam.w.x, cam.w.y, cam.w.z) == (0.0, 0.0, -1.0)
+    assert (cam.u.x, abs(cam.u.y), cam.u.z) == (1.0, 0.0, 0.0)
+    assert (cam.v.x, cam.v.y, cam.v.z) == (0.0, 1.0, 0.0)
+    assert tuple(cam.focusPoint) == (-1, -1)
+    assert tuple(cam.lense) == (np.float32(0.035), np.float32(1.8))
+    px = pbr.pixel_dimension(800, 600, 45.0)
+    assert px == pytest.approx((800 / 600) * 2 * np.tan(np.radians(45.0) / 2) / 800, rel=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_MODELS), reason="reference assets only exist in the build container")
+@pytest.mark.parametrize("name,faces,objects", [
+    ("pillars.obj", 56, 5), ("spheres.obj", 800, 4), ("squirrel-mirror.obj", 1020, 3),
+    ("squirrels.obj", 1408, 3), ("suzanne.obj", 1082, 10), ("applejack3.obj", 8068, 2),
+])
+def test_reference_assets_load(cfg_defaults, name, faces, objects):
+    pbr = cfg_defaults
+    sc = pbr.HostScene.load_obj(REFERENCE_MODELS, name)
+    assert sc.info["faces"] == faces and sc.info["objects"] == objects
+    arr = sc.arrays()
+    assert arr["facesV"][:, :3].max() < sc.info["vertices"]

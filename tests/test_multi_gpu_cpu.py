@@ -1,0 +1,80 @@
+"""The N > 1 path on CPU: two processes, gloo.  Each rank renders ONLY its tiles (with the
+oracle standing in for the device — this is a test), packs them in the compact tile-major layout,
+all-gathers, de-interleaves; the result must be bit-identical to the single-process frame
+(SURVEY.md §8e invariant).  Also checks the layout helpers against each other."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, same_values
+
+W, H, FRAMES = 64, 48, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _render_rows(pbr, orc, world, rank):
+    """Full-frame oracle render restricted to the pixels of `rank`'s tiles."""
+    pbr.cfg_reset()
+    sc = pbr.HostScene.generate("cornell")
+    cfg, cam, px = sc.config(W, H), sc.camera(), pbr.pixel_dimension(W, H)
+    img = orc.Renderer(sc.desc, cfg).render(0, pbr.frame_seeds(0, FRAMES), px, cam)
+    mask = pbr.tiles.rows_of_rank(W, H, world, rank)
+    return np.where(mask[..., None], img, 0).astype(np.float32), img
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import pbr_loader
+    pbr = pbr_loader.load()
+    from oracle import oracle as orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine, _ = _render_rows(pbr, orc, world, rank)
+        local = torch.from_numpy(pbr.tiles.pack_rank_tiles(mine, world, rank).copy()).reshape(-1)
+        gathered = torch.empty(world * local.numel(), dtype=local.dtype)
+        dist.all_gather_into_tensor(gathered, local)
+        frame = pbr.tiles.unpack_gathered(gathered.numpy(), W, H, world)
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), frame)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_is_bit_identical_to_one_rank(tmp_path, pbr, oracle):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    _, full = _render_rows(pbr, oracle, 1, 0)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % rank))
+        assert same_values(got, full), "rank %d" % rank
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_tile_layout_round_trip(pbr, world):
+    rng = np.random.default_rng(world)
+    w, h = 72, 40                                   # 45 tiles: not divisible by 2, 8
+    img = rng.random((h, w, 4), dtype=np.float32)
+    t = pbr.tiles
+    assert same_values(t.from_tile_major(t.to_tile_major(img), w, h), img)
+    bufs = np.stack([t.pack_rank_tiles(img, world, r) for r in range(world)])
+    assert bufs.shape[1] == t.tile_counts(w, h, world)[3]
+    assert same_values(t.unpack_gathered(bufs, w, h, world), img)
+    masks = sum(t.rows_of_rank(w, h, world, r).astype(int) for r in range(world))
+    assert (masks == 1).all()                       # every pixel has exactly one owner
+    ids = np.concatenate([t.local_tile_ids(w, h, world, r) for r in range(world)])
+    assert sorted(ids.tolist()) == list(range(45))
