@@ -1,0 +1,422 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs — bit for bit (compared numerically: -0 == +0, NaN == NaN) — stage by stage and
+on whole images, plus size-independent properties at BASELINE.json's full resolution.
+Every test here needs a real MI355X."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, same_values, describe_mismatch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_golden  # noqa: E402
+
+
+@pytest.fixture()
+def device(pbr, gpu_device):
+    dev = pbr.Device(gpu_device)
+    yield dev
+    dev.close()
+
+
+def make_scene(pbr, kind="cornell", seed=1, triangles=0, **cfg):
+    pbr.cfg_reset()
+    pbr.cfg_set(**cfg)
+    return pbr.HostScene.generate(kind, seed, triangles)
+
+
+def both_render(pbr, oracle, dev, sc, w, h, frames, first=0, cam=None, cfg=None, desc=None):
+    cfg = cfg or sc.config(w, h)
+    cam = cam or sc.camera()
+    desc = desc or sc.desc
+    px = pbr.pixel_dimension(w, h)
+    seeds = pbr.frame_seeds(first, frames)
+    ref = oracle.Renderer(desc, cfg, threads=8)
+    want = ref.render(first, seeds, px, cam)
+    dev.upload_scene(desc)
+    dev.configure(cfg)
+    dev.render(first, seeds, px, cam)
+    return dev.read_output(), want, ref
+
+
+# ----------------------------------------------------------------------------------------------
+# stages
+# ----------------------------------------------------------------------------------------------
+
+def test_math_layer_bit_exact(pbr, oracle, device):
+    rng = np.random.default_rng(0)
+    wide = np.concatenate([rng.uniform(-60, 60, 200000), rng.uniform(-2e4, 2e4, 50000), [0, -0.0, np.inf, -np.inf, np.nan, 3e8, 1e-40]]).astype(np.float32)
+    unit = np.concatenate([rng.uniform(-1, 1, 200000), [-1, 1, 0.5, -0.5, 1.5, np.nan]]).astype(np.float32)
+    for op, x in (("sin", wide), ("cos", wide), ("tan", wide), ("randhash", wide), ("acos", unit), ("atan", wide)):
+        got, want = device.diag_math(op, x), oracle.math(op, x)
+        assert same_values(got, want), op + ": " + describe_mismatch(got, want)
+    base = np.concatenate([rng.uniform(0, 1, 200000), rng.uniform(0, 30, 50000)]).astype(np.float32)
+    expo = np.concatenate([10 ** rng.uniform(-3, 5.5, 200000), rng.uniform(-20, 20, 50000)]).astype(np.float32)
+    assert same_values(device.diag_math("pow", base, expo), oracle.math("pow", base, expo))
+    sp = np.array([0, -0.0, 1, -1, np.inf, -np.inf, np.nan, 2, -2, 0.5, -0.5, 3, -3, 1e-40, 16777216, 16777217, -7], np.float32)
+    X, Y = [a.ravel().copy() for a in np.meshgrid(sp, sp)]
+    got, want = device.diag_math("pow", X, Y), oracle.math("pow", X, Y)
+    assert same_values(got, want), describe_mismatch(got, want)
+
+
+@pytest.mark.parametrize("kind,triangles,skip", [("cornell", 0, True), ("cornell", 0, False), ("sponza", 8000, True), ("dragon", 8000, True), ("hairball", 6000, True)])
+def test_traversal_bit_exact(pbr, oracle, device, kind, triangles, skip):
+    sc = make_scene(pbr, kind, 2, triangles, **{"bvh.skip_ahead": skip})
+    cfg = sc.config(64, 64)
+    v = sc.arrays()["vertices"][:, :3]
+    rng = np.random.default_rng(3)
+    rays = np.concatenate([rng.uniform(v.min(0) - 0.3, v.max(0) + 0.3, (5000, 3)), rng.normal(size=(5000, 3))], axis=1).astype(np.float32)
+    rays[:, 3:] /= np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+    rays[:7, 3:] = [[1, 0, 0], [0, 1, 0], [0, 0, -1], [0, -1, 0], [1, 1, 0], [0, 0, 1], [-1, 0, 0]]   # axis-parallel: 1/0 = inf in the slab test
+    device.upload_scene(sc.desc)
+    t, face, normal, counts = device.diag_trace(rays)
+    ot, oface, onormal, ocounts = oracle.trace_rays(sc.desc, cfg, rays)
+    assert same_values(t, ot), describe_mismatch(t, ot)
+    hit = np.isfinite(ot)
+    assert hit.sum() > 500
+    assert np.array_equal(face[hit], oface[hit]) and same_values(normal[hit], onormal[hit])
+    assert np.array_equal(counts, ocounts)
+    assert device.guard_trips() == [0, 0, 0]
+
+
+MATERIALS_SA = [
+    [1, 1, 0, 0, 0, 1, 0, 0, .7, .7, .7, 0, 1, 1, 1, 0],
+    [1, 1, 200, 200, .7, .6, 0, 0, .8, .8, .85, 0, .9, .9, .9, 0],
+    [1, 1, 100000, 100000, 1, 1, 0, 0, 1, 1, 1, 0, 1, 1, 1, 0],       # suzanne.mtl "Suzanne": pow( x, 1e5 )
+    [1, 1, 10, 1000, .3, .8, 0, 0, .5, .6, .7, 0, .9, .8, .7, 0],     # anisotropic
+    [0.1, 1.5, 0, 0, .2, 1, 0, 0, .95, .95, 1, 0, 1, 1, 1, 0],        # glass
+    [0.6, 1.33, 50, 50, .5, .5, 0, 0, .2, .4, .9, 0, 1, 1, 1, 0],
+]
+MATERIALS_SCHLICK = [
+    [1, 1, 1, 1, .7, .7, .7, 0, 1, 1, 1, 0],
+    [1, 1, 1, 0.15, .8, .8, .85, 0, .9, .9, .9, 0],
+    [1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 0],                             # mirror
+    [1, 1, 0.3, 0.6, .5, .6, .7, 0, .9, .8, .7, 0],                   # anisotropic, p < 1
+    [0.1, 1.5, 1, 0.05, .95, .95, 1, 0, 1, 1, 1, 0],
+]
+
+
+def single_material_desc(pbr, sc, brdf, mtl):
+    """The scene's geometry with ONE material (index 0 is what the diag kernels read)."""
+    d = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    m = np.tile(np.asarray(mtl, np.float32), (sc.desc.num_materials, 1)).copy()
+    d.materials, d.brdf = m.ctypes.data, brdf
+    return d, m
+
+
+@pytest.mark.parametrize("brdf,materials", [(1, MATERIALS_SA), (0, MATERIALS_SCHLICK)])
+def test_brdf_and_new_ray_bit_exact(pbr, oracle, device, brdf, materials):
+    sc = make_scene(pbr, **{"render.brdf": brdf})
+    rng = np.random.default_rng(9)
+    n = 4000
+
+    def unit(a):
+        return a / np.linalg.norm(a, axis=1, keepdims=True)
+
+    normal = unit(rng.normal(size=(n, 3)))
+    out_dir = unit(rng.normal(size=(n, 3)))
+    out_dir -= 2 * np.maximum(0, (out_dir * normal).sum(1, keepdims=True)) * normal     # arriving: out_dir . n <= 0
+    in_dir = unit(rng.normal(size=(n, 3)))
+    in_dir += 2 * np.maximum(0, -(in_dir * normal).sum(1, keepdims=True)) * normal      # leaving: in_dir . n >= 0
+    ev = np.zeros((n, 16), np.float32)
+    ev[:, 0:3], ev[:, 3:6], ev[:, 6:9] = out_dir, in_dir, normal
+    nr = np.zeros((n, 12), np.float32)
+    nr[:, 0:3] = rng.uniform(-1, 1, (n, 3))
+    nr[:, 3:6], nr[:, 6:9] = out_dir, normal
+    nr[: n // 4, 6:9] *= -1                                                               # back-facing normals too
+    nr[:, 9] = rng.uniform(0.01, 5, n)
+    nr[:, 10] = rng.uniform(0, 300, n)
+    fp = ctypes.POINTER(ctypes.c_float)
+
+    for mtl in materials:
+        desc, keep = single_material_desc(pbr, sc, brdf, mtl)
+        device.upload_scene(desc)
+        m0 = np.asarray(mtl, np.float32)
+        want = np.empty((n, 4), np.float32)
+        oracle.lib().orc_brdf_eval(brdf, m0.ctypes.data, ev.ctypes.data_as(fp), n, want.ctypes.data_as(fp))
+        got = device.diag_brdf(ev)
+        assert same_values(got, want), "brdf %r: %s" % (mtl[:6], describe_mismatch(got, want))
+        want = np.empty((n, 8), np.float32)
+        oracle.lib().orc_new_ray(brdf, m0.ctypes.data, nr.ctypes.data_as(fp), n, want.ctypes.data_as(fp))
+        got = device.diag_new_ray(nr)
+        assert same_values(got, want), "new ray %r: %s" % (mtl[:6], describe_mismatch(got, want))
+
+
+# ----------------------------------------------------------------------------------------------
+# whole images
+# ----------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("schedule", ["refill", "tile"])
+@pytest.mark.parametrize("cfg", [
+    {"render.max_depth": 4},
+    {"render.max_depth": 4, "render.brdf": 0},
+    {"render.max_depth": 8, "render.max_added_depth": 2},
+    {"render.samples": 3},
+    {"render.antialiasing": 0.0, "render.max_depth": 1, "render.max_added_depth": 0},
+])
+def test_cornell_image_bit_exact(pbr, oracle, device, monkeypatch, schedule, cfg):
+    monkeypatch.setenv("PBR_SCHEDULE", schedule)
+    sc = make_scene(pbr, **cfg)
+    got, want, ref = both_render(pbr, oracle, device, sc, 64, 48, 5)
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert same_values(device.read_debug(), ref.debug)
+    assert device.counters() == ref.counter_dict()
+    assert device.guard_trips() == [0, 0, 0]
+
+
+@pytest.mark.parametrize("kind,triangles,w,h", [("sponza", 20000, 96, 56), ("dragon", 20000, 64, 64), ("hairball", 20000, 64, 64)])
+def test_larger_scenes_bit_exact(pbr, oracle, device, kind, triangles, w, h):
+    sc = make_scene(pbr, kind, 4, triangles)
+    got, want, ref = both_render(pbr, oracle, device, sc, w, h, 4)
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert device.counters() == ref.counter_dict()
+
+
+def lit_scene(pbr, brdf):
+    """Cornell + one orb light above the hole + one point light (a scene file with lights needs
+    render.shadow_rays = 1 at load time, ObjParser.cpp:133; here the arrays are patched)."""
+    sc = make_scene(pbr, **{"render.brdf": brdf, "render.max_depth": 4})
+    lights = np.zeros((2, 12), np.float32)
+    lights[0] = [0.1, 1.6, 0.2, 0, 4.0, 3.5, 3.0, 0, 2, 0.12, 0, 0]
+    lights[1] = [-0.5, 0.4, 0.6, 0, 1, 1, 1, 0, 1, 0, 0, 0]
+    desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    desc.lights, desc.num_lights = lights.ctypes.data, 2
+    return sc, desc, lights
+
+
+@pytest.mark.parametrize("brdf", [1, 0])
+@pytest.mark.parametrize("shadow", [0, 1])
+def test_lights_and_shadow_rays_bit_exact(pbr, oracle, device, brdf, shadow):
+    sc, desc, keep = lit_scene(pbr, brdf)
+    cfg = sc.config(64, 64)
+    cfg.shadow_rays = shadow
+    got, want, ref = both_render(pbr, oracle, device, sc, 64, 64, 4, cfg=cfg, desc=desc)
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert device.counters() == ref.counter_dict()
+    # the orb is visible through the hole: some pixels carry its colour, not the sky's
+    assert (want[..., 0] > 1.5).any()
+
+
+def test_depth_of_field_frame_by_frame(pbr, oracle, device):
+    """setFocus: every pixel reads the focus pixel's previous-frame distance (pathtracing.cl:58-65),
+    so frames cannot be fused; frame 0 has no previous distances (w = 0: no lens offset)."""
+    sc = make_scene(pbr, **{"render.max_depth": 4})
+    w, h = 64, 64
+    cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    cam.focusPoint[0], cam.focusPoint[1] = 20, 30
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    with pytest.raises(pbr.PbrError, match="focusPoint"):
+        device.render(0, pbr.frame_seeds(0, 2), px, cam)
+    ref = oracle.Renderer(sc.desc, cfg, threads=8)
+    for k, seed in enumerate(pbr.frame_seeds(0, 4)):
+        weight = float(np.float32(k) / np.float32(k + 1))
+        ref.image = ref.render_frame(float(seed), weight, px, cam)
+        device.render_frame(float(seed), weight, px, cam)
+        got = device.read_output()
+        assert same_values(got, ref.image), "frame %d: %s" % (k, describe_mismatch(got, ref.image))
+        device.accumulate()
+    nofocus = pbr.Camera.from_buffer_copy(cam)
+    nofocus.focusPoint[0] = nofocus.focusPoint[1] = -1
+    plain = oracle.Renderer(sc.desc, cfg, threads=8).render(0, pbr.frame_seeds(0, 4), px, nofocus)
+    assert not same_values(plain, ref.image)                       # the lens did something
+
+
+def test_write_input_and_explicit_weights(pbr, oracle, device):
+    """CL::updateImageReadOnly + arbitrary pixelWeight: the reference's host ping-pong."""
+    sc = make_scene(pbr)
+    w, h = 40, 24
+    cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    prev = np.random.default_rng(1).random((h, w, 4), dtype=np.float32)
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    device.write_input(prev)
+    device.render_frame(1.25, 0.3, px, cam)
+    ref = oracle.Renderer(sc.desc, cfg)
+    ref.image = prev.copy()
+    want = ref.render_frame(1.25, 0.3, px, cam)
+    assert same_values(device.read_output(), want)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_sharding_is_bit_identical(pbr, oracle, device, world):
+    """SURVEY.md §8e invariant on one GPU: `world` contexts each render their tiles; the
+    exported compact buffers, concatenated as an all-gather would, re-assemble the 1-rank frame."""
+    import torch
+    sc = make_scene(pbr, **{"render.max_depth": 4})
+    w, h = 72, 40                                                   # 45 tiles: uneven shares
+    cam, px, seeds = sc.camera(), pbr.pixel_dimension(w, h), pbr.frame_seeds(0, 5)
+    full, want, _ = both_render(pbr, oracle, device, sc, w, h, 5)
+    assert same_values(full, want)
+
+    gathered, devs = None, []
+    for rank in range(world):
+        d = pbr.Device(0)
+        devs.append(d)
+        cfg = sc.config(w, h)
+        cfg.tile_world, cfg.tile_rank = world, rank
+        d.upload_scene(sc.desc)
+        d.configure(cfg)
+        d.render(0, seeds, px, cam)
+        if gathered is None:
+            gathered = torch.zeros(world * d.tile_bytes() // 4, dtype=torch.float32, device="cuda")
+        d.export_tiles(gathered.data_ptr() + rank * d.tile_bytes())
+        part = d.read_output()
+        mask = pbr.tiles.rows_of_rank(w, h, world, rank)
+        assert same_values(part[mask], want[mask]) and not part[~mask].any()
+        # the exported buffer is the layout tiles.py describes
+        host = gathered.cpu().numpy().reshape(world, -1)[rank]
+        assert same_values(host.reshape(-1, 64, 4), pbr.tiles.pack_rank_tiles(np.where(mask[..., None], want, 0), world, rank))
+    torch.cuda.synchronize()
+    devs[0].import_tiles(gathered.data_ptr())
+    assert same_values(devs[0].read_full(), want)
+    for d in devs:
+        d.close()
+
+
+@pytest.mark.parametrize("name", sorted(make_golden.CASES))
+def test_hip_reproduces_golden_fixtures(pbr, device, name):
+    kind, seed, tris, overrides, w, h, frames = make_golden.CASES[name]
+    want = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    sc = make_scene(pbr, kind, seed, tris, **overrides)
+    assert np.array_equal(sc.arrays()["bvh"], want["bvh"])
+    device.upload_scene(sc.desc)
+    device.configure(sc.config(w, h))
+    device.render(0, pbr.frame_seeds(0, frames), float(want["px_dim"]), sc.camera())
+    got = device.read_output()
+    assert same_values(got, want["image"]), describe_mismatch(got, want["image"])
+    assert same_values(device.read_debug(), want["debug"])
+    c = device.counters()
+    assert [c["nodes"], c["tris"], c["hits"], c["paths"]] == want["counters"].tolist()
+    t, face, _, counts = device.diag_trace(want["rays"])
+    assert same_values(t, want["ray_t"]) and np.array_equal(counts, want["ray_counts"])
+
+
+def test_path_tracer_driver_matches_device_calls(pbr, oracle, gpu_device):
+    """The C++ PathTracer (host/path_tracer.h) driven like GLWidget drives the reference's:
+    initOpenCLBuffers, then generateImage per frame; and generateImages (fused)."""
+    sc = make_scene(pbr, **{"render.max_depth": 4})
+    w, h = 64, 40
+    cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    want = oracle.Renderer(sc.desc, cfg, threads=8).render(0, pbr.frame_seeds(0, 4), px, cam)
+    pt = pbr.PathTracer(gpu_device, w, h)
+    pt.initOpenCLBuffers(sc)
+    for _ in range(4):
+        img = pt.generateImage()
+    assert pt.sampleCount() == 4 and same_values(img, want)
+    pt2 = pbr.PathTracer(gpu_device, w, h)
+    pt2.initOpenCLBuffers(sc)
+    assert same_values(pt2.generateImages(4), want)
+    more = pt2.generateImages(3)                                    # continues the running mean at n = 4
+    want7 = oracle.Renderer(sc.desc, cfg, threads=8).render(0, pbr.frame_seeds(0, 7), px, cam)
+    assert same_values(more, want7)
+    pt.close()
+    pt2.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# error behaviour of the boundary
+# ----------------------------------------------------------------------------------------------
+
+def test_call_sequence_and_validation_errors(pbr, device):
+    sc = make_scene(pbr)
+    cam, px = sc.camera(), pbr.pixel_dimension(64, 64)
+    with pytest.raises(pbr.PbrError, match="before"):
+        device.render(0, pbr.frame_seeds(0, 1), px, cam)
+    device.upload_scene(sc.desc)
+    with pytest.raises(pbr.PbrError, match="before"):
+        device.render(0, pbr.frame_seeds(0, 1), px, cam)
+
+    cfg = sc.config(60, 64)
+    with pytest.raises(pbr.PbrError, match="multiples of 8"):
+        device.configure(cfg)
+    cfg = sc.config(64, 64)
+    cfg.phong_tessellation = 0.5
+    with pytest.raises(pbr.PbrError, match="Phong"):
+        device.configure(cfg)
+    cfg = sc.config(64, 64)
+    cfg.brdf = 0
+    device.configure(cfg)
+    with pytest.raises(pbr.PbrError, match="BRDF"):
+        device.render(0, pbr.frame_seeds(0, 1), px, cam)
+
+    # a face without `usemtl` carries material -1 (ObjParser.cpp:192): out of bounds in the reference
+    arr = sc.arrays()
+    bad = arr["facesV"].copy()
+    bad[3, 3] = 0xFFFFFFFF
+    d = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    d.facesV = bad.ctypes.data
+    with pytest.raises(pbr.PbrError, match="material index"):
+        device.upload_scene(d)
+    links = arr["bvh"].copy()
+    links[2, 7] = 1e6
+    d = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    d.bvh = links.ctypes.data
+    with pytest.raises(pbr.PbrError, match="node 2"):
+        device.upload_scene(d)
+    d = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    d.num_nodes = 1
+    with pytest.raises(pbr.PbrError, match="root is never tested"):
+        device.upload_scene(d)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json sizes: size-independent properties at 1920 x 1080
+# ----------------------------------------------------------------------------------------------
+
+def test_full_hd_properties(pbr, oracle, device):
+    """Config 2 (Cornell, 1920x1080, depth 8) at a few frames: deterministic; continuing a render
+    equals one longer render; paths = W*H*frames; and a band of rows equals the oracle's."""
+    sc = make_scene(pbr, **{"render.max_depth": 8})
+    w, h = 1920, 1080
+    cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    device.render(0, pbr.frame_seeds(0, 6), px, cam)
+    a = device.read_output()
+    assert device.counters()["paths"] == w * h * 6
+    device.reset_accum()
+    device.render(0, pbr.frame_seeds(0, 6), px, cam)
+    assert same_values(device.read_output(), a)                     # run-to-run identical
+    device.reset_accum()
+    device.render(0, pbr.frame_seeds(0, 2), px, cam)
+    device.render(2, pbr.frame_seeds(2, 4), px, cam)
+    assert same_values(device.read_output(), a)                     # 2 + 4 frames == 6 frames
+    rows = (536, 552)
+    ref = oracle.Renderer(sc.desc, cfg, threads=8)
+    for k, seed in enumerate(pbr.frame_seeds(0, 6)):
+        out = ref.render_frame(float(seed), float(np.float32(k) / np.float32(k + 1)), px, cam, rows=rows)
+        ref.image[rows[0]:rows[1]] = out[rows[0]:rows[1]]
+    assert same_values(a[rows[0]:rows[1]], ref.image[rows[0]:rows[1]])
+    assert np.isfinite(a[..., :3]).all() and a[..., :3].min() >= 0.0
+
+
+def test_full_hd_sharded_equals_unsharded(pbr, device):
+    """Config 4's invariant at full size: 8-way tile shards, gathered, are the 1-GPU frame."""
+    import torch
+    sc = make_scene(pbr, "sponza", 2, 30000)
+    w, h, world = 1920, 1080, 8
+    cam, px, seeds = sc.camera(), pbr.pixel_dimension(w, h), pbr.frame_seeds(0, 2)
+    device.upload_scene(sc.desc)
+    device.configure(sc.config(w, h))
+    device.render(0, seeds, px, cam)
+    want = device.read_output()
+    gathered = torch.zeros(world * (w * h * 16 // world) // 4, dtype=torch.float32, device="cuda")
+    d = pbr.Device(0)
+    d.upload_scene(sc.desc)
+    for rank in range(world):
+        cfg = sc.config(w, h)
+        cfg.tile_world, cfg.tile_rank = world, rank
+        d.configure(cfg)
+        d.render(0, seeds, px, cam)
+        assert d.tile_bytes() == w * h * 16 // world
+        d.export_tiles(gathered.data_ptr() + rank * d.tile_bytes())
+    torch.cuda.synchronize()
+    d.import_tiles(gathered.data_ptr())
+    assert same_values(d.read_full(), want)
+    d.close()
