@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s (camera paths per second) of the path-tracing hot path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scene cornell|sponza|dragon|hairball]
+
+One "step" = one frame = one pass of the hot path over every pixel (SAMPLES = 1 path per pixel,
+the reference's default).  The K timed steps run as ONE fused device launch (pbr_render: the
+running mean stays in registers across frames), after W untimed warm-up frames; scene arrays and
+the accumulated image are resident in HBM before the timed region starts.  Default workload =
+BASELINE.json configs[1]: Cornell box, 1920x1080, 256 spp, depth 8, 1 GPU.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): 8x8-pixel tiles are dealt
+round-robin to the ranks (tile t -> rank t % N), the scene is replicated, no collective on the
+data path; the timed region ends with one RCCL all-gather of the compact tile buffers
+(W*H*16/N bytes per rank) and the scatter into the full frame.  The total work is fixed, so
+this is strong scaling.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4 copy ~6290
+
+WORKLOADS = {
+    # scene: (generator kind, seed, triangles, max_depth, BASELINE.json config it stands for)
+    "cornell": ("cornell", 1, 0, 8, "configs[1]: Cornell box 1920x1080, 256 spp, depth 8"),
+    "dragon": ("dragon", 1, 870000, 3, "configs[2]: Dragon-class (procedural, ~870k tris) 1920x1080, depth 3"),
+    "sponza": ("sponza", 2, 260000, 3, "configs[3]: Sponza-class (procedural, ~260k tris) 1920x1080, depth 3"),
+    "hairball": ("hairball", 3, 2000000, 3, "configs[4]: hairball (procedural, 2M tris), depth 3"),
+}
+
+
+def algorithmic_bytes(counters, pixel_frames, samples_per_frame=1):
+    """32 B per node visit + 36 B per triangle test + 52 B per shaded hit
+    + 32 B (accumulator read + write) per pixel and frame."""
+    return 32 * counters["nodes"] + 36 * counters["tris"] + 52 * counters["hits"] + 32 * pixel_frames
+
+
+def diff(a, b):
+    return {k: a[k] - b[k] for k in a}
+
+
+def cpu_baseline(pbr, scene, cfg, cam, px, budget_s):
+    """The oracle (oracle/pt_oracle.c, kind 'port') on all host cores over a bounded sample of
+    the same workload: whole frames of the same scene / resolution / depth until ~budget_s."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    ref = oracle.Renderer(scene.desc, cfg, threads=cores)
+    frames, t0, elapsed = 0, time.perf_counter(), 0.0
+    # a band of rows per call keeps each call short; whole frames are what is reported
+    while True:
+        seed = float(pbr.frame_seeds(frames, 1)[0])
+        weight = float(np.float32(frames) / np.float32(frames + 1))
+        ref.image = ref.render_frame(seed, weight, px, cam)
+        frames += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed >= budget_s or frames >= 64:
+            break
+    samples = cfg.width * cfg.height * frames
+    return {
+        "value": samples / elapsed / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": "%d frame(s) of the same %dx%d workload in %.1f s (oracle/pt_oracle.c, OpenMP, %d threads)" % (
+            frames, cfg.width, cfg.height, elapsed, cores),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--scene", default="cornell", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--triangles", type=int, default=-1, help="override the scene's triangle budget")
+    ap.add_argument("--depth", type=int, default=-1, help="override render.max_depth")
+    ap.add_argument("--brdf", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs a torch.distributed.run launch (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import pbr_loader
+    pbr = pbr_loader.load()
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    kind, seed, triangles, depth, label = WORKLOADS[args.scene]
+    triangles = args.triangles if args.triangles >= 0 else triangles
+    depth = args.depth if args.depth > 0 else depth
+    pbr.cfg_reset()
+    pbr.cfg_set(**{"render.max_depth": depth, "render.brdf": args.brdf})
+    t_build = time.perf_counter()
+    scene = pbr.HostScene.generate(kind, seed, triangles)
+    t_build = time.perf_counter() - t_build
+
+    w, h = args.width, args.height
+    cfg, cam, px = scene.config(w, h), scene.camera(), pbr.pixel_dimension(w, h)
+    cfg.tile_world, cfg.tile_rank = world, rank
+
+    dev = pbr.Device(local_rank)
+    dev.upload_scene(scene.desc)
+    dev.configure(cfg)
+
+    gather_out = gather_in = None
+    if world > 1:
+        n_floats = dev.tile_bytes() // 4
+        gather_in = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
+        gather_out = torch.zeros(n_floats * world, dtype=torch.float32, device="cuda")
+
+    def sync():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # warm-up: W frames (their own launch), accumulated image stays on the device
+    if args.warmup > 0:
+        dev.render(0, pbr.frame_seeds(0, args.warmup), px, cam)
+    before = dev.counters()
+
+    sync()
+    t0 = time.perf_counter()
+    dev.render(args.warmup, pbr.frame_seeds(args.warmup, args.steps), px, cam)   # synchronous: returns after the launch completed
+    kernel_ms = dev.last_kernel_ms()
+    if world > 1:
+        dev.export_tiles(gather_in.data_ptr())
+        dist.all_gather_into_tensor(gather_out, gather_in)
+        torch.cuda.synchronize()
+        dev.import_tiles(gather_out.data_ptr())
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    counters = diff(dev.counters(), before)
+    stats = [elapsed, kernel_ms / 1e3, float(counters["nodes"]), float(counters["tris"]), float(counters["hits"]), float(counters["paths"])]
+    if world > 1:
+        t = torch.tensor(stats, dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, kernel_s = float(tmax[0]), float(tmax[1])
+        counters = {"nodes": int(t[2]), "tris": int(t[3]), "hits": int(t[4]), "paths": int(t[5])}
+    else:
+        kernel_s = kernel_ms / 1e3
+
+    if rank == 0:
+        samples = w * h * args.steps * int(cfg.samples)
+        assert counters["paths"] == samples, (counters, samples)
+        algo = algorithmic_bytes(counters, w * h * args.steps)
+        # per launch of the dominant kernel (pathTracing): one launch per rank; the slowest rank's duration
+        achieved = algo / world / kernel_s / 1e9
+        out = {
+            "metric": "Msamples/s (paths/s) @1080p fixed seed; 1/2/4/8 MI355X scaling",
+            "value": samples / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": label if (w, h) == (1920, 1080) else label + " at %dx%d" % (w, h),
+                "scene": args.scene, "triangles": scene.info["faces"], "bvh_nodes": scene.info["flat_nodes"],
+                "width": w, "height": h, "spp": args.steps * int(cfg.samples), "max_depth": depth,
+                "max_added_depth": int(cfg.max_added_depth), "brdf": int(cfg.brdf),
+                "seeds": "seed_k = 0.0333 * (k + 1)", "tiles": "8x8 px, tile t -> rank t %% %d" % world,
+                "host_bvh_build_s": round(t_build, 3),
+            },
+            "kernel_ms": kernel_s * 1e3,
+            "per_sample": {
+                "node_visits": counters["nodes"] / samples, "triangle_tests": counters["tris"] / samples,
+                "shaded_hits": counters["hits"] / samples, "algorithmic_bytes": algo / samples,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
+                "algorithmic_bytes_per_launch": algo / world,
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            cfg1 = scene.config(w, h)
+            out["cpu_baseline"] = cpu_baseline(pbr, scene, cfg1, cam, px, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()
