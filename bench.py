@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--depth", type=int, default=-1, help="override render.max_depth")
     ap.add_argument("--brdf", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --one-device: rehearse the N > 1 path on a single GPU (tests); the gather then goes through host memory")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
+    ap.add_argument("--dump", default="", help="rank 0 writes the gathered / rendered frame to this .npy")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,8 +107,10 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        if args.one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     kind, seed, triangles, depth, label = WORKLOADS[args.scene]
     triangles = args.triangles if args.triangles >= 0 else triangles
@@ -146,7 +152,12 @@ def main():
     kernel_ms = dev.last_kernel_ms()
     if world > 1:
         dev.export_tiles(gather_in.data_ptr())
-        dist.all_gather_into_tensor(gather_out, gather_in)
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(gather_out, gather_in)
+        else:
+            host_out = torch.empty(gather_out.numel(), dtype=torch.float32)
+            dist.all_gather_into_tensor(host_out, gather_in.cpu())
+            gather_out.copy_(host_out)
         torch.cuda.synchronize()
         dev.import_tiles(gather_out.data_ptr())
     sync()
@@ -155,7 +166,7 @@ def main():
     counters = diff(dev.counters(), before)
     stats = [elapsed, kernel_ms / 1e3, float(counters["nodes"]), float(counters["tris"]), float(counters["hits"]), float(counters["paths"])]
     if world > 1:
-        t = torch.tensor(stats, dtype=torch.float64, device="cuda")
+        t = torch.tensor(stats, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -206,6 +217,8 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             cfg1 = scene.config(w, h)
             out["cpu_baseline"] = cpu_baseline(pbr, scene, cfg1, cam, px, args.cpu_seconds)
+        if args.dump:
+            np.save(args.dump, dev.read_full() if world > 1 else dev.read_output())
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -859,6 +859,10 @@ static void traverseLights( const ctx_t* c, ray4* ray ) {
 	}
 }
 
+/* Optional per-node visit histogram (analysis aid for cache studies; NULL = off). */
+static uint32_t* g_node_hist = 0;
+void orc_debug_set_node_hist( uint32_t* hist ) { g_node_hist = hist; }
+
 /* traverse, pt_bvh.cl:82-123 */
 static void traverse( ctx_t* c, ray4* ray ) {
 	const v3 invDir = V3( det_rcp( ray->dir.x ), det_rcp( ray->dir.y ), det_rcp( ray->dir.z ) );
@@ -869,6 +873,9 @@ static void traverse( ctx_t* c, ray4* ray ) {
 
 	do {
 		c->dbg_nodes += 1.0f;
+		if( g_node_hist ) {
+			__atomic_fetch_add( &g_node_hist[index], 1u, __ATOMIC_RELAXED );
+		}
 		const orc_bvh_node node = c->scene->bvh[index];
 		const int currentIndex = index;
 

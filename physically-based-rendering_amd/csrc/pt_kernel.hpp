@@ -39,7 +39,8 @@ using namespace ptm;
 #define M_1_PI_D 0x1.45f306dc9c883p-2
 
 struct DevParams {
-	const float4* nodes;    // 2 x float4 per node: {min.xyz, face0|-1}, {max.xyz, face1|-1 or miss link|-1} (w = int bits)
+	const float4* nodes;    // 2 x float4 per node: {min.xyz, w0}, {max.xyz, w1} — w0 / w1 are int bits, see decodeNode
+	const float4* hotNodes; // the numHot most-visited nodes (same 32-B records), copied to LDS by every block
 	const float4* tris;     // 3 x float4 per face: {a.xyz, e1.x}, {e1.y, e1.z, e2.x, e2.y}, {e2.z, material(int bits), 0, 0}
 	const float4* mats;     // 4 x float4 per material: {d, Ni, p|nu, rough|nv}, {Rs, Rd, 0, 0}, Kd, Ks
 	const float4* lights;   // 3 x float4 per light: pos, rgb, {type, radius, 0, 0}
@@ -57,6 +58,8 @@ struct DevParams {
 
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
+	int numHot;             // records of hotNodes a block stages in LDS (slot s < numHot is resident)
+	int firstSlot;          // slot of node 1, where every walk starts
 	int nFrames, firstCount;
 	int useExplicitWeight;
 	float explicitWeight;
@@ -207,12 +210,130 @@ PT_DEV float triangleT( const DevParams& P, int face, const Ray& ray, float rayT
 
 // traverse (pt_bvh.cl:82-123) / traverseShadows (:133-177).  ANYHIT: the shadow variant —
 // no `ray.t > tNear` cull, stops at the first face hit nearer than the light.
-template<bool ANYHIT, bool LIGHTS>
-PT_DEV void traverse( const DevParams& P, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
+// The slab test of intersectBox (pt_intersect.cl:11-25) plus the hit condition of the walk
+// (pt_bvh.cl:107-110; the shadow walk has no `ray.t > tNear` cull, :151-154).
+template<bool ANYHIT>
+PT_DEV bool boxHit( const float4 lo, const float4 hi, const Ray& ray, const f3 invDir, float rayT, float* tNearOut ) {
+	const float t1x = ( lo.x - ray.origin.x ) * invDir.x;
+	const float t1y = ( lo.y - ray.origin.y ) * invDir.y;
+	const float t1z = ( lo.z - ray.origin.z ) * invDir.z;
+	const float t2x = ( hi.x - ray.origin.x ) * invDir.x;
+	const float t2y = ( hi.y - ray.origin.y ) * invDir.y;
+	const float t2z = ( hi.z - ray.origin.z ) * invDir.z;
+	const float tNear = fmax1( fmax1( fmin1( t1x, t2x ), fmin1( t1y, t2y ) ), fmin1( t1z, t2z ) );
+	const float tFar = fmin1( fmin1( fmax1( t1x, t2x ), fmax1( t1y, t2y ) ), fmin1( fmax1( t1z, t2z ), inff() ) );
+	*tNearOut = tNear;
+
+	bool isNodeHit = ( tNear <= tFar ) && ( tFar > EPSILON5 );
+
+	if( !ANYHIT ) {
+		isNodeHit = isNodeHit && ( rayT > tNear );
+	}
+
+	return isNodeHit;
+}
+
+// intersectFaces / intersectFace, pt_bvh.cl:10-46, for one hit leaf
+PT_DEV void testLeaf( const DevParams& P, int face0, int face1, const Ray& ray, float tNear, Hit& hit, unsigned& faceTests ) {
+	float t = triangleT( P, face0, ray, hit.t, tNear );
+	faceTests++;
+
+	if( hit.t > t ) {
+		hit.t = t;
+		hit.face = face0;
+	}
+
+	if( face1 != -1 ) {
+		t = triangleT( P, face1, ray, hit.t, tNear );
+		faceTests++;
+
+		if( hit.t > t ) {
+			hit.t = t;
+			hit.face = face1;
+		}
+	}
+}
+
+// ---- node records and the LDS-resident tree top ------------------------------------------
+// A node is 32 B, {min.xyz, w0}{max.xyz, w1}, in the reference's DFS order (pt_bvh.cl:96-102: a
+// hit continues at index + 1, a miss at the miss link).  pbr_upload_scene re-encodes the two
+// link words so that a walk also knows, without any lookup, whether its NEXT node is one of the
+// hot nodes staged in LDS and in which slot:
+//   container  w0 = 1 << 31 | hitSlot << 12 | missSlot      w1 = miss link (-1: walk ends)
+//   leaf       w0 = face0 | hasSecondFace << 30              w1 = slot of node index + 1
+// with slot 0xFFF = "not staged".  Slots are ranked by expected visit frequency (surface area
+// of the parent box), so a block may stage any prefix [0, numHot) of the ranking.
+#define PT_NO_SLOT 0xFFF
+
+struct Cursor {
+	int index;   // node index in the global array
+	int slot;    // LDS slot of that node, or >= numHot
+};
+
+struct NodeLinks {
+	bool leaf;
+	int face0, face1;   // leaf only; face1 = -1 if single
+	Cursor onHit, onMiss;
+};
+
+template<bool USE_LDS>
+PT_DEV void fetchNode( const DevParams& P, const float4* lds, Cursor c, float4* lo, float4* hi ) {
+	if( USE_LDS && c.slot < P.numHot ) {
+		*lo = lds[c.slot * 2 + 0];
+		*hi = lds[c.slot * 2 + 1];
+	}
+	else {
+		*lo = P.nodes[c.index * 2 + 0];
+		*hi = P.nodes[c.index * 2 + 1];
+	}
+}
+
+PT_DEV NodeLinks decodeNode( Cursor c, const float4 lo, const float4 hi ) {
+	const int w0 = __float_as_int( lo.w );
+	const int w1 = __float_as_int( hi.w );
+	NodeLinks n;
+	n.leaf = ( w0 >= 0 );
+	n.onHit.index = c.index + 1;
+
+	if( n.leaf ) {
+		n.face0 = w0 & 0x3FFFFFFF;
+		n.face1 = ( w0 & 0x40000000 ) ? n.face0 + 1 : -1;
+		n.onHit.slot = w1 & 0xFFF;
+		n.onMiss = n.onHit;
+	}
+	else {
+		n.face0 = -1;
+		n.face1 = -1;
+		n.onHit.slot = ( w0 >> 12 ) & 0xFFF;
+		n.onMiss.index = w1;
+		n.onMiss.slot = w0 & 0xFFF;
+	}
+
+	return n;
+}
+
+PT_DEV Cursor firstNode( const DevParams& P ) {
+	// the walk starts at node 1 (pt_bvh.cl:84)
+	Cursor c;
+	c.index = 1;
+	c.slot = P.firstSlot;
+	return c;
+}
+
+// traverse (pt_bvh.cl:82-123) / traverseShadows (:133-177).  ANYHIT: the shadow variant — no
+// `ray.t > tNear` cull, stops at the first face hit nearer than the light.  Per lane this is
+// exactly the reference's sequence of node visits and face tests.
+//
+// Loop shape.  Two alternatives were measured on MI355X and rejected: walking
+// boxes until every lane of the wave stands on a leaf before testing faces (dragon-class: 0.65x),
+// and requesting both possible successors before the slab test (+7 % on the dragon-class scene
+// at 3 waves / SIMD, a loss as soon as registers are tight).
+template<bool ANYHIT, bool LIGHTS, bool USE_LDS>
+PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
 	const f3 invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
 	const float tLight = hit.t;
 	const int numNodes = P.numNodes;
-	int index = 1;
+	Cursor cur = firstNode( P );
 #ifdef PBR_GUARD_TRAV
 	int guardSteps = 0;
 #endif
@@ -233,61 +354,35 @@ PT_DEV void traverse( const DevParams& P, const Ray& ray, Hit& hit, unsigned& no
 			nodeVisits++;
 		}
 
-		const float4 lo = P.nodes[index * 2 + 0];
-		const float4 hi = P.nodes[index * 2 + 1];
-		const int face0 = __float_as_int( lo.w );
-		const int link = __float_as_int( hi.w );
-		const int current = index;
+		float4 lo, hi;
+		fetchNode<USE_LDS>( P, lds, cur, &lo, &hi );
+		const NodeLinks node = decodeNode( cur, lo, hi );
+		float tNear;
 
-		index = ( face0 < 0 ) ? link : current + 1;
-
-		// intersectBox, pt_intersect.cl:11-25
-		const float t1x = ( lo.x - ray.origin.x ) * invDir.x;
-		const float t1y = ( lo.y - ray.origin.y ) * invDir.y;
-		const float t1z = ( lo.z - ray.origin.z ) * invDir.z;
-		const float t2x = ( hi.x - ray.origin.x ) * invDir.x;
-		const float t2y = ( hi.y - ray.origin.y ) * invDir.y;
-		const float t2z = ( hi.z - ray.origin.z ) * invDir.z;
-		const float tNear = fmax1( fmax1( fmin1( t1x, t2x ), fmin1( t1y, t2y ) ), fmin1( t1z, t2z ) );
-		const float tFar = fmin1( fmin1( fmax1( t1x, t2x ), fmax1( t1y, t2y ) ), fmin1( fmax1( t1z, t2z ), inff() ) );
-
-		bool isNodeHit = ( tNear <= tFar ) && ( tFar > EPSILON5 );
-
-		if( !ANYHIT ) {
-			isNodeHit = isNodeHit && ( hit.t > tNear );
-		}
-
-		if( !isNodeHit ) {
+		if( !boxHit<ANYHIT>( lo, hi, ray, invDir, hit.t, &tNear ) ) {
+			cur = node.onMiss;
 			continue;
 		}
 
-		index = current + 1;
+		cur = node.onHit;
 
-		if( face0 >= 0 ) {
-			// intersectFaces / intersectFace, pt_bvh.cl:10-46
-			float t = triangleT( P, face0, ray, hit.t, tNear );
-			faceTests++;
-
-			if( hit.t > t ) {
-				hit.t = t;
-				hit.face = face0;
-			}
-
-			if( link != -1 ) {
-				t = triangleT( P, link, ray, hit.t, tNear );
-				faceTests++;
-
-				if( hit.t > t ) {
-					hit.t = t;
-					hit.face = link;
-				}
-			}
+		if( node.leaf ) {
+			testLeaf( P, node.face0, node.face1, ray, tNear, hit, faceTests );
 
 			if( ANYHIT && hit.t < tLight ) {
 				break;
 			}
 		}
-	} while( index > 0 && index < numNodes );
+	} while( cur.index > 0 && cur.index < numNodes );
+}
+
+// Every block stages the hot nodes once (32 B x numHot, coalesced) before its waves start.
+PT_DEV void stageHotNodes( const DevParams& P, float4* lds ) {
+	for( int i = (int) threadIdx.x; i < P.numHot * 2; i += (int) blockDim.x ) {
+		lds[i] = P.hotNodes[i];
+	}
+
+	__syncthreads();
 }
 
 // Geometric normal of a face: fast_normalize( cross( edge1, edge2 ) ), pt_intersect.cl:122
@@ -775,11 +870,12 @@ PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
 	}
 }
 
-// One bounce of the lane's current path: traverse, shade, and — when the path / frame ends —
-// fold it into the running mean and start the next path.  Returns true when the pixel has had
-// all P.nFrames frames.
+// Everything of one bounce that follows the closest-hit traversal (pathtracing.cl:261-333):
+// shade the hit, and — when the path / frame ends — fold it into the running mean and start the
+// next path.  Returns true when the pixel has had all P.nFrames frames; otherwise st.ray is the
+// next ray to trace.
 template<int BRDF, bool SHADOW, bool LIGHTS>
-PT_DEV bool stepPixel( const DevParams& P, PixelState& st, LaneCounters& cnt ) {
+PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt, const Hit hit ) {
 	// references keep the shading code below in the reference's vocabulary
 	Ray& ray = st.ray;
 	f3& color = st.color;
@@ -790,12 +886,6 @@ PT_DEV bool stepPixel( const DevParams& P, PixelState& st, LaneCounters& cnt ) {
 	int& depthAdded = st.depthAdded;
 	unsigned& dbgTris = st.dbgTris;
 	unsigned& totHits = cnt.hits;
-
-	// ---- traverse (pathtracing.cl:259) ----
-	Hit hit;
-	hit.t = inff();
-	hit.face = 0;
-	traverse<false, LIGHTS>( P, ray, hit, st.dbgNodes, dbgTris );
 
 	st.focus = ( st.sample + depth == 0 ) ? hit.t : st.focus;
 
@@ -856,7 +946,7 @@ PT_DEV bool stepPixel( const DevParams& P, PixelState& st, LaneCounters& cnt ) {
 						lh.t = tLight;
 						lh.face = 0;
 						unsigned unusedNodes = 0;
-						traverse<true, LIGHTS>( P, lightRay, lh, unusedNodes, dbgTris );
+						traverse<true, LIGHTS, true>( P, lds, lightRay, lh, unusedNodes, dbgTris );
 						lightDir = lightRay.dir;
 
 						if( lh.t >= tLight ) {
@@ -968,6 +1058,16 @@ PT_DEV bool stepPixel( const DevParams& P, PixelState& st, LaneCounters& cnt ) {
 	return false;
 }
 
+// One bounce of the lane's current path: traverse (pathtracing.cl:259), then shadeStep.
+template<int BRDF, bool SHADOW, bool LIGHTS>
+PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt ) {
+	Hit hit;
+	hit.t = inff();
+	hit.face = 0;
+	traverse<false, LIGHTS, true>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
+	return shadeStep<BRDF, SHADOW, LIGHTS>( P, lds, st, cnt, hit );
+}
+
 // Work distribution.  EVERY lane draws pixel slots from one device-wide counter with a plain
 // per-lane atomicAdd( counter, 1 ); hipcc folds the adds of the lanes that are active at that
 // point into one wave-level add (v_mbcnt + s_bcnt1 + a single global_atomic_add) and hands
@@ -986,8 +1086,22 @@ PT_DEV bool stepPixel( const DevParams& P, PixelState& st, LaneCounters& cnt ) {
 // (A lane-0 atomic + readfirstlane + wave-uniform `break` formulation of this loop was
 // miscompiled by ROCm 7.2 hipcc into an endless re-run of tile 0 on gfx950 — DESIGN.md,
 // "Toolchain notes" — hence the deliberately per-lane control flow.)
-template<int BRDF, bool SHADOW, bool LIGHTS, bool REFILL>
-__global__ __launch_bounds__( 256 ) void pathTracing( const DevParams P ) {
+// Block = 1024 threads (16 waves): one or two blocks own a CU's 160 KB of LDS for the staged tree
+// top.  MINW = waves per SIMD the register allocation must admit (__launch_bounds__):
+//   4  "lean"  <= 128 VGPRs, 1 block / CU — no spills; best when the scene fits the caches and
+//              the kernel is bound by its own arithmetic (Cornell-class);
+//   8  "wide"  <= 64 VGPRs, 2 blocks / CU — the traversal loop stays spill-free (it needs ~45
+//              registers), the shading code spills to scratch; twice the waves to hide the latency
+//              of dependent node fetches, +45-70 % on the 260k - 2M triangle scenes.
+#define PBR_BLOCK 1024
+
+extern __shared__ float4 gHotNodes[];
+
+template<int BRDF, bool SHADOW, bool LIGHTS, bool REFILL, int MINW>
+__global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParams P ) {
+	const float4* lds = gHotNodes;
+	stageHotNodes( P, gHotNodes );
+
 	const unsigned total = (unsigned) P.numLocalTiles * 64u;
 	LaneCounters cnt;
 	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
@@ -1013,7 +1127,7 @@ __global__ __launch_bounds__( 256 ) void pathTracing( const DevParams P ) {
 				break;
 			}
 #endif
-			if( stepPixel<BRDF, SHADOW, LIGHTS>( P, st, cnt ) ) {
+			if( stepPixel<BRDF, SHADOW, LIGHTS>( P, lds, st, cnt ) ) {
 				finishPixel( P, st );
 
 				if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
@@ -1047,7 +1161,7 @@ __global__ __launch_bounds__( 256 ) void pathTracing( const DevParams P ) {
 			const long long guardMax = (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1;
 #endif
 
-			while( !stepPixel<BRDF, SHADOW, LIGHTS>( P, st, cnt ) ) {
+			while( !stepPixel<BRDF, SHADOW, LIGHTS>( P, lds, st, cnt ) ) {
 #ifdef PBR_GUARD_PATH
 				if( ++guardSteps > guardMax ) {
 					atomicAdd( &P.guard[1], 1u );
@@ -1063,6 +1177,166 @@ __global__ __launch_bounds__( 256 ) void pathTracing( const DevParams P ) {
 			}
 
 			slot = atomicAdd( P.workCounter, 1u );
+		}
+	}
+
+	flushCounters( P, cnt );
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Batched schedule: the wave64 ballot scheme
+// ---------------------------------------------------------------------------------------
+// The schedules above keep the 64 lanes of a wave in lock step per bounce: every traversal lasts
+// as long as the wave's longest ray, and a leaf's triangle tests run while the lanes that stand
+// on container nodes idle (measured on the Sponza-class scene: ~28 % of the issued lane slots do
+// useful work).  Here every lane is a small state machine and ONE wave iteration advances each
+// lane by one node:
+//
+//   NODE   fetch the node, slab test, follow the hit / miss link (pt_bvh.cl:88-117)
+//   LEAF   the lane stands on a hit leaf; its (long) triangle tests are deferred ...
+//   SHADE  the lane's ray has left the tree; its (very long) shading step is deferred ...
+//   DONE   no pixel left
+//
+// ... until a ballot shows at least PBR_LEAF_BATCH (PBR_SHADE_BATCH) lanes waiting in that state,
+// or no lane of the wave can make progress otherwise.  Lanes that are shaded start their next ray —
+// or, when their pixel has had all its frames, take the next pixel slot — in the same iteration.
+// Per lane the sequence of node visits, face tests and random draws is exactly the reference's, so
+// the image stays bit-identical; only the interleaving across lanes changes.
+#ifndef PBR_LEAF_BATCH
+#define PBR_LEAF_BATCH 24
+#endif
+#ifndef PBR_SHADE_BATCH
+#define PBR_SHADE_BATCH 24
+#endif
+
+enum { MODE_NODE = 0, MODE_LEAF = 1, MODE_SHADE = 2, MODE_DONE = 3 };
+
+struct WalkState {
+	f3 invDir;
+	Cursor cur;
+	Hit hit;
+	int leafFace0, leafFace1;
+	float leafTNear;
+};
+
+template<bool LIGHTS>
+PT_DEV int startWalk( const DevParams& P, const Ray& ray, WalkState& w ) {
+	w.invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
+	w.cur = firstNode( P );
+	w.hit.t = inff();
+	w.hit.face = 0;
+	w.leafFace0 = -1;
+	w.leafFace1 = -1;
+	w.leafTNear = 0.0f;
+
+	if( LIGHTS ) {
+		traverseLights( P, ray, w.hit );
+	}
+
+	return MODE_NODE;
+}
+
+template<int BRDF, bool SHADOW, bool LIGHTS, int MINW>
+__global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const DevParams P ) {
+	const float4* lds = gHotNodes;
+	stageHotNodes( P, gHotNodes );
+
+	const unsigned total = (unsigned) P.numLocalTiles * 64u;
+	const int numNodes = P.numNodes;
+	LaneCounters cnt;
+	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
+	PixelState st;
+	WalkState w;
+	int mode = MODE_DONE;
+
+	{
+		const unsigned slot = atomicAdd( P.workCounter, 1u );
+
+		if( slot < total ) {
+			beginPixel( P, st, slot, cnt );
+			mode = startWalk<LIGHTS>( P, st.ray, w );
+		}
+	}
+
+#ifdef PBR_GUARD_PATH
+	long long guardSteps = 0;
+	const long long guardMax = ( (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1 ) * ( (long long) numNodes + 4 ) * ( (long long) total + 1 );
+#endif
+
+	while( mode != MODE_DONE ) {
+#ifdef PBR_GUARD_PATH
+		if( ++guardSteps > guardMax ) {
+			atomicAdd( &P.guard[1], 1u );
+			break;
+		}
+#endif
+		// ---- one node -------------------------------------------------------------------
+		if( mode == MODE_NODE ) {
+			st.dbgNodes++;
+
+			float4 lo, hi;
+			fetchNode<true>( P, lds, w.cur, &lo, &hi );
+			const NodeLinks node = decodeNode( w.cur, lo, hi );
+			float tNear;
+
+			if( boxHit<false>( lo, hi, st.ray, w.invDir, w.hit.t, &tNear ) ) {
+				w.cur = node.onHit;
+
+				if( node.leaf ) {
+					w.leafFace0 = node.face0;
+					w.leafFace1 = node.face1;
+					w.leafTNear = tNear;
+					mode = MODE_LEAF;
+				}
+			}
+			else {
+				w.cur = node.onMiss;
+			}
+
+			if( mode == MODE_NODE && !( w.cur.index > 0 && w.cur.index < numNodes ) ) {
+				mode = MODE_SHADE;
+			}
+		}
+
+		// ---- deferred triangle tests ------------------------------------------------------
+		{
+			const int nLeaf = __popcll( __ballot( mode == MODE_LEAF ) );
+			const int nNode = __popcll( __ballot( mode == MODE_NODE ) );
+
+			if( mode == MODE_LEAF && ( nLeaf >= PBR_LEAF_BATCH || nNode == 0 ) ) {
+				testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, w.hit, st.dbgTris );
+				mode = ( w.cur.index > 0 && w.cur.index < numNodes ) ? MODE_NODE : MODE_SHADE;
+			}
+		}
+
+		// ---- deferred shading ---------------------------------------------------------------
+		{
+			const int nShade = __popcll( __ballot( mode == MODE_SHADE ) );
+			const int nWalking = __popcll( __ballot( mode == MODE_NODE || mode == MODE_LEAF ) );
+
+			if( mode == MODE_SHADE && ( nShade >= PBR_SHADE_BATCH || nWalking == 0 ) ) {
+				if( shadeStep<BRDF, SHADOW, LIGHTS>( P, lds, st, cnt, w.hit ) ) {
+					finishPixel( P, st );
+
+					if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
+						flushCounters( P, cnt );
+					}
+
+					const unsigned slot = atomicAdd( P.workCounter, 1u );
+
+					if( slot < total ) {
+						beginPixel( P, st, slot, cnt );
+						mode = startWalk<LIGHTS>( P, st.ray, w );
+					}
+					else {
+						mode = MODE_DONE;
+					}
+				}
+				else {
+					mode = startWalk<LIGHTS>( P, st.ray, w );
+				}
+			}
 		}
 	}
 
@@ -1168,7 +1442,7 @@ __global__ void diagTrace( const DevParams P, const float* rays, int n, float* o
 	hit.t = inff();
 	hit.face = 0;
 	unsigned nodes = 0, tris = 0;
-	traverse<false, LIGHTS>( P, ray, hit, nodes, tris );
+	traverse<false, LIGHTS, false>( P, nullptr, ray, hit, nodes, tris );
 
 	f3 normal = mk3( 0.0f, 0.0f, 0.0f );
 
@@ -1184,6 +1458,37 @@ __global__ void diagTrace( const DevParams P, const float* rays, int n, float* o
 	outNormal[i * 3 + 2] = normal.z;
 	outCounts[i * 2 + 0] = nodes;
 	outCounts[i * 2 + 1] = tris;
+}
+
+// Traversal-only throughput probe: persistent lanes draw ray indices from P.workCounter, walk,
+// store {t, face} — what the walk alone sustains at full occupancy (no shading registers).
+template<bool USE_LDS>
+__global__ __launch_bounds__( PBR_BLOCK, 8 ) void diagTraceStream( const DevParams P, const float4* rays, unsigned n, float2* out ) {
+	const float4* lds = gHotNodes;
+
+	if( USE_LDS ) {
+		stageHotNodes( P, gHotNodes );
+	}
+
+	unsigned nodes = 0, tris = 0;
+	unsigned i = atomicAdd( P.workCounter, 1u );
+
+	while( i < n ) {
+		const float4 a = rays[(size_t) i * 2 + 0];
+		const float4 b = rays[(size_t) i * 2 + 1];
+		Ray ray;
+		ray.origin = mk3( a.x, a.y, a.z );
+		ray.dir = mk3( b.x, b.y, b.z );
+		Hit hit;
+		hit.t = inff();
+		hit.face = 0;
+		traverse<false, false, USE_LDS>( P, lds, ray, hit, nodes, tris );
+		out[i] = make_float2( hit.t, __int_as_float( hit.face ) );
+		i = atomicAdd( P.workCounter, 1u );
+	}
+
+	atomicAdd( &P.counters[0], (unsigned long long) nodes );
+	atomicAdd( &P.counters[1], (unsigned long long) tris );
 }
 
 // in: n x 16 {out_dir, in_dir, normal, pad}; out: n x 4 (as orc_brdf_eval); material 0 of P.mats

@@ -420,3 +420,26 @@ def test_full_hd_sharded_equals_unsharded(pbr, device):
     d.import_tiles(gathered.data_ptr())
     assert same_values(d.read_full(), want)
     d.close()
+
+
+def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
+    """bench.py's N > 1 path (tile sharding + all-gather + scatter) rehearsed with two processes on
+    ONE GPU (gloo): the gathered frame is the single-rank frame, bit for bit, and every path is counted."""
+    import json
+    import subprocess
+    common = ["--steps", "3", "--warmup", "1", "--width", "256", "--height", "144", "--cpu-seconds", "0"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dump", str(tmp_path / "one.npy")] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--one-device", "--dump", str(tmp_path / "two.npy")] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    j2 = json.loads(two.stdout.strip().splitlines()[-1])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2
+    assert j1["per_sample"] == j2["per_sample"]                     # same work, counted once
+    assert j2["roofline"]["frac"] > 0 and j2["value"] > 0
+    assert same_values(np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy"))
