@@ -15,8 +15,10 @@
 #include "pbr_hip.h"
 #include "pbr_hip_diag.h"
 #include "pt_kernel.hpp"
+#include "pt_wavefront.hpp"
 
 using ptk::DevParams;
+using ptk::WfParams;
 
 struct pbr_ctx {
 	int device = -1;
@@ -52,6 +54,13 @@ struct pbr_ctx {
 	unsigned long long* dCounters = nullptr;
 	unsigned int* dWork = nullptr;
 	unsigned int* dGuard = nullptr;
+
+	// wavefront schedule (pt_wavefront.hpp): per-pixel state, two ray queues, {count[2], head[2]}
+	float4* dWfState = nullptr;
+	unsigned int* dWfQueue[2] = { nullptr, nullptr };
+	unsigned int* dWfCtl = nullptr;
+	size_t wfPixels = 0;
+	unsigned int lastPasses = 0;
 };
 
 namespace {
@@ -88,7 +97,19 @@ void freeScene( pbr_ctx* ctx ) {
 	ctx->hasScene = false;
 }
 
+void freeWavefront( pbr_ctx* ctx ) {
+	(void) hipFree( ctx->dWfState );
+	(void) hipFree( ctx->dWfQueue[0] );
+	(void) hipFree( ctx->dWfQueue[1] );
+	(void) hipFree( ctx->dWfCtl );
+	ctx->dWfState = nullptr;
+	ctx->dWfQueue[0] = ctx->dWfQueue[1] = nullptr;
+	ctx->dWfCtl = nullptr;
+	ctx->wfPixels = 0;
+}
+
 void freeImages( pbr_ctx* ctx ) {
+	freeWavefront( ctx );
 	(void) hipFree( ctx->dImgIn );
 	(void) hipFree( ctx->dImgOut );
 	(void) hipFree( ctx->dImgDbg );
@@ -120,18 +141,22 @@ KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 	return ptk::pathTracing<1, false, false, REFILL, MINW>;
 }
 
+#ifndef PBR_BATCHED_MINW
+#define PBR_BATCHED_MINW 4
+#endif
+
 KernelFn pickKernelBatched( uint32_t brdf, bool shadow, bool lights ) {
 	if( brdf == 0 ) {
 		if( lights ) {
-			return shadow ? ptk::pathTracingBatched<0, true, true, 4> : ptk::pathTracingBatched<0, false, true, 4>;
+			return shadow ? ptk::pathTracingBatched<0, true, true, PBR_BATCHED_MINW> : ptk::pathTracingBatched<0, false, true, PBR_BATCHED_MINW>;
 		}
-		return ptk::pathTracingBatched<0, false, false, 4>;
+		return ptk::pathTracingBatched<0, false, false, PBR_BATCHED_MINW>;
 	}
 
 	if( lights ) {
-		return shadow ? ptk::pathTracingBatched<1, true, true, 4> : ptk::pathTracingBatched<1, false, true, 4>;
+		return shadow ? ptk::pathTracingBatched<1, true, true, PBR_BATCHED_MINW> : ptk::pathTracingBatched<1, false, true, PBR_BATCHED_MINW>;
 	}
-	return ptk::pathTracingBatched<1, false, false, 4>;
+	return ptk::pathTracingBatched<1, false, false, PBR_BATCHED_MINW>;
 }
 
 // Lane-level refill pays one (wave-aggregated) atomic per finished pixel; below this many
@@ -147,6 +172,105 @@ KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights, bool refill, bool 
 		return refill ? pickKernelMode<true, 8>( brdf, shadow, lights ) : pickKernelMode<false, 8>( brdf, shadow, lights );
 	}
 	return refill ? pickKernelMode<true, 4>( brdf, shadow, lights ) : pickKernelMode<false, 4>( brdf, shadow, lights );
+}
+
+typedef void ( *WfKernelFn )( const DevParams, const WfParams );
+
+WfKernelFn pickWfShade( uint32_t brdf, bool shadow, bool lights ) {
+	if( brdf == 0 ) {
+		if( lights ) {
+			return shadow ? ptk::wfShade<0, true, true> : ptk::wfShade<0, false, true>;
+		}
+		return ptk::wfShade<0, false, false>;
+	}
+
+	if( lights ) {
+		return shadow ? ptk::wfShade<1, true, true> : ptk::wfShade<1, false, true>;
+	}
+	return ptk::wfShade<1, false, false>;
+}
+
+// The wavefront schedule of one fused launch: wfInit, then { wfTrace, wfShade } until no pixel has
+// a ray left, then wfReduce.  The host only reads the queue length back every few passes.
+int launchWavefront( pbr_ctx* ctx, DevParams P, bool shadow, bool lights ) {
+	const size_t pixels = (size_t) ctx->numLocalTiles * 64;
+
+	if( ctx->wfPixels != pixels ) {
+		freeWavefront( ctx );
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWfState, sizeof( float4 ) * ptk::WF_CHUNKS * pixels ) );
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWfQueue[0], sizeof( unsigned ) * pixels ) );
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWfQueue[1], sizeof( unsigned ) * pixels ) );
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWfCtl, sizeof( unsigned ) * 4 ) );
+		ctx->wfPixels = pixels;
+	}
+
+	WfParams W;
+	W.state = ctx->dWfState;
+	W.stride = (unsigned) pixels;
+	W.queue[0] = ctx->dWfQueue[0];
+	W.queue[1] = ctx->dWfQueue[1];
+	W.count = ctx->dWfCtl;
+	W.head = ctx->dWfCtl + 2;
+	W.cur = 0;
+
+	const WfKernelFn trace = lights ? ptk::wfTrace<true> : ptk::wfTrace<false>;
+	const WfKernelFn shade = pickWfShade( ctx->cfg.brdf, shadow, lights );
+
+	// traversal: 2 blocks of 1024 threads per CU (8 waves / SIMD), each stages its share of the hot nodes
+	size_t slots = std::min<size_t>( ctx->numHotAvail, ( 80 * 1024 - 1024 ) / 32 );
+
+	if( const char* cap = std::getenv( "PBR_LDS_SLOTS" ) ) {
+		slots = std::min<size_t>( slots, (size_t) std::max( 0, std::atoi( cap ) ) );
+	}
+
+	P.numHot = (int) slots;
+	const size_t ldsBytes = slots * 32;
+	HIP_TRY( ctx, hipFuncSetAttribute( (const void*) trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes ) );
+	const dim3 traceGrid( (unsigned) ctx->numCUs * 2 ), traceBlock( PBR_BLOCK );
+	const dim3 wideGrid( (unsigned) ctx->numCUs * 8 ), wideBlock( 256 );
+
+	DevParams Pshade = P;
+	Pshade.numHot = 0;   // shading kernels do not stage LDS (their shadow walks read nodes from memory)
+
+	const unsigned maxPasses = (unsigned) ( P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 2 );
+	unsigned passes = 0;
+	unsigned batch = 8;
+	unsigned remaining = (unsigned) pixels;
+
+	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
+	hipLaunchKernelGGL( ptk::wfInit, wideGrid, wideBlock, 0, ctx->stream, Pshade, W );
+	HIP_TRY( ctx, hipGetLastError() );
+
+	while( remaining != 0 && passes < maxPasses ) {
+		const unsigned todo = std::min( batch, maxPasses - passes );
+
+		for( unsigned b = 0; b < todo; b++ ) {
+			hipLaunchKernelGGL( trace, traceGrid, traceBlock, ldsBytes, ctx->stream, P, W );
+			hipLaunchKernelGGL( shade, wideGrid, wideBlock, 0, ctx->stream, Pshade, W );
+			W.cur ^= 1;
+		}
+
+		HIP_TRY( ctx, hipGetLastError() );
+		passes += todo;
+		HIP_TRY( ctx, hipMemcpyAsync( &remaining, ctx->dWfCtl + W.cur, sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream ) );
+		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+		batch = 16;
+	}
+
+	if( remaining != 0 ) {
+		return fail( ctx, PBR_EDEVICE, "wavefront schedule did not drain after %u passes (%u rays left)", passes, remaining );
+	}
+
+	hipLaunchKernelGGL( ptk::wfReduce, wideGrid, wideBlock, 0, ctx->stream, Pshade, W );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+
+	float ms = 0.0f;
+	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
+	ctx->lastKernelMs = (double) ms;
+	ctx->lastPasses = passes;
+	return PBR_OK;
 }
 
 int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* seeds,
@@ -252,6 +376,10 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	if( force != nullptr && std::strcmp( force, "batched" ) == 0 ) {
 		kernel = pickKernelBatched( ctx->cfg.brdf, shadow, lights );
+	}
+
+	if( force != nullptr && std::strcmp( force, "wavefront" ) == 0 && !dof ) {
+		return launchWavefront( ctx, P, shadow, lights );
 	}
 
 	// persistent grid: as many blocks as stay resident, never more than there is work for.

@@ -212,14 +212,24 @@ PT_DEV float triangleT( const DevParams& P, int face, const Ray& ray, float rayT
 // no `ray.t > tNear` cull, stops at the first face hit nearer than the light.
 // The slab test of intersectBox (pt_intersect.cl:11-25) plus the hit condition of the walk
 // (pt_bvh.cl:107-110; the shadow walk has no `ray.t > tNear` cull, :151-154).
+typedef float f2v __attribute__( ( ext_vector_type( 2 ) ) );
+
 template<bool ANYHIT>
 PT_DEV bool boxHit( const float4 lo, const float4 hi, const Ray& ray, const f3 invDir, float rayT, float* tNearOut ) {
-	const float t1x = ( lo.x - ray.origin.x ) * invDir.x;
-	const float t1y = ( lo.y - ray.origin.y ) * invDir.y;
-	const float t1z = ( lo.z - ray.origin.z ) * invDir.z;
-	const float t2x = ( hi.x - ray.origin.x ) * invDir.x;
-	const float t2y = ( hi.y - ray.origin.y ) * invDir.y;
-	const float t2z = ( hi.z - ray.origin.z ) * invDir.z;
+	// ( bb - origin ) * invDir for both planes of an axis; the x/y pairs are written as 2-vectors so
+	// that hipcc emits v_pk_add_f32 / v_pk_mul_f32 (two IEEE operations per instruction, same
+	// rounding as the scalar forms)
+	const f2v oxy = { ray.origin.x, ray.origin.y };
+	const f2v ixy = { invDir.x, invDir.y };
+	const f2v lxy = { lo.x, lo.y };
+	const f2v hxy = { hi.x, hi.y };
+	const f2v t1xy = ( lxy - oxy ) * ixy;
+	const f2v t2xy = ( hxy - oxy ) * ixy;
+	const f2v oz = { ray.origin.z, ray.origin.z };
+	const f2v iz = { invDir.z, invDir.z };
+	const f2v bz = { lo.z, hi.z };
+	const f2v tz = ( bz - oz ) * iz;
+	const float t1x = t1xy.x, t1y = t1xy.y, t2x = t2xy.x, t2y = t2xy.y, t1z = tz.x, t2z = tz.y;
 	const float tNear = fmax1( fmax1( fmin1( t1x, t2x ), fmin1( t1y, t2y ) ), fmin1( t1z, t2z ) );
 	const float tFar = fmin1( fmin1( fmax1( t1x, t2x ), fmax1( t1y, t2y ) ), fmin1( fmax1( t1z, t2z ), inff() ) );
 	*tNearOut = tNear;
@@ -289,26 +299,17 @@ PT_DEV void fetchNode( const DevParams& P, const float4* lds, Cursor c, float4* 
 }
 
 PT_DEV NodeLinks decodeNode( Cursor c, const float4 lo, const float4 hi ) {
+	// straight-line selects: both encodings are decoded and the right fields kept
 	const int w0 = __float_as_int( lo.w );
 	const int w1 = __float_as_int( hi.w );
 	NodeLinks n;
 	n.leaf = ( w0 >= 0 );
+	n.face0 = w0 & 0x3FFFFFFF;
+	n.face1 = ( w0 & 0x40000000 ) ? n.face0 + 1 : -1;
 	n.onHit.index = c.index + 1;
-
-	if( n.leaf ) {
-		n.face0 = w0 & 0x3FFFFFFF;
-		n.face1 = ( w0 & 0x40000000 ) ? n.face0 + 1 : -1;
-		n.onHit.slot = w1 & 0xFFF;
-		n.onMiss = n.onHit;
-	}
-	else {
-		n.face0 = -1;
-		n.face1 = -1;
-		n.onHit.slot = ( w0 >> 12 ) & 0xFFF;
-		n.onMiss.index = w1;
-		n.onMiss.slot = w0 & 0xFFF;
-	}
-
+	n.onHit.slot = n.leaf ? ( w1 & 0xFFF ) : ( ( w0 >> 12 ) & 0xFFF );
+	n.onMiss.index = n.leaf ? n.onHit.index : w1;
+	n.onMiss.slot = n.leaf ? n.onHit.slot : ( w0 & 0xFFF );
 	return n;
 }
 
@@ -1093,7 +1094,9 @@ PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, La
 //   8  "wide"  <= 64 VGPRs, 2 blocks / CU — the traversal loop stays spill-free (it needs ~45
 //              registers), the shading code spills to scratch; twice the waves to hide the latency
 //              of dependent node fetches, +45-70 % on the 260k - 2M triangle scenes.
+#ifndef PBR_BLOCK
 #define PBR_BLOCK 1024
+#endif
 
 extern __shared__ float4 gHotNodes[];
 

@@ -23,7 +23,7 @@ for brdf in (1, 0):
     ref = oracle.Renderer(sc.desc, cfg, threads=4)
     want = ref.render(0, seeds, px, cam)
     dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(cfg)
-    for sched in ("refill", "tile"):
+    for sched in ("refill", "tile", "wavefront"):
         os.environ["PBR_SCHEDULE"] = sched
         dev.reset_accum()
         attempt("brdf%d %s fused" % (brdf, sched), lambda: dev.render(0, seeds, px, cam))
@@ -46,9 +46,9 @@ sc = pbr.HostScene.generate("cornell")
 W, H = 1920, 1080
 cfg = sc.config(W, H); cam = sc.camera(); px = pbr.pixel_dimension(W, H, 45.0)
 dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(cfg)
-for sched in ("refill", "tile"):
+for sched in ("refill", "tile", "wavefront"):
     os.environ["PBR_SCHEDULE"] = sched
-    for frames in (1, 16, 64):
+    for frames in (16,):
         dev.reset_accum()
         attempt("1080p %s %d" % (sched, frames), lambda: dev.render(0, pbr.frame_seeds(0, frames), px, cam), 120.0)
         print("1080p depth8 %-6s %3d frames: kernel %.2f ms -> %.1f Msamples/s" % (sched, frames, dev.last_kernel_ms(), W * H * frames / dev.last_kernel_ms() / 1e3), flush=True)

@@ -1,19 +1,20 @@
 #!/bin/bash
 # usage: scripts/pmc.sh <outdir> <kernel-substring> -- <command...>   (run from repo root on the GPU box)
-# Runs the command once per counter set (separate --pmc passes) and prints per-kernel sums.
+# One rocprofv3 --pmc pass per counter set, each under its own timeout; prints per-kernel sums.
 out=$1; kern=$2; shift 3
 export TMPDIR=/tmp
+mkdir -p $out
 sets=(
-"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD"
-"TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE GRBM_TA_BUSY"
+"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS"
 "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
 "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum TCP_GATE_EN1_sum"
 "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_BUSY_sum"
 "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_TAG_STALL_sum TCC_CYCLE_sum"
+"SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES"
 )
 i=0
 for s in "${sets[@]}"; do
-  rocprofv3 --pmc $s --kernel-trace --output-format csv -d $out/set$i -- "$@" > $out/set$i.log 2>&1
+  timeout 150 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $out/set$i -- "$@" > $out/set$i.log 2>&1 || echo "set $i failed/timeout: $s"
   i=$((i+1))
 done
 python3 - "$out" "$kern" <<'PY'
@@ -26,6 +27,8 @@ for f in sorted(glob.glob(out + "/set*/*/*_counter_collection.csv")):
             k = (r["Dispatch_Id"], r["Counter_Name"])
             agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
             agg[(r["Dispatch_Id"], "ns")] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    last = sorted({d for d, _ in agg}, key=int)[-1:]
     for (d, c), v in agg.items():
-        print("dispatch %s %-40s %.6g" % (d, c, v))
+        if d in last:
+            print("dispatch %s %-40s %.6g" % (d, c, v))
 PY

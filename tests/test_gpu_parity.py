@@ -151,7 +151,7 @@ def test_brdf_and_new_ray_bit_exact(pbr, oracle, device, brdf, materials):
 # whole images
 # ----------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("schedule", ["refill", "tile"])
+@pytest.mark.parametrize("schedule", ["refill", "tile", "batched", "wavefront"])
 @pytest.mark.parametrize("cfg", [
     {"render.max_depth": 4},
     {"render.max_depth": 4, "render.brdf": 0},
@@ -170,9 +170,25 @@ def test_cornell_image_bit_exact(pbr, oracle, device, monkeypatch, schedule, cfg
 
 
 @pytest.mark.parametrize("kind,triangles,w,h", [("sponza", 20000, 96, 56), ("dragon", 20000, 64, 64), ("hairball", 20000, 64, 64)])
-def test_larger_scenes_bit_exact(pbr, oracle, device, kind, triangles, w, h):
+@pytest.mark.parametrize("schedule,variant", [("refill", "wide"), ("refill", "lean"), ("tile", "wide"), ("batched", "lean"), ("wavefront", "wide")])
+def test_larger_scenes_bit_exact(pbr, oracle, device, monkeypatch, kind, triangles, w, h, schedule, variant):
+    """Every schedule (pt_kernel.hpp: tile / refill / batched, pt_wavefront.hpp) and both register
+    budgets, with the tree top staged in LDS, against the oracle."""
+    monkeypatch.setenv("PBR_SCHEDULE", schedule)
+    monkeypatch.setenv("PBR_VARIANT", variant)
     sc = make_scene(pbr, kind, 4, triangles)
     got, want, ref = both_render(pbr, oracle, device, sc, w, h, 4)
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert same_values(device.read_debug(), ref.debug)
+    assert device.counters() == ref.counter_dict()
+
+
+@pytest.mark.parametrize("slots", ["0", "7", "300"])
+def test_lds_staging_size_does_not_change_results(pbr, oracle, device, monkeypatch, slots):
+    """Any prefix of the hot-node ranking may be staged (PBR_LDS_SLOTS caps it; 0 = none)."""
+    monkeypatch.setenv("PBR_LDS_SLOTS", slots)
+    sc = make_scene(pbr, "sponza", 4, 12000)
+    got, want, ref = both_render(pbr, oracle, device, sc, 64, 40, 3)
     assert same_values(got, want), describe_mismatch(got, want)
     assert device.counters() == ref.counter_dict()
 
@@ -358,6 +374,13 @@ def test_call_sequence_and_validation_errors(pbr, device):
     d = pbr.SceneDesc.from_buffer_copy(sc.desc)
     d.bvh = links.ctypes.data
     with pytest.raises(pbr.PbrError, match="node 2"):
+        device.upload_scene(d)
+    leaves = np.nonzero(arr["bvh"][:, 7] > arr["bvh"][:, 3])[0]                # leaves with two faces
+    pair = arr["bvh"].copy()
+    pair[leaves[0], 7] += 1                                                      # second face must be first + 1
+    d = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    d.bvh = pair.ctypes.data
+    with pytest.raises(pbr.PbrError, match="first face \\+ 1"):
         device.upload_scene(d)
     d = pbr.SceneDesc.from_buffer_copy(sc.desc)
     d.num_nodes = 1
