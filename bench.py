@@ -46,6 +46,21 @@ def algorithmic_bytes(counters, pixel_frames, samples_per_frame=1):
     return 32 * counters["nodes"] + 36 * counters["tris"] + 52 * counters["hits"] + 32 * pixel_frames
 
 
+def recorded_traffic(scene, w, h, depth, brdf, samples):
+    """HBM-side bytes per launch from the committed PMC passes (profiles/r01/pmc_traffic.json:
+    rocprofv3 --pmc in separate runs, TCC_EA0_RDREQ_* x request size + WRITE_SIZE, i.e. the gfx950
+    corrected form of FETCH_SIZE + WRITE_SIZE).  Only for the exact workload that was profiled;
+    scaled by the number of samples; None otherwise (PMC counters cannot be read from inside this run)."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(scene)
+    except (OSError, ValueError):
+        return None
+    if not rec or (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) != (w, h, depth, brdf):
+        return None
+    return rec["bytes_per_sample"] * samples
+
+
 def diff(a, b):
     return {k: a[k] - b[k] for k in a}
 
@@ -209,7 +224,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": (recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), samples) or 0) / world or None,
+                "traffic_source": "profiles/r01/pmc_traffic.json (separate rocprofv3 --pmc passes of this workload, scaled to this run's samples)",
                 "kernel": "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
                 "algorithmic_bytes_per_launch": algo / world,
             },

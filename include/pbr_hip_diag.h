@@ -31,6 +31,16 @@ int pbr_diag_brdf( pbr_ctx* ctx, const float* in, int n, float* out );
  * seed, pad}; out: n x 8 {origin[3], dir[3], seed after, addDepth}. */
 int pbr_diag_new_ray( pbr_ctx* ctx, const float* in, int n, float* out );
 
+/* Traversal-only throughput probe: streams n rays {ox,oy,oz,-, dx,dy,dz,-} through a persistent
+ * closest-hit kernel `repeats` times with `lds_slots` hot nodes staged in LDS; best kernel time in
+ * *ms_out, hits {t, face bits} in out2. */
+int pbr_diag_trace_stream( pbr_ctx* ctx, int lds_slots, const float* rays8, uint32_t n, int repeats, float* out2, double* ms_out );
+
+/* Memory-counter calibration: reads `reads` elements of a zero-filled table of table_bytes in a
+ * known pattern (mode 0 coalesced 16 B / lane stream, 1 random 16-B elements, 2 random 32-B
+ * records) so that rocprofv3's FETCH_SIZE / TCC_EA0_RDREQ_* can be interpreted. */
+int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t reads, double* ms_out );
+
 /* Loop-bound trips recorded by a PBR_GUARD build ([0] tile loop, [1] path loop, [2] traversal);
  * all zero in a normal build. */
 int pbr_diag_guard_trips( pbr_ctx* ctx, uint32_t out[3] );

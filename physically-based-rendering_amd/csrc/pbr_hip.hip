@@ -1121,6 +1121,47 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 	return PBR_OK;
 }
 
+// Counter calibration: allocate a zero-filled table of table_bytes, read `reads` elements / records
+// in the given pattern (0 stream, 1 random 16 B, 2 random 32 B); reports the kernel time.  Run it
+// under rocprofv3 --pmc to see what the memory counters say about a KNOWN amount of traffic.
+int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t reads, double* ms_out ) {
+	if( ctx == nullptr || ctx->stream == nullptr || mode < 0 || mode > 2 || table_bytes < 4096 || reads == 0 || ms_out == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "diag_calibrate: bad argument" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	DevBuf table, sink;
+	HIP_TRY( ctx, table.alloc( (size_t) table_bytes ) );
+	HIP_TRY( ctx, sink.alloc( 64 ) );
+	HIP_TRY( ctx, hipMemset( table.p, 0, (size_t) table_bytes ) );
+	HIP_TRY( ctx, hipDeviceSynchronize() );
+
+	const unsigned long long count = table_bytes / 16;
+	const unsigned blocks = (unsigned) ctx->numCUs * 8;
+	const unsigned long long threads = (unsigned long long) blocks * 256;
+	const unsigned steps = (unsigned) ( ( reads + threads - 1 ) / threads );
+
+	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
+
+	if( mode == 0 ) {
+		hipLaunchKernelGGL( ptk::diagCalibrate<0>, dim3( blocks ), dim3( 256 ), 0, ctx->stream, (const float4*) table.p, count, steps, (float*) sink.p );
+	}
+	else if( mode == 1 ) {
+		hipLaunchKernelGGL( ptk::diagCalibrate<1>, dim3( blocks ), dim3( 256 ), 0, ctx->stream, (const float4*) table.p, count, steps, (float*) sink.p );
+	}
+	else {
+		hipLaunchKernelGGL( ptk::diagCalibrate<2>, dim3( blocks ), dim3( 256 ), 0, ctx->stream, (const float4*) table.p, count, steps, (float*) sink.p );
+	}
+
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	float ms = 0.0f;
+	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
+	*ms_out = (double) ms * 1.0;
+	return PBR_OK;
+}
+
 int pbr_diag_guard_trips( pbr_ctx* ctx, uint32_t out[3] ) {
 	if( ctx == nullptr || ctx->stream == nullptr || out == nullptr ) {
 		return fail( ctx, PBR_EINVAL, "diag_guard_trips: bad argument" );
