@@ -41,6 +41,15 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int lds_slots, const float* rays8, uint
  * records) so that rocprofv3's FETCH_SIZE / TCC_EA0_RDREQ_* can be interpreted. */
 int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t reads, double* ms_out );
 
+/* The path-tracing launches of the last render: their summed duration (HIP events around each one)
+ * and their number.  A multi-frame render is one launch unless its per-frame result buffer would
+ * exceed 16 GiB; pbr_last_kernel_ms covers the whole render, foldFrames launches included. */
+int pbr_diag_last_trace( pbr_ctx* ctx, double* trace_ms, uint32_t* launches );
+
+/* All 16 device counter slots: [0..3] = pbr_counters; [4..15] are written only by experiment
+ * builds (-DPBR_EXP_STATS: wave iterations / active lanes of the lock-step walk) and stay 0 otherwise. */
+int pbr_diag_raw_counters( pbr_ctx* ctx, uint64_t out[16] );
+
 /* Loop-bound trips recorded by a PBR_GUARD build ([0] tile loop, [1] path loop, [2] traversal);
  * all zero in a normal build. */
 int pbr_diag_guard_trips( pbr_ctx* ctx, uint32_t out[3] );

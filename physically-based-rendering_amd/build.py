@@ -47,7 +47,7 @@ def _run(cmd):
 
 
 def build_hip(force=False, guard=False):
-    sources = [os.path.join(CSRC, f) for f in ("pbr_hip.hip", "pt_kernel.hpp", "pt_math.hpp")]
+    sources = [os.path.join(CSRC, f) for f in ("pbr_hip.hip", "pt_kernel.hpp", "pt_math.hpp", "pt_wavefront.hpp")]
     sources += [os.path.join(INCLUDE, f) for f in ("pbr_hip.h", "pbr_hip_diag.h")]
     target = HIP_GUARD_LIB if guard else HIP_LIB
     if not force and not _stale(target, sources):

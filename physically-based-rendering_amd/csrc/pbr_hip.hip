@@ -23,7 +23,7 @@ using ptk::WfParams;
 struct pbr_ctx {
 	int device = -1;
 	hipStream_t stream = nullptr;
-	hipEvent_t evStart = nullptr, evStop = nullptr;
+	hipEvent_t evStart = nullptr, evStop = nullptr, evTraceStart = nullptr, evTraceStop = nullptr;
 	std::string error;
 	double lastKernelMs = 0.0;
 	int numCUs = 0;
@@ -49,6 +49,10 @@ struct pbr_ctx {
 	float4* dImgDbg = nullptr;
 	float4* dRows = nullptr;       // W x H row-major staging for read-back / write_input
 	float4* dFull = nullptr;       // all tiles of the frame, filled by pbr_import_tiles
+	float4* dFrameBuf = nullptr;   // frame-parallel launches: {finalColor, focus} per frame and local pixel slot
+	size_t frameBufFrames = 0;
+	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
+	uint32_t lastTraceLaunches = 0; // ... and how many there were (frame-parallel renders are chunked)
 	float* dSeeds = nullptr;
 	size_t seedCapacity = 0;
 	unsigned long long* dCounters = nullptr;
@@ -115,6 +119,9 @@ void freeImages( pbr_ctx* ctx ) {
 	(void) hipFree( ctx->dImgDbg );
 	(void) hipFree( ctx->dRows );
 	(void) hipFree( ctx->dFull );
+	(void) hipFree( ctx->dFrameBuf );
+	ctx->dFrameBuf = nullptr;
+	ctx->frameBufFrames = 0;
 	ctx->dImgIn = ctx->dImgOut = ctx->dImgDbg = ctx->dRows = ctx->dFull = nullptr;
 	ctx->configured = false;
 }
@@ -124,10 +131,25 @@ bool integral( float w, double lo, double hi ) {
 	return ( w == std::floor( w ) ) && ( (double) w >= lo ) && ( (double) w <= hi );
 }
 
+// queue heads of the pixel-slot queue, one 128-B line per band (pt_kernel.hpp, nextSlot)
+const size_t kWorkBytes = sizeof( unsigned int ) * PT_BANDS * PT_BAND_STRIDE;
+
+// frame-parallel launches: cap of the per-frame result buffer (16 B per local pixel and frame)
+const size_t kFrameBufBytes = (size_t) 16 << 30;
+
+// 4 public counters (pbr_counters) + 12 slots for experiment statistics (pbr_diag_raw_counters)
+const size_t kCounterSlots = 16;
+
 typedef void ( *KernelFn )( const DevParams );
 
+// PBR_LAB (experiments only, scripts/lab.sh): instantiate just the variants the four bench scenes run,
+// so that an A/B build of the library takes seconds.  Never defined for the product build.
 template<bool REFILL, int MINW>
 KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
+#ifdef PBR_LAB
+	(void) brdf; (void) shadow; (void) lights;
+	return ptk::pathTracing<1, false, false, true, MINW>;
+#else
 	if( brdf == 0 ) {
 		if( lights ) {
 			return shadow ? ptk::pathTracing<0, true, true, REFILL, MINW> : ptk::pathTracing<0, false, true, REFILL, MINW>;
@@ -139,6 +161,7 @@ KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 		return shadow ? ptk::pathTracing<1, true, true, REFILL, MINW> : ptk::pathTracing<1, false, true, REFILL, MINW>;
 	}
 	return ptk::pathTracing<1, false, false, REFILL, MINW>;
+#endif
 }
 
 #ifndef PBR_BATCHED_MINW
@@ -146,6 +169,9 @@ KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 #endif
 
 KernelFn pickKernelBatched( uint32_t brdf, bool shadow, bool lights ) {
+#ifdef PBR_LAB
+	return pickKernelMode<true, 8>( brdf, shadow, lights );
+#else
 	if( brdf == 0 ) {
 		if( lights ) {
 			return shadow ? ptk::pathTracingBatched<0, true, true, PBR_BATCHED_MINW> : ptk::pathTracingBatched<0, false, true, PBR_BATCHED_MINW>;
@@ -157,6 +183,30 @@ KernelFn pickKernelBatched( uint32_t brdf, bool shadow, bool lights ) {
 		return shadow ? ptk::pathTracingBatched<1, true, true, PBR_BATCHED_MINW> : ptk::pathTracingBatched<1, false, true, PBR_BATCHED_MINW>;
 	}
 	return ptk::pathTracingBatched<1, false, false, PBR_BATCHED_MINW>;
+#endif
+}
+
+#ifndef PBR_PHASED_MINW
+#define PBR_PHASED_MINW 8
+#endif
+
+KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights ) {
+#ifdef PBR_LAB
+	(void) brdf; (void) shadow; (void) lights;
+	return ptk::pathTracingPhased<1, false, false, PBR_PHASED_MINW>;
+#else
+	if( brdf == 0 ) {
+		if( lights ) {
+			return shadow ? ptk::pathTracingPhased<0, true, true, PBR_PHASED_MINW> : ptk::pathTracingPhased<0, false, true, PBR_PHASED_MINW>;
+		}
+		return ptk::pathTracingPhased<0, false, false, PBR_PHASED_MINW>;
+	}
+
+	if( lights ) {
+		return shadow ? ptk::pathTracingPhased<1, true, true, PBR_PHASED_MINW> : ptk::pathTracingPhased<1, false, true, PBR_PHASED_MINW>;
+	}
+	return ptk::pathTracingPhased<1, false, false, PBR_PHASED_MINW>;
+#endif
 }
 
 // Lane-level refill pays one (wave-aggregated) atomic per finished pixel; below this many
@@ -167,16 +217,27 @@ const uint32_t kRefillMinFrames = 4;
 // get the "wide" register budget (pt_kernel.hpp); small scenes the "lean" one.
 const uint32_t kWideMinNodes = 2048;
 
+#ifndef PBR_LEAN_MINW
+#define PBR_LEAN_MINW 4
+#endif
+#ifndef PBR_WIDE_MINW
+#define PBR_WIDE_MINW 8
+#endif
+
 KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights, bool refill, bool wide ) {
 	if( wide ) {
-		return refill ? pickKernelMode<true, 8>( brdf, shadow, lights ) : pickKernelMode<false, 8>( brdf, shadow, lights );
+		return refill ? pickKernelMode<true, PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelMode<false, PBR_WIDE_MINW>( brdf, shadow, lights );
 	}
-	return refill ? pickKernelMode<true, 4>( brdf, shadow, lights ) : pickKernelMode<false, 4>( brdf, shadow, lights );
+	return refill ? pickKernelMode<true, PBR_LEAN_MINW>( brdf, shadow, lights ) : pickKernelMode<false, PBR_LEAN_MINW>( brdf, shadow, lights );
 }
 
 typedef void ( *WfKernelFn )( const DevParams, const WfParams );
 
 WfKernelFn pickWfShade( uint32_t brdf, bool shadow, bool lights ) {
+#ifdef PBR_LAB
+	(void) brdf; (void) shadow; (void) lights;
+	return ptk::wfShade<1, false, false>;
+#else
 	if( brdf == 0 ) {
 		if( lights ) {
 			return shadow ? ptk::wfShade<0, true, true> : ptk::wfShade<0, false, true>;
@@ -188,6 +249,7 @@ WfKernelFn pickWfShade( uint32_t brdf, bool shadow, bool lights ) {
 		return shadow ? ptk::wfShade<1, true, true> : ptk::wfShade<1, false, true>;
 	}
 	return ptk::wfShade<1, false, false>;
+#endif
 }
 
 // The wavefront schedule of one fused launch: wfInit, then { wfTrace, wfShade } until no pixel has
@@ -213,7 +275,11 @@ int launchWavefront( pbr_ctx* ctx, DevParams P, bool shadow, bool lights ) {
 	W.head = ctx->dWfCtl + 2;
 	W.cur = 0;
 
+#ifdef PBR_LAB
+	const WfKernelFn trace = ptk::wfTrace<false>;
+#else
 	const WfKernelFn trace = lights ? ptk::wfTrace<true> : ptk::wfTrace<false>;
+#endif
 	const WfKernelFn shade = pickWfShade( ctx->cfg.brdf, shadow, lights );
 
 	// traversal: 2 blocks of 1024 threads per CU (8 waves / SIMD), each stages its share of the hot nodes
@@ -305,7 +371,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	}
 
 	HIP_TRY( ctx, hipMemcpyAsync( ctx->dSeeds, seeds, sizeof( float ) * nFrames, hipMemcpyHostToDevice, ctx->stream ) );
-	HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, sizeof( unsigned int ), ctx->stream ) );
+	HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, kWorkBytes, ctx->stream ) );
 
 	DevParams P;
 	std::memset( &P, 0, sizeof( P ) );
@@ -340,6 +406,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	P.height = (int) ctx->cfg.height;
 	P.tilesX = ctx->tilesX;
 	P.numLocalTiles = ctx->numLocalTiles;
+	// the local tiles as a grid for the banded queue: its true shape when unsharded, about that when sharded
+	P.queueWidth = std::max( 1, ( ctx->tilesX + (int) ctx->cfg.tile_world - 1 ) / (int) ctx->cfg.tile_world );
+	P.queueRows = ( ctx->numLocalTiles + P.queueWidth - 1 ) / P.queueWidth;
 	P.tileWorld = (int) ctx->cfg.tile_world;
 	P.tileRank = (int) ctx->cfg.tile_rank;
 	P.numNodes = (int) ctx->numNodes;
@@ -378,6 +447,13 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		kernel = pickKernelBatched( ctx->cfg.brdf, shadow, lights );
 	}
 
+	if( force != nullptr && std::strcmp( force, "phased" ) == 0 ) {
+		kernel = pickKernelPhased( ctx->cfg.brdf, shadow, lights );
+	}
+
+	// the refill / batched / phased kernels take (pixel, frame) units and leave the running mean to foldFrames
+	const bool frameParallel = refill || ( force != nullptr && ( std::strcmp( force, "batched" ) == 0 || std::strcmp( force, "phased" ) == 0 ) );
+
 	if( force != nullptr && std::strcmp( force, "wavefront" ) == 0 && !dof ) {
 		return launchWavefront( ctx, P, shadow, lights );
 	}
@@ -413,15 +489,87 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	blocks = ( blocks > needed ) ? needed : blocks;
 	blocks = ( blocks < 1 ) ? 1 : blocks;
 
+	if( !frameParallel ) {
+		HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
+		hipLaunchKernelGGL( kernel, dim3( (unsigned) blocks ), dim3( (unsigned) blockThreads ), ldsBytes, ctx->stream, P );
+		HIP_TRY( ctx, hipGetLastError() );
+		HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
+		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+
+		float ms = 0.0f;
+		HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
+		ctx->lastKernelMs = (double) ms;
+		ctx->lastTraceMs = (double) ms;
+		ctx->lastTraceLaunches = 1;
+		return PBR_OK;
+	}
+
+	// Frame-parallel: every (pixel, frame) is its own unit of work — the frames of a pixel are
+	// independent up to the running mean (pathtracing.cl:28,255,332) — so the launch ends with
+	// single frames in flight, not with whole pixels; {finalColor, focus} of each go to dFrameBuf
+	// and foldFrames applies setColors in frame order.  The buffer (16 B per pixel and frame) is
+	// capped, longer renders run as several launch pairs.
+	const size_t pixelSlots = (size_t) ctx->numLocalTiles * 64;
+	const size_t frameBytes = sizeof( float4 ) * pixelSlots;
+	size_t chunk = std::max<size_t>( 1, kFrameBufBytes / frameBytes );
+	chunk = std::min<size_t>( chunk, nFrames );
+	// the queue heads count pixel slots x frames of a band in 32 bits
+	chunk = std::min<size_t>( chunk, std::max<size_t>( 1, 0x7FFFFFFFull / ( pixelSlots + 64 * (size_t) P.queueWidth ) ) );
+
+	if( const char* cap = std::getenv( "PBR_CHUNK_FRAMES" ) ) {    // experiments / tests: force several launch pairs
+		chunk = std::min<size_t>( chunk, (size_t) std::max( 1, std::atoi( cap ) ) );
+	}
+
+	if( ctx->frameBufFrames < chunk ) {
+		(void) hipFree( ctx->dFrameBuf );
+		ctx->dFrameBuf = nullptr;
+		ctx->frameBufFrames = 0;
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dFrameBuf, frameBytes * chunk ) );
+		ctx->frameBufFrames = chunk;
+	}
+
+	P.frameBuf = ctx->dFrameBuf;
+	P.frameStride = (unsigned) pixelSlots;
+	const unsigned foldBlocks = (unsigned) ( ( pixelSlots + 255 ) / 256 );
+	double traceMs = 0.0;
+	uint32_t launches = 0;
+
 	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
-	hipLaunchKernelGGL( kernel, dim3( (unsigned) blocks ), dim3( (unsigned) blockThreads ), ldsBytes, ctx->stream, P );
-	HIP_TRY( ctx, hipGetLastError() );
+
+	for( uint32_t done = 0; done < nFrames; done += (uint32_t) chunk ) {
+		const uint32_t n = std::min<uint32_t>( (uint32_t) chunk, nFrames - done );
+		P.nFrames = (int) n;
+		P.firstCount = (int) ( firstCount + done );
+		P.seeds = ctx->dSeeds + done;
+
+		if( done > 0 ) {
+			HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, kWorkBytes, ctx->stream ) );
+		}
+
+		HIP_TRY( ctx, hipEventRecord( ctx->evTraceStart, ctx->stream ) );
+		hipLaunchKernelGGL( kernel, dim3( (unsigned) blocks ), dim3( (unsigned) blockThreads ), ldsBytes, ctx->stream, P );
+		HIP_TRY( ctx, hipGetLastError() );
+		HIP_TRY( ctx, hipEventRecord( ctx->evTraceStop, ctx->stream ) );
+		// the running mean so far: the input image for the first chunk, imageOut after that
+		hipLaunchKernelGGL( ptk::foldFrames, dim3( foldBlocks ), dim3( 256 ), 0, ctx->stream, P,
+			(const float4*) ( done == 0 ? ctx->dImgIn : ctx->dImgOut ), ctx->dImgOut );
+		HIP_TRY( ctx, hipGetLastError() );
+		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );   // one chunk for all but very long renders
+
+		float ms = 0.0f;
+		HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evTraceStart, ctx->evTraceStop ) );
+		traceMs += (double) ms;
+		launches++;
+	}
+
 	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
 	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
 
 	float ms = 0.0f;
 	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
 	ctx->lastKernelMs = (double) ms;
+	ctx->lastTraceMs = traceMs;
+	ctx->lastTraceLaunches = launches;
 
 	return PBR_OK;
 }
@@ -475,13 +623,15 @@ int pbr_create( int device, pbr_ctx** out ) {
 	ctx->numCUs = prop.multiProcessorCount;
 	HIP_TRY( ctx, hipStreamCreateWithFlags( &ctx->stream, hipStreamNonBlocking ) );
 	HIP_TRY( ctx, hipEventCreate( &ctx->evStart ) );
+	HIP_TRY( ctx, hipEventCreate( &ctx->evTraceStart ) );
+	HIP_TRY( ctx, hipEventCreate( &ctx->evTraceStop ) );
 	HIP_TRY( ctx, hipEventCreate( &ctx->evStop ) );
-	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dCounters, sizeof( unsigned long long ) * 4 ) );
-	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWork, sizeof( unsigned int ) ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dCounters, sizeof( unsigned long long ) * kCounterSlots ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWork, kWorkBytes ) );
 	// host-visible so that it can be read while a kernel is still running
 	HIP_TRY( ctx, hipHostMalloc( (void**) &ctx->dGuard, sizeof( unsigned int ) * 4, hipHostMallocMapped ) );
 	std::memset( ctx->dGuard, 0, sizeof( unsigned int ) * 4 );
-	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * 4 ) );
+	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * kCounterSlots ) );
 
 	return PBR_OK;
 }
@@ -501,6 +651,8 @@ void pbr_destroy( pbr_ctx* ctx ) {
 		(void) hipFree( ctx->dWork );
 		(void) hipHostFree( ctx->dGuard );
 		(void) hipEventDestroy( ctx->evStart );
+		(void) hipEventDestroy( ctx->evTraceStart );
+		(void) hipEventDestroy( ctx->evTraceStop );
 		(void) hipEventDestroy( ctx->evStop );
 		(void) hipStreamDestroy( ctx->stream );
 	}
@@ -765,7 +917,7 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	HIP_TRY( ctx, hipMemset( ctx->dImgIn, 0, fullBytes ) );
 	HIP_TRY( ctx, hipMemset( ctx->dImgOut, 0, fullBytes ) );
 	HIP_TRY( ctx, hipMemset( ctx->dImgDbg, 0, fullBytes ) );
-	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * 4 ) );
+	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * kCounterSlots ) );
 	HIP_TRY( ctx, hipDeviceSynchronize() );   // the memsets ran on the null stream; launches use ctx->stream
 	ctx->configured = true;
 
@@ -798,7 +950,7 @@ int pbr_reset_accum( pbr_ctx* ctx ) {
 	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
 	const size_t fullBytes = sizeof( float4 ) * 64 * (size_t) ctx->numTiles;
 	HIP_TRY( ctx, hipMemsetAsync( ctx->dImgIn, 0, fullBytes, ctx->stream ) );
-	HIP_TRY( ctx, hipMemsetAsync( ctx->dCounters, 0, sizeof( unsigned long long ) * 4, ctx->stream ) );
+	HIP_TRY( ctx, hipMemsetAsync( ctx->dCounters, 0, sizeof( unsigned long long ) * kCounterSlots, ctx->stream ) );
 	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
 	return PBR_OK;
 }
@@ -1090,7 +1242,7 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 	double best = 1e30;
 
 	for( int r = 0; r < repeats; r++ ) {
-		HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, sizeof( unsigned int ), ctx->stream ) );
+		HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, kWorkBytes, ctx->stream ) );
 		HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
 
 		// mode = number of hot nodes to stage in LDS (0 = none); 8 waves / SIMD => 2048 threads per CU
@@ -1159,6 +1311,26 @@ int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t r
 	float ms = 0.0f;
 	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
 	*ms_out = (double) ms * 1.0;
+	return PBR_OK;
+}
+
+int pbr_diag_last_trace( pbr_ctx* ctx, double* trace_ms, uint32_t* launches ) {
+	if( ctx == nullptr || trace_ms == nullptr || launches == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "diag_last_trace: null argument" );
+	}
+
+	*trace_ms = ctx->lastTraceMs;
+	*launches = ctx->lastTraceLaunches;
+	return PBR_OK;
+}
+
+int pbr_diag_raw_counters( pbr_ctx* ctx, uint64_t out[16] ) {
+	if( ctx == nullptr || out == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "diag_raw_counters: null argument" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	HIP_TRY( ctx, hipMemcpy( out, ctx->dCounters, sizeof( uint64_t ) * kCounterSlots, hipMemcpyDeviceToHost ) );
 	return PBR_OK;
 }
 

@@ -48,8 +48,10 @@ struct DevParams {
 	float4* imgOut;
 	float4* imgDbg;
 	const float* seeds;     // one per frame
+	float4* frameBuf;       // frame-parallel launches: {finalColor, focus} of frame k, pixel slot s at [k * frameStride + s]
+	unsigned frameStride;   // = numLocalTiles * 64
 	unsigned long long* counters;  // nodes, tris, hits, paths
-	unsigned int* workCounter;
+	unsigned int* workCounter;  // PT_BANDS heads, one per band of the pixel-slot queue, PT_BAND_STRIDE words apart (nextSlot)
 	unsigned int* guard;    // [0] tile-loop, [1] path-loop, [2] traversal trips (PBR_GUARD builds only)
 
 	float eye[3], cw[3], cu[3], cv[3];
@@ -57,6 +59,7 @@ struct DevParams {
 	float lenseFocal, lenseAperture;
 
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
+	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
 	int numHot;             // records of hotNodes a block stages in LDS (slot s < numHot is resident)
 	int firstSlot;          // slot of node 1, where every walk starts
@@ -325,10 +328,22 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 // `ray.t > tNear` cull, stops at the first face hit nearer than the light.  Per lane this is
 // exactly the reference's sequence of node visits and face tests.
 //
-// Loop shape.  Two alternatives were measured on MI355X and rejected: walking
-// boxes until every lane of the wave stands on a leaf before testing faces (dragon-class: 0.65x),
-// and requesting both possible successors before the slab test (+7 % on the dragon-class scene
-// at 3 waves / SIMD, a loss as soon as registers are tight).
+// Loop shape: two phases per round.  Measured on MI355X (scripts/ab.py with -DPBR_EXP_STATS), a
+// plain lock-step loop enters the face tests in 30-70 % of its iterations with only 2-7 of the 64
+// lanes standing on a hit leaf — and the face tests are 3-4x as long as the slab test.  So a lane that
+// hits a leaf PARKS (remembers the leaf, stops walking) while the others walk on; once a share
+// PBR_PARK_NUM / 2^PBR_PARK_SHIFT of the lanes that entered the node phase have left it (parked
+// or finished), all parked lanes test their faces together.  With few lanes left the share rounds
+// to one lane, i.e. the plain lock-step walk.  Rejected after measurement (bit-identical, slower):
+// waiting until EVERY lane stands on a leaf (dragon-class 0.65x), and requesting both successors
+// of a node before the slab test (a loss once registers are tight).
+#ifndef PBR_PARK_NUM
+#define PBR_PARK_NUM 1
+#endif
+#ifndef PBR_PARK_SHIFT
+#define PBR_PARK_SHIFT 1
+#endif
+
 template<bool ANYHIT, bool LIGHTS, bool USE_LDS>
 PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
 	const f3 invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
@@ -338,43 +353,120 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 #ifdef PBR_GUARD_TRAV
 	int guardSteps = 0;
 #endif
+#ifdef PBR_EXP_STATS
+	unsigned statIters = 0, statActive = 0, statLeafIters = 0, statLeafActive = 0;
+#endif
 
 	if( LIGHTS ) {
 		traverseLights( P, ray, hit );
 	}
 
-	do {
+	bool walking = true;   // the walk always visits node 1 (pt_bvh.cl:84-88)
+	unsigned visits = 0;
+	int leafFace0 = 0, leafFace1 = -1;
+	float leafTNear = 0.0f;
+
+	for( ;; ) {
+		bool parked = false;
+
+		// ---- node phase: the lanes that are walking
+		if( walking ) {
+			const int entered = __popcll( __ballot( 1 ) );
+			const int leave = ( entered * PBR_PARK_NUM ) >> PBR_PARK_SHIFT;
+			const int keep = entered - ( ( leave < 1 ) ? 1 : leave );
+
+			do {
 #ifdef PBR_GUARD_TRAV
-		// a forward-only walk visits each node at most once
-		if( ++guardSteps > numNodes ) {
-			atomicAdd( &P.guard[2], 1u );
-			break;
-		}
+				// a forward-only walk visits each node at most once
+				if( ++guardSteps > numNodes ) {
+					atomicAdd( &P.guard[2], 1u );
+					walking = false;
+					break;
+				}
 #endif
-		if( !ANYHIT ) {
-			nodeVisits++;
+				visits++;
+#ifdef PBR_EXP_STATS   // lab only: wave-level iteration statistics
+				{
+					const unsigned long long act = __ballot( 1 );
+					if( (int) __lane_id() == __ffsll( (long long) act ) - 1 ) {
+						statIters++;
+						statActive += (unsigned) __popcll( act );
+					}
+				}
+#endif
+
+				float4 lo, hi;
+				fetchNode<USE_LDS>( P, lds, cur, &lo, &hi );
+				const NodeLinks node = decodeNode( cur, lo, hi );
+				float tNear;
+#ifdef PBR_EXP_PAD_VALU   // sensitivity probes (scripts/lab.sh): extra work per node visit
+				{
+					float pad = lo.x;
+					for( int k = 0; k < PBR_EXP_PAD_VALU; k++ ) {
+						asm volatile( "v_add_f32 %0, %0, %0" : "+v"( pad ) );
+					}
+				}
+#endif
+#ifdef PBR_EXP_PAD_VMEM
+				for( int k = 0; k < PBR_EXP_PAD_VMEM; k++ ) {
+					const volatile float4* vg = (const volatile float4*) P.nodes;
+					const float x = vg[cur.index * 2 + ( k & 1 )].x;
+					asm volatile( "" :: "v"( x ) );
+				}
+#endif
+
+				if( boxHit<ANYHIT>( lo, hi, ray, invDir, hit.t, &tNear ) ) {
+					cur = node.onHit;
+
+					if( node.leaf ) {
+						parked = true;
+						leafFace0 = node.face0;
+						leafFace1 = node.face1;
+						leafTNear = tNear;
+					}
+				}
+				else {
+					cur = node.onMiss;
+				}
+
+				walking = ( cur.index > 0 && cur.index < numNodes );
+			} while( walking && !parked && __popcll( __ballot( walking && !parked ) ) > keep );
 		}
 
-		float4 lo, hi;
-		fetchNode<USE_LDS>( P, lds, cur, &lo, &hi );
-		const NodeLinks node = decodeNode( cur, lo, hi );
-		float tNear;
-
-		if( !boxHit<ANYHIT>( lo, hi, ray, invDir, hit.t, &tNear ) ) {
-			cur = node.onMiss;
-			continue;
-		}
-
-		cur = node.onHit;
-
-		if( node.leaf ) {
-			testLeaf( P, node.face0, node.face1, ray, tNear, hit, faceTests );
+		// ---- leaf phase: intersectFaces (pt_bvh.cl:10-46) for every parked lane
+		if( parked ) {
+#ifdef PBR_EXP_STATS
+			{
+				const unsigned long long act = __ballot( 1 );
+				if( (int) __lane_id() == __ffsll( (long long) act ) - 1 ) {
+					statLeafIters++;
+					statLeafActive += (unsigned) __popcll( act );
+				}
+			}
+#endif
+			testLeaf( P, leafFace0, leafFace1, ray, leafTNear, hit, faceTests );
 
 			if( ANYHIT && hit.t < tLight ) {
-				break;
+				walking = false;
 			}
 		}
-	} while( cur.index > 0 && cur.index < numNodes );
+
+		if( __ballot( walking ) == 0ull ) {
+			break;
+		}
+	}
+
+	if( !ANYHIT ) {
+		nodeVisits += visits;
+	}
+#ifdef PBR_EXP_STATS
+	if( !ANYHIT ) {
+		atomicAdd( &P.counters[4], (unsigned long long) statIters );
+		atomicAdd( &P.counters[5], (unsigned long long) statActive );
+		atomicAdd( &P.counters[6], (unsigned long long) statLeafIters );
+		atomicAdd( &P.counters[7], (unsigned long long) statLeafActive );
+	}
+#endif
 }
 
 // Every block stages the hot nodes once (32 B x numHot, coalesced) before its waves start.
@@ -821,17 +913,25 @@ PT_DEV void flushCounters( const DevParams& P, LaneCounters& c ) {
 	c.nodes = c.tris = c.hits = c.paths = 0;
 }
 
-// Take up pixel `slot`: load the accumulated value and start frame 0's first path.
-PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneCounters& cnt ) {
+// Take up pixel `slot`: load the accumulated value and start the first path of frame `frame`.
+// FP (frame-parallel): the unit of work is ONE frame of the pixel; its {finalColor, focus} go to
+// P.frameBuf and the running mean is folded afterwards, in frame order, by foldFrames.
+template<bool FP = false>
+PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneCounters& cnt, unsigned frame = 0u ) {
 	const int tileGlobal = (int) ( slot >> 6 ) * P.tileWorld + P.tileRank;
 	const int inTile = (int) ( slot & 63u );
 	st.slot = slot;
 	st.px = ( tileGlobal % P.tilesX ) * 8 + ( inTile & 7 );
 	st.py = ( tileGlobal / P.tilesX ) * 8 + ( inTile >> 3 );
 
-	const float4 prev = P.imgIn[slot];
-	st.acc = mk3( prev.x, prev.y, prev.z );
-	st.accW = prev.w;
+	st.acc = mk3( 0.0f, 0.0f, 0.0f );
+	st.accW = 0.0f;
+
+	if( !FP ) {
+		const float4 prev = P.imgIn[slot];
+		st.acc = mk3( prev.x, prev.y, prev.z );
+		st.accW = prev.w;
+	}
 
 	// getPreviousFocus, pathtracing.cl:58-65 (single-frame launches only; CLAMP_TO_EDGE)
 	st.tFocus = -1.0f;
@@ -841,16 +941,16 @@ PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneC
 		const int fx = ( P.focusX > P.width - 1 ) ? P.width - 1 : P.focusX;
 		const int fy = ( P.focusY > P.height - 1 ) ? P.height - 1 : P.focusY;
 		const int ft = ( fy >> 3 ) * P.tilesX + ( fx >> 3 );
-		st.tObject = prev.w;
+		st.tObject = FP ? P.imgIn[slot].w : st.accW;
 		st.tFocus = P.imgIn[(size_t) ft * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) )].w;
 	}
 
-	st.frame = 0;
+	st.frame = (int) frame;
 	st.sample = 0;
 	st.finalColor = mk3( 0.0f, 0.0f, 0.0f );
 	st.secondaryPaths = 1;
 	st.focus = 0.0f;
-	st.seed = P.seeds[0];
+	st.seed = P.seeds[frame];
 	st.dbgNodes = 0;
 	st.dbgTris = 0;
 
@@ -861,12 +961,16 @@ PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneC
 	cnt.paths++;
 }
 
-// Store the finished pixel (all frames of this launch accumulated).
+// Store the finished pixel (all frames of this launch accumulated); FP: the finished frame went
+// to P.frameBuf in shadeStep, only the debug image is left to write (st.frame was advanced).
+template<bool FP = false>
 PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
-	P.imgOut[st.slot] = make_float4( st.acc.x, st.acc.y, st.acc.z, st.accW );
+	if( !FP ) {
+		P.imgOut[st.slot] = make_float4( st.acc.x, st.acc.y, st.acc.z, st.accW );
+	}
 
 	// writeDebugImage, pathtracing.cl:73-78 (counters of the LAST frame of this launch)
-	if( P.imgDbg != nullptr ) {
+	if( P.imgDbg != nullptr && ( !FP || st.frame == P.nFrames ) ) {
 		P.imgDbg[st.slot] = make_float4( (float) st.dbgTris / 1082.0f, (float) st.dbgNodes / 1265.0f, 0.0f, 0.0f );
 	}
 }
@@ -875,7 +979,7 @@ PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
 // shade the hit, and — when the path / frame ends — fold it into the running mean and start the
 // next path.  Returns true when the pixel has had all P.nFrames frames; otherwise st.ray is the
 // next ray to trace.
-template<int BRDF, bool SHADOW, bool LIGHTS>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false>
 PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt, const Hit hit ) {
 	// references keep the shading code below in the reference's vocabulary
 	Ray& ray = st.ray;
@@ -1024,6 +1128,15 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 			finalColor = mk3( finalColor.x / ns, finalColor.y / ns, finalColor.z / ns );
 		}
 
+		if( FP ) {
+			// the unit ends here; foldFrames applies the running mean in frame order
+			P.frameBuf[(size_t) st.frame * P.frameStride + st.slot] = make_float4( finalColor.x, finalColor.y, finalColor.z, st.focus );
+			cnt.nodes += st.dbgNodes;
+			cnt.tris += st.dbgTris;
+			st.frame++;
+			return true;
+		}
+
 		const unsigned n = (unsigned) ( P.firstCount + st.frame );
 		const float w = P.useExplicitWeight ? P.explicitWeight : ( (float) n / (float) ( n + 1u ) );
 		st.acc = mk3(
@@ -1060,13 +1173,88 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 }
 
 // One bounce of the lane's current path: traverse (pathtracing.cl:259), then shadeStep.
-template<int BRDF, bool SHADOW, bool LIGHTS>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false>
 PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt ) {
 	Hit hit;
 	hit.t = inff();
 	hit.face = 0;
 	traverse<false, LIGHTS, true>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
-	return shadeStep<BRDF, SHADOW, LIGHTS>( P, lds, st, cnt, hit );
+	return shadeStep<BRDF, SHADOW, LIGHTS, FP>( P, lds, st, cnt, hit );
+}
+
+// ---- the pixel-slot queue ----------------------------------------------------------------
+// Work is handed out in pixel slots (64 per 8x8 tile).  The local tiles form a grid of
+// queueRows x queueWidth tiles, cut into PT_BANDS horizontal bands with one queue head each; a
+// wave prefers the band of the XCD it runs on (HW_REG_XCC_ID) and moves on to the other bands once
+// its own is empty.  So the 8 XCDs — each with a private 4 MiB L2 — work on 8 different parts of
+// the image instead of all on the same strip, and the rays in flight on one XCD (primary rays and
+// the first bounces that start where they hit) share that L2 with 1/8 of the scene's hot lines
+// instead of all of them.  Inside a band, tiles are dealt column by column, so the ~1024 tiles
+// that the waves of one XCD hold at a time form a compact block, not a 1920-pixel-wide strip.
+// Placement is for speed only: every slot is handed out exactly once whichever wave asks.
+#ifndef PT_BANDS
+#define PT_BANDS 8
+#endif
+#define PT_BAND_STRIDE 32   // words between queue heads: one 128-B line each
+#define PT_NO_WORK 0xFFFFFFFFu
+
+struct WorkCursor {
+	unsigned exhausted;   // bit b: this lane has seen band b empty
+	int home;             // preferred band
+};
+
+PT_DEV WorkCursor beginWork() {
+	unsigned xcc;
+	asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"( xcc ) );
+	WorkCursor wc;
+	wc.exhausted = 0u;
+	wc.home = (int) ( xcc & ( PT_BANDS - 1 ) );
+	return wc;
+}
+
+// Next unit of work: a pixel slot (local tile * 64 + position in tile) — and, for frame-parallel
+// launches (frames > 1 units per pixel), which frame of it — or PT_NO_WORK.  Per-lane control flow on
+// purpose ("Toolchain notes"); the band index is made wave-uniform before the atomic so
+// that hipcc still folds the adds of the active lanes into one wave-level add.
+PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, unsigned& frame ) {
+	const unsigned width = (unsigned) P.queueWidth;
+	const unsigned rowsTotal = (unsigned) P.queueRows;
+	const unsigned tiles = (unsigned) P.numLocalTiles;
+
+	while( wc.exhausted != ( 1u << PT_BANDS ) - 1u ) {
+		// first band, starting at home, that this lane has not seen empty
+		const unsigned rotated = ( ( wc.exhausted >> wc.home ) | ( wc.exhausted << ( PT_BANDS - wc.home ) ) ) & ( ( 1u << PT_BANDS ) - 1u );
+		const int mine = ( wc.home + __builtin_ctz( ~rotated ) ) & ( PT_BANDS - 1 );
+		const int band = __builtin_amdgcn_readfirstlane( mine );
+		const unsigned q = atomicAdd( P.workCounter + band * PT_BAND_STRIDE, 1u );
+		const unsigned row0 = ( (unsigned) band * rowsTotal ) / PT_BANDS;
+		const unsigned rows = ( (unsigned) ( band + 1 ) * rowsTotal ) / PT_BANDS - row0;
+
+		// frame-parallel launches: the band's tiles once per frame, frame after frame
+		const unsigned bandSlots = rows * width * 64u;
+
+		if( q >= bandSlots * frames ) {
+			wc.exhausted |= 1u << band;
+			continue;
+		}
+
+		frame = ( frames > 1u ) ? q / bandSlots : 0u;
+		const unsigned qf = q - frame * bandSlots;
+		const unsigned tq = qf >> 6;
+#ifdef PBR_QUEUE_ROWMAJOR   // lab only: tiles of a band in row-major order
+		const unsigned tile = row0 * width + tq;
+#else
+		const unsigned col = tq / rows;
+		const unsigned row = tq - col * rows;
+		const unsigned tile = ( row0 + row ) * width + col;
+#endif
+
+		if( tile < tiles ) {
+			return tile * 64u + ( qf & 63u );
+		}
+	}
+
+	return PT_NO_WORK;
 }
 
 // Work distribution.  EVERY lane draws pixel slots from one device-wide counter with a plain
@@ -1103,24 +1291,31 @@ extern __shared__ float4 gHotNodes[];
 template<int BRDF, bool SHADOW, bool LIGHTS, bool REFILL, int MINW>
 __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParams P ) {
 	const float4* lds = gHotNodes;
+#ifdef PBR_EXP_TAIL   // lab only: how much of the launch do waves spend finished, waiting for the last one?
+	const unsigned long long tailStart = wall_clock64();
+#endif
 	stageHotNodes( P, gHotNodes );
 
-	const unsigned total = (unsigned) P.numLocalTiles * 64u;
+	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
+	(void) total;
 	LaneCounters cnt;
 	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
 	PixelState st;
 
-	unsigned slot = atomicAdd( P.workCounter, 1u );
+	WorkCursor work = beginWork();
+	unsigned frame = 0;
+	unsigned slot = nextSlot( P, work, REFILL ? (unsigned) P.nFrames : 1u, frame );
 
 	if( REFILL ) {
-		bool have = ( slot < total );
+		// frame-parallel: the unit of work is one frame of one pixel
+		bool have = ( slot != PT_NO_WORK );
 #ifdef PBR_GUARD_PATH
 		long long guardSteps = 0;
 		const long long guardMax = ( (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1 ) * ( (long long) total + 1 );
 #endif
 
 		if( have ) {
-			beginPixel( P, st, slot, cnt );
+			beginPixel<true>( P, st, slot, cnt, frame );
 		}
 
 		while( have ) {
@@ -1130,18 +1325,18 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 				break;
 			}
 #endif
-			if( stepPixel<BRDF, SHADOW, LIGHTS>( P, lds, st, cnt ) ) {
-				finishPixel( P, st );
+			if( stepPixel<BRDF, SHADOW, LIGHTS, true>( P, lds, st, cnt ) ) {
+				finishPixel<true>( P, st );
 
 				if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
 					flushCounters( P, cnt );
 				}
 
-				slot = atomicAdd( P.workCounter, 1u );
-				have = ( slot < total );
+				slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
+				have = ( slot != PT_NO_WORK );
 
 				if( have ) {
-					beginPixel( P, st, slot, cnt );
+					beginPixel<true>( P, st, slot, cnt, frame );
 				}
 			}
 		}
@@ -1151,7 +1346,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 		int guardTiles = 0;
 #endif
 
-		while( slot < total ) {
+		while( slot != PT_NO_WORK ) {
 #ifdef PBR_GUARD_TILES
 			if( ++guardTiles > P.numLocalTiles + 1 ) {
 				atomicAdd( &P.guard[0], 1u );
@@ -1179,11 +1374,20 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 				flushCounters( P, cnt );
 			}
 
-			slot = atomicAdd( P.workCounter, 1u );
+			slot = nextSlot( P, work, 1u, frame );
 		}
 	}
 
 	flushCounters( P, cnt );
+#ifdef PBR_EXP_TAIL
+	if( ( threadIdx.x & 63u ) == 0u ) {
+		const unsigned long long tailEnd = wall_clock64();
+		atomicAdd( &P.counters[12], tailEnd - tailStart );
+		atomicMax( &P.counters[13], tailEnd );
+		atomicMax( &P.counters[14], ~tailStart );
+		atomicAdd( &P.counters[15], 1ull );
+	}
+#endif
 }
 
 
@@ -1245,7 +1449,8 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 	const float4* lds = gHotNodes;
 	stageHotNodes( P, gHotNodes );
 
-	const unsigned total = (unsigned) P.numLocalTiles * 64u;
+	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
+	(void) total;
 	const int numNodes = P.numNodes;
 	LaneCounters cnt;
 	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
@@ -1253,11 +1458,14 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 	WalkState w;
 	int mode = MODE_DONE;
 
-	{
-		const unsigned slot = atomicAdd( P.workCounter, 1u );
+	WorkCursor work = beginWork();
+	unsigned frame = 0;
 
-		if( slot < total ) {
-			beginPixel( P, st, slot, cnt );
+	{
+		const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
+
+		if( slot != PT_NO_WORK ) {
+			beginPixel<true>( P, st, slot, cnt, frame );
 			mode = startWalk<LIGHTS>( P, st.ray, w );
 		}
 	}
@@ -1319,17 +1527,17 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 			const int nWalking = __popcll( __ballot( mode == MODE_NODE || mode == MODE_LEAF ) );
 
 			if( mode == MODE_SHADE && ( nShade >= PBR_SHADE_BATCH || nWalking == 0 ) ) {
-				if( shadeStep<BRDF, SHADOW, LIGHTS>( P, lds, st, cnt, w.hit ) ) {
-					finishPixel( P, st );
+				if( shadeStep<BRDF, SHADOW, LIGHTS, true>( P, lds, st, cnt, w.hit ) ) {
+					finishPixel<true>( P, st );
 
 					if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
 						flushCounters( P, cnt );
 					}
 
-					const unsigned slot = atomicAdd( P.workCounter, 1u );
+					const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
 
-					if( slot < total ) {
-						beginPixel( P, st, slot, cnt );
+					if( slot != PT_NO_WORK ) {
+						beginPixel<true>( P, st, slot, cnt, frame );
 						mode = startWalk<LIGHTS>( P, st.ray, w );
 					}
 					else {
@@ -1346,6 +1554,189 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 	flushCounters( P, cnt );
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Phased schedule: the batched idea as nested phase loops
+// ---------------------------------------------------------------------------------------
+// Same lane state machine as pathTracingBatched, but the wave alternates between PHASES instead of
+// re-evaluating every state in one flat loop:
+//
+//   node phase   a tight loop over the lanes that are walking; a lane leaves it when it hits a
+//                leaf (-> LEAF) or its ray has left the tree (-> SHADE); the loop itself ends once
+//                PBR_PH_PARK lanes have left it (or nobody is left)
+//   leaf phase   the triangle tests of every lane parked on a leaf, in one go
+//   shade phase  once PBR_PH_SHADE lanes wait for shading (or nothing else can run): shade them,
+//                start their next rays / take their next pixels
+//
+// The node loop carries only the walk state; the path state is untouched between shade phases.
+#ifndef PBR_PH_PARK
+#define PBR_PH_PARK 16
+#endif
+#ifndef PBR_PH_SHADE
+#define PBR_PH_SHADE 24
+#endif
+
+template<int BRDF, bool SHADOW, bool LIGHTS, int MINW>
+__global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const DevParams P ) {
+	const float4* lds = gHotNodes;
+	stageHotNodes( P, gHotNodes );
+
+	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
+	(void) total;
+	const int numNodes = P.numNodes;
+	LaneCounters cnt;
+	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
+	PixelState st;
+	WalkState w;
+	int mode = MODE_DONE;
+#ifdef PBR_EXP_STATS
+	unsigned sNodeIt = 0, sNodeAct = 0, sLeafIt = 0, sLeafAct = 0, sShadeIt = 0, sShadeAct = 0, sOuter = 0, sNodePh = 0;
+#define PH_STAT( it, act ) { const unsigned long long m_ = __ballot( 1 ); if( (int) __lane_id() == __ffsll( (long long) m_ ) - 1 ) { it++; act += (unsigned) __popcll( m_ ); } }
+#else
+#define PH_STAT( it, act )
+#endif
+
+	WorkCursor work = beginWork();
+	unsigned frame = 0;
+
+	{
+		const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
+
+		if( slot != PT_NO_WORK ) {
+			beginPixel<true>( P, st, slot, cnt, frame );
+			mode = startWalk<LIGHTS>( P, st.ray, w );
+		}
+	}
+
+#ifdef PBR_GUARD_PATH
+	long long guardSteps = 0;
+	const long long guardMax = ( (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1 ) * ( (long long) numNodes + 4 ) * ( (long long) total + 1 );
+#endif
+
+	while( __ballot( mode != MODE_DONE ) != 0ull ) {
+#ifdef PBR_GUARD_PATH
+		if( ++guardSteps > guardMax ) {
+			atomicAdd( &P.guard[1], 1u );
+			break;
+		}
+#endif
+		// ---- node phase ---------------------------------------------------------------------
+		if( mode == MODE_NODE ) {
+			const int keep = __popcll( __ballot( 1 ) ) - PBR_PH_PARK;
+			unsigned visits = 0;
+
+#ifdef PBR_EXP_STATS
+			{ unsigned dummy = 0; PH_STAT( sNodePh, dummy ) }
+#endif
+			do {
+				visits++;
+				PH_STAT( sNodeIt, sNodeAct )
+
+				float4 lo, hi;
+				fetchNode<true>( P, lds, w.cur, &lo, &hi );
+				const NodeLinks node = decodeNode( w.cur, lo, hi );
+				float tNear;
+
+				if( boxHit<false>( lo, hi, st.ray, w.invDir, w.hit.t, &tNear ) ) {
+					w.cur = node.onHit;
+
+					if( node.leaf ) {
+						w.leafFace0 = node.face0;
+						w.leafFace1 = node.face1;
+						w.leafTNear = tNear;
+						mode = MODE_LEAF;
+					}
+				}
+				else {
+					w.cur = node.onMiss;
+				}
+
+				if( mode == MODE_NODE && !( w.cur.index > 0 && w.cur.index < numNodes ) ) {
+					mode = MODE_SHADE;
+				}
+			} while( mode == MODE_NODE && __popcll( __ballot( mode == MODE_NODE ) ) > keep );
+
+			st.dbgNodes += visits;
+		}
+
+		// ---- leaf phase ---------------------------------------------------------------------
+		if( mode == MODE_LEAF ) {
+			PH_STAT( sLeafIt, sLeafAct )
+			testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, w.hit, st.dbgTris );
+			mode = ( w.cur.index > 0 && w.cur.index < numNodes ) ? MODE_NODE : MODE_SHADE;
+		}
+
+		// ---- shade phase --------------------------------------------------------------------
+		{
+			const int nShade = __popcll( __ballot( mode == MODE_SHADE ) );
+			const int nNode = __popcll( __ballot( mode == MODE_NODE ) );
+
+			if( mode == MODE_SHADE && ( nShade >= PBR_PH_SHADE || nNode == 0 ) ) {
+				PH_STAT( sShadeIt, sShadeAct )
+				if( shadeStep<BRDF, SHADOW, LIGHTS, true>( P, lds, st, cnt, w.hit ) ) {
+					finishPixel<true>( P, st );
+
+					if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
+						flushCounters( P, cnt );
+					}
+
+					const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
+
+					if( slot != PT_NO_WORK ) {
+						beginPixel<true>( P, st, slot, cnt, frame );
+						mode = startWalk<LIGHTS>( P, st.ray, w );
+					}
+					else {
+						mode = MODE_DONE;
+					}
+				}
+				else {
+					mode = startWalk<LIGHTS>( P, st.ray, w );
+				}
+			}
+		}
+	}
+
+	flushCounters( P, cnt );
+#ifdef PBR_EXP_STATS
+	atomicAdd( &P.counters[8], (unsigned long long) sNodeIt );
+	atomicAdd( &P.counters[9], (unsigned long long) sNodeAct );
+	atomicAdd( &P.counters[10], (unsigned long long) sLeafIt );
+	atomicAdd( &P.counters[11], (unsigned long long) sLeafAct );
+	atomicAdd( &P.counters[12], (unsigned long long) sShadeIt );
+	atomicAdd( &P.counters[13], (unsigned long long) sShadeAct );
+	atomicAdd( &P.counters[14], (unsigned long long) sNodePh );
+#endif
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Frame-parallel launches: fold the frames into the running mean
+// ---------------------------------------------------------------------------------------
+// setColors (pt_rgb.cl:9-21) for frames firstCount .. firstCount + nFrames - 1 of every local pixel,
+// in frame order: exactly the arithmetic shadeStep applies when one lane walks a pixel through
+// all its frames.  imageOut.w = focus (first-hit distance) of the last frame.
+__global__ __launch_bounds__( 256 ) void foldFrames( const DevParams P, const float4* src, float4* dst ) {
+	const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( slot >= P.frameStride ) {
+		return;
+	}
+
+	float4 acc = src[slot];
+
+	for( int k = 0; k < P.nFrames; k++ ) {
+		const float4 fc = P.frameBuf[(size_t) k * P.frameStride + slot];
+		const unsigned n = (unsigned) ( P.firstCount + k );
+		const float w = P.useExplicitWeight ? P.explicitWeight : ( (float) n / (float) ( n + 1u ) );
+		acc.x = fc.x + ( acc.x - fc.x ) * w;
+		acc.y = fc.y + ( acc.y - fc.y ) * w;
+		acc.z = fc.z + ( acc.z - fc.z ) * w;
+		acc.w = fc.w;
+	}
+
+	dst[slot] = acc;
+}
 
 // ---------------------------------------------------------------------------------------
 // Framebuffer layout helpers

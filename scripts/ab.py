@@ -22,10 +22,30 @@ for job in jobs:
     times = []
     for rep in range(2):
         dev.reset_accum()
+        c0 = dev.counters()
         dev.render(0, pbr.frame_seeds(0, frames), px, cam)
+        c1 = dev.counters()
         times.append(dev.last_kernel_ms())
     img = dev.read_output()
     digest = hashlib.sha1(np.ascontiguousarray(img).tobytes()).hexdigest()[:12]
     best = min(times)
-    print("%-34s %-9s %3d frames  %9.2f ms  %8.1f Msamples/s  sha1 %s" % (tag, name, frames, best, W * H * frames / best / 1e3, digest), flush=True)
+    visits = c1["nodes"] - c0["nodes"]
+    print("%-34s %-9s %3d frames  %9.2f ms  %8.1f Msamples/s  %6.1f G visits/s (%5.1f nodes %4.1f tris /sample)  sha1 %s" % (
+        tag, name, frames, best, W * H * frames / best / 1e3, visits / best / 1e6, visits / (W * H * frames),
+        (c1["tris"] - c0["tris"]) / (W * H * frames), digest), flush=True)
+    import ctypes
+    raw = (ctypes.c_uint64 * 16)()
+    if hasattr(pbr.hip, "pbr_diag_raw_counters") and os.environ.get("PBR_STATS"):
+        pbr.hip.pbr_diag_raw_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        pbr.hip.pbr_diag_raw_counters(dev._ctx, raw)
+        it, act, lit, lact = raw[4], raw[5], raw[6], raw[7]
+        if it:
+            print("    stats: wave-iterations %.3e  active lanes/iteration %.1f  iterations with a leaf %.1f %%  lanes in the leaf branch %.2f" % (
+                it, act / it, 100.0 * lit / it, lact / max(lit, 1)), flush=True)
+        if raw[15]:
+            span = raw[13] - ((~raw[14]) & 0xFFFFFFFFFFFFFFFF)
+            print("    tail: %d waves, launch span %.3f ms (100 MHz clock), mean wave busy %.1f %% of the span" % (raw[15], span / 1e5, 100.0 * raw[12] / (raw[15] * span)), flush=True)
+        if raw[8]:
+            print("    phased: node iterations %.3e (%.1f lanes, %.1f per phase)  leaf phases %.3e (%.1f lanes)  shade phases %.3e (%.1f lanes)" % (
+                raw[8], raw[9] / raw[8], raw[8] / max(raw[14], 1), raw[10], raw[11] / max(raw[10], 1), raw[12], raw[13] / max(raw[12], 1)), flush=True)
     dev.close()

@@ -1,0 +1,102 @@
+// Micro-benchmark (measurement aid, not product): issue rate of plain vs packed f32 VALU, min3 and
+// LDS b128 reads at 1, 2, 4 and 8 waves per SIMD on gfx950.   hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP8( X ) X X X X X X X X
+
+template<int MODE>
+__global__ __launch_bounds__( 1024 ) void rate( float* out, int iters ) {
+	extern __shared__ float4 lds[];
+	float a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;
+	typedef float f2 __attribute__( ( ext_vector_type( 2 ) ) );
+	f2 p0 = { a0, 1 }, p1 = { 1, 2 }, p2 = { 2, 3 }, p3 = { 3, 4 }, p4 = { 4, 5 }, p5 = { 5, 6 }, p6 = { 6, 7 }, p7 = { 7, 8 };
+	unsigned addr = ( threadIdx.x * 2654435761u ) & 0x7FF0u;
+
+	if( MODE == 4 ) {
+		for( int i = threadIdx.x; i < 2048; i += blockDim.x ) {
+			lds[i] = make_float4( i, 0, 0, 0 );
+		}
+		__syncthreads();
+	}
+
+	for( int i = 0; i < iters; i++ ) {
+		if( MODE == 0 ) {
+			REP8( asm volatile( "v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n v_add_f32 %4, %4, %4\n v_add_f32 %5, %5, %5\n v_add_f32 %6, %6, %6\n v_add_f32 %7, %7, %7"
+				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ), "+v"( a7 ) ); )
+		}
+		else if( MODE == 1 ) {
+			REP8( asm volatile( "v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3\n v_pk_add_f32 %4, %4, %4\n v_pk_add_f32 %5, %5, %5\n v_pk_add_f32 %6, %6, %6\n v_pk_add_f32 %7, %7, %7"
+				: "+v"( p0 ), "+v"( p1 ), "+v"( p2 ), "+v"( p3 ), "+v"( p4 ), "+v"( p5 ), "+v"( p6 ), "+v"( p7 ) ); )
+		}
+		else if( MODE == 2 ) {
+			REP8( asm volatile( "v_min3_f32 %0, %0, %1, %2\n v_min3_f32 %1, %1, %2, %3\n v_min3_f32 %2, %2, %3, %4\n v_min3_f32 %3, %3, %4, %5\n v_min3_f32 %4, %4, %5, %6\n v_min3_f32 %5, %5, %6, %7\n v_min3_f32 %6, %6, %7, %0\n v_min3_f32 %7, %7, %0, %1"
+				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ), "+v"( a7 ) ); )
+		}
+		else if( MODE == 3 ) {
+			REP8( asm volatile( "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0"
+				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ), "+v"( a7 ) :: "vcc" ); )
+		}
+		else if( MODE == 4 ) {
+			// 8 random 16-B LDS reads per lane, address chain through the loaded value's zero fields
+			float4 v;
+			REP8( asm volatile( "ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"( v ) : "v"( addr ) : "memory" );
+			      addr = ( addr * 1664525u + 1013904223u + __float_as_uint( v.y ) ) & 0x7FF0u; )
+			a1 += v.x;
+		}
+		else if( MODE == 5 ) {
+			// 8 independent random LDS reads in flight
+			float4 v0, v1, v2, v3;
+			unsigned b = addr;
+			asm volatile( "ds_read_b128 %0, %4\n ds_read_b128 %1, %5\n ds_read_b128 %2, %6\n ds_read_b128 %3, %7\n s_waitcnt lgkmcnt(0)"
+				: "=v"( v0 ), "=v"( v1 ), "=v"( v2 ), "=v"( v3 ) : "v"( b ), "v"( b ^ 0x1230u ), "v"( b ^ 0x4560u ), "v"( b ^ 0x7890u & 0x7FF0u ) : "memory" );
+			asm volatile( "ds_read_b128 %0, %4\n ds_read_b128 %1, %5\n ds_read_b128 %2, %6\n ds_read_b128 %3, %7\n s_waitcnt lgkmcnt(0)"
+				: "=v"( v0 ), "=v"( v1 ), "=v"( v2 ), "=v"( v3 ) : "v"( b ^ 0x10u ), "v"( b ^ 0x2340u ), "v"( b ^ 0x5670u ), "v"( b ^ 0x0ab0u ) : "memory" );
+			addr = ( addr * 1664525u + 1013904223u ) & 0x7FF0u;
+			a1 += v0.x + v1.x + v2.x + v3.x;
+		}
+	}
+
+	out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+}
+
+template<int MODE>
+void run( const char* name, int cus, float* out ) {
+	const int iters = 4096;
+
+	for( int wavesPerSimd = 1; wavesPerSimd <= 8; wavesPerSimd *= 2 ) {
+		// blocks of 256 threads = 1 wave per SIMD; blocks per CU = wavesPerSimd
+		const int threads = ( wavesPerSimd >= 4 ) ? 1024 : 256 * wavesPerSimd;
+		const int blocks = cus * ( wavesPerSimd >= 4 ? wavesPerSimd / 4 : 1 );
+		hipEvent_t e0, e1;
+		hipEventCreate( &e0 );
+		hipEventCreate( &e1 );
+		rate<MODE><<<blocks, threads, 32768>>>( out, 16 );
+		hipEventRecord( e0 );
+		rate<MODE><<<blocks, threads, 32768>>>( out, iters );
+		hipEventRecord( e1 );
+		hipDeviceSynchronize();
+		float ms;
+		hipEventElapsedTime( &ms, e0, e1 );
+		const double instrPerWave = 64.0 * iters;
+		const double nsPerInstrPerSimd = ms * 1e6 / ( instrPerWave * wavesPerSimd );
+		printf( "%-28s waves/SIMD %d: %8.3f ms  -> %.3f ns per wave-instruction per SIMD (%.2f cycles @2.4 GHz)\n", name, wavesPerSimd, ms, nsPerInstrPerSimd, nsPerInstrPerSimd * 2.4 );
+	}
+}
+
+int main() {
+	hipDeviceProp_t prop;
+	hipGetDeviceProperties( &prop, 0 );
+	const int cus = prop.multiProcessorCount;
+	printf( "%s, %d CUs, clock %d kHz\n", prop.name, cus, prop.clockRate );
+	float* out;
+	hipMalloc( &out, sizeof( float ) * cus * 2 * 1024 );
+	run<0>( "v_add_f32", cus, out );
+	run<1>( "v_pk_add_f32", cus, out );
+	run<2>( "v_min3_f32", cus, out );
+	run<3>( "v_cndmask/v_mov", cus, out );
+	run<4>( "ds_read_b128 random dependent", cus, out );
+	run<5>( "ds_read_b128 random x8 indep", cus, out );
+	return 0;
+}

@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage: scripts/pmc_one.sh <outdir> "<counters>" <kernel-substring> -- <command...>   one rocprofv3 --pmc pass
+out=$1; ctrs=$2; kern=$3; shift 4
+export TMPDIR=/tmp
+mkdir -p $out
+timeout 200 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/run -- "$@" > $out/run.log 2>&1 || echo "failed/timeout: $ctrs"
+python3 - "$out" "$kern" <<'PY'
+import csv, glob, sys, collections
+out, kern = sys.argv[1], sys.argv[2]
+for f in sorted(glob.glob(out + "/run/*/*_counter_collection.csv")):
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if kern in r["Kernel_Name"]:
+            k = (r["Dispatch_Id"], r["Counter_Name"])
+            agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
+            agg[(r["Dispatch_Id"], "ns")] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    for d in sorted({d for d, _ in agg}, key=int)[-4:]:
+        print("dispatch", d, "  ".join("%s=%.5g" % (c, v) for (dd, c), v in agg.items() if dd == d))
+PY

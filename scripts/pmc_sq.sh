@@ -1,0 +1,29 @@
+#!/bin/bash
+# usage: scripts/pmc_sq.sh <outdir> <kernel-substring> -- <command...>   SQ-only counter passes (2 runs)
+out=$1; kern=$2; shift 3
+export TMPDIR=/tmp
+mkdir -p $out
+sets=(
+"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS"
+"SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES"
+)
+i=0
+for s in "${sets[@]}"; do
+  timeout 150 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $out/set$i -- "$@" > $out/set$i.log 2>&1 || echo "set $i failed/timeout: $s"
+  i=$((i+1))
+done
+python3 - "$out" "$kern" <<'PY'
+import csv, glob, sys, collections
+out, kern = sys.argv[1], sys.argv[2]
+for f in sorted(glob.glob(out + "/set*/*/*_counter_collection.csv")):
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if kern in r["Kernel_Name"]:
+            k = (r["Dispatch_Id"], r["Counter_Name"])
+            agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
+            agg[(r["Dispatch_Id"], "ns")] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    last = sorted({d for d, _ in agg}, key=int)[-1:]
+    for (d, c), v in agg.items():
+        if d in last:
+            print("dispatch %s %-40s %.6g" % (d, c, v))
+PY

@@ -151,7 +151,7 @@ def test_brdf_and_new_ray_bit_exact(pbr, oracle, device, brdf, materials):
 # whole images
 # ----------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("schedule", ["refill", "tile", "batched", "wavefront"])
+@pytest.mark.parametrize("schedule", ["refill", "tile", "batched", "phased", "wavefront"])
 @pytest.mark.parametrize("cfg", [
     {"render.max_depth": 4},
     {"render.max_depth": 4, "render.brdf": 0},
@@ -170,9 +170,9 @@ def test_cornell_image_bit_exact(pbr, oracle, device, monkeypatch, schedule, cfg
 
 
 @pytest.mark.parametrize("kind,triangles,w,h", [("sponza", 20000, 96, 56), ("dragon", 20000, 64, 64), ("hairball", 20000, 64, 64)])
-@pytest.mark.parametrize("schedule,variant", [("refill", "wide"), ("refill", "lean"), ("tile", "wide"), ("batched", "lean"), ("wavefront", "wide")])
+@pytest.mark.parametrize("schedule,variant", [("refill", "wide"), ("refill", "lean"), ("tile", "wide"), ("batched", "lean"), ("phased", "wide"), ("wavefront", "wide")])
 def test_larger_scenes_bit_exact(pbr, oracle, device, monkeypatch, kind, triangles, w, h, schedule, variant):
-    """Every schedule (pt_kernel.hpp: tile / refill / batched, pt_wavefront.hpp) and both register
+    """Every schedule (pt_kernel.hpp: tile / refill / batched / phased, pt_wavefront.hpp) and both register
     budgets, with the tree top staged in LDS, against the oracle."""
     monkeypatch.setenv("PBR_SCHEDULE", schedule)
     monkeypatch.setenv("PBR_VARIANT", variant)
@@ -180,6 +180,33 @@ def test_larger_scenes_bit_exact(pbr, oracle, device, monkeypatch, kind, triangl
     got, want, ref = both_render(pbr, oracle, device, sc, w, h, 4)
     assert same_values(got, want), describe_mismatch(got, want)
     assert same_values(device.read_debug(), ref.debug)
+    assert device.counters() == ref.counter_dict()
+
+
+@pytest.mark.parametrize("chunk", ["1", "2", "3"])
+@pytest.mark.parametrize("schedule", ["refill", "phased"])
+def test_frame_parallel_chunks_fold_in_frame_order(pbr, oracle, device, monkeypatch, schedule, chunk):
+    """Multi-frame renders hand out (pixel, frame) units and fold the frames afterwards (foldFrames);
+    a render split into several launch pairs (PBR_CHUNK_FRAMES) must give the same bits, debug
+    image (last frame's counters) and totals as the oracle's frame-by-frame sequence."""
+    monkeypatch.setenv("PBR_SCHEDULE", schedule)
+    monkeypatch.setenv("PBR_CHUNK_FRAMES", chunk)
+    sc = make_scene(pbr, **{"render.max_depth": 3, "render.samples": 2})
+    got, want, ref = both_render(pbr, oracle, device, sc, 56, 40, 7)
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert same_values(device.read_debug(), ref.debug)
+    assert device.counters() == ref.counter_dict()
+
+
+@pytest.mark.parametrize("w,h", [(8, 8), (24, 136), (200, 8), (72, 72)])
+@pytest.mark.parametrize("schedule", ["refill", "tile"])
+def test_banded_queue_covers_every_pixel_once(pbr, oracle, device, monkeypatch, schedule, w, h):
+    """The pixel-slot queue is cut into 8 bands (one head per XCD, tiles column by column inside a
+    band); image shapes with fewer tile rows than bands, one row, one column."""
+    monkeypatch.setenv("PBR_SCHEDULE", schedule)
+    sc = make_scene(pbr, **{"render.max_depth": 2})
+    got, want, ref = both_render(pbr, oracle, device, sc, w, h, 4)
+    assert same_values(got, want), describe_mismatch(got, want)
     assert device.counters() == ref.counter_dict()
 
 
