@@ -34,9 +34,8 @@ struct pbr_ctx {
 	float4* dTris = nullptr;
 	float4* dMats = nullptr;
 	float4* dLights = nullptr;
-	float4* dHotNodes = nullptr;   // the most-visited nodes, ranked; blocks stage a prefix of it in LDS
-	uint32_t numHotAvail = 0;
-	int firstSlot = 0xFFF;
+	uint32_t numHotAvail = 0;      // records at the head of the node stream that are ranked for LDS staging
+	int firstRef = 0;              // record of node 1
 	uint32_t numNodes = 0, numFaces = 0, numMaterials = 0, numLights = 0;
 	uint32_t sceneBrdf = 1;
 
@@ -96,8 +95,7 @@ void freeScene( pbr_ctx* ctx ) {
 	(void) hipFree( ctx->dTris );
 	(void) hipFree( ctx->dMats );
 	(void) hipFree( ctx->dLights );
-	(void) hipFree( ctx->dHotNodes );
-	ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dLights = ctx->dHotNodes = nullptr;
+	ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dLights = nullptr;
 	ctx->hasScene = false;
 }
 
@@ -376,8 +374,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	DevParams P;
 	std::memset( &P, 0, sizeof( P ) );
 	P.nodes = ctx->dNodes;
-	P.hotNodes = ctx->dHotNodes;
-	P.firstSlot = ctx->firstSlot;
+	P.firstRef = ctx->firstRef;
 	P.tris = ctx->dTris;
 	P.mats = ctx->dMats;
 	P.lights = ctx->dLights;
@@ -747,7 +744,8 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 		}
 	}
 
-	const uint32_t maxSlots = 0xFFF;   // slot ids are 12 bits, 0xFFF = none
+	// at most what one block can stage with a CU's 160 KB of LDS to itself
+	const uint32_t maxHot = ( 160 * 1024 - 256 ) / 32;
 	std::vector<uint32_t> ranked;
 	ranked.reserve( N );
 
@@ -755,43 +753,55 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 		ranked.push_back( i );
 	}
 
-	const uint32_t numHot = (uint32_t) std::min<size_t>( ranked.size(), maxSlots );
+	const uint32_t numHot = (uint32_t) std::min<size_t>( ranked.size(), maxHot );
 	std::partial_sort( ranked.begin(), ranked.begin() + numHot, ranked.end(), [&]( uint32_t a, uint32_t b ) {
 		return ( weight[a] != weight[b] ) ? ( weight[a] > weight[b] ) : ( a < b );
 	} );
 
-	std::vector<int> slotOf( (size_t) N + 1, 0xFFF );
+	// ---- the node stream (pt_kernel.hpp decodeNode): hot nodes by rank, then the rest in DFS order ----
+	std::vector<int> recordOf( (size_t) N, -1 );   // node index -> record; the root has none
 
 	for( uint32_t r = 0; r < numHot; r++ ) {
-		slotOf[ranked[r]] = (int) r;
+		recordOf[ranked[r]] = (int) r;
 	}
 
-	// ---- encode (pt_kernel.hpp decodeNode); one node of padding keeps index + 1 addressable ----
-	std::vector<float4> nodes( (size_t) ( N + 1 ) * 2, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );
-	std::vector<float4> hot( (size_t) ( numHot ? numHot : 1 ) * 2, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );
+	{
+		int next = (int) numHot;
 
-	for( uint32_t i = 0; i < N; i++ ) {
+		for( uint32_t i = 1; i < N; i++ ) {
+			if( recordOf[i] < 0 ) {
+				recordOf[i] = next++;
+			}
+		}
+	}
+
+	// the walk stops outside (0, N), pt_bvh.cl:122
+	auto refOf = [&]( long long node ) {
+		return ( node > 0 && node < (long long) N ) ? recordOf[(size_t) node] : -1;
+	};
+
+	std::vector<float4> nodes( (size_t) N * 2, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );
+
+	for( uint32_t i = 1; i < N; i++ ) {
 		const pbr_bvh_node& n = s->bvh[i];
-		const int nextSlot = slotOf[i + 1];
 		int w0, w1;
 
 		if( face0s[i] < 0 ) {
-			const int missSlot = ( links[i] >= 0 ) ? slotOf[links[i]] : 0xFFF;
-			w0 = (int) ( 0x80000000u | ( (uint32_t) nextSlot << 12 ) | (uint32_t) missSlot );
-			w1 = links[i];
+			if( i + 1 >= N ) {
+				return fail( ctx, PBR_EINVAL, "node %u: the last node is a container (its children would lie outside the array)", i );
+			}
+
+			w0 = refOf( (long long) i + 1 );
+			w1 = refOf( links[i] );
 		}
 		else {
-			w0 = face0s[i] | ( ( links[i] >= 0 ) ? 0x40000000 : 0 );
-			w1 = nextSlot;
+			w0 = (int) ( 0x80000000u | ( ( links[i] >= 0 ) ? 0x40000000u : 0u ) | (uint32_t) face0s[i] );
+			w1 = refOf( (long long) i + 1 );
 		}
 
-		nodes[(size_t) i * 2 + 0] = make_float4( n.bbMin.x, n.bbMin.y, n.bbMin.z, __builtin_bit_cast( float, w0 ) );
-		nodes[(size_t) i * 2 + 1] = make_float4( n.bbMax.x, n.bbMax.y, n.bbMax.z, __builtin_bit_cast( float, w1 ) );
-	}
-
-	for( uint32_t r = 0; r < numHot; r++ ) {
-		hot[(size_t) r * 2 + 0] = nodes[(size_t) ranked[r] * 2 + 0];
-		hot[(size_t) r * 2 + 1] = nodes[(size_t) ranked[r] * 2 + 1];
+		const size_t r = (size_t) recordOf[i];
+		nodes[r * 2 + 0] = make_float4( n.bbMin.x, n.bbMin.y, n.bbMax.x, n.bbMax.y );
+		nodes[r * 2 + 1] = make_float4( n.bbMin.z, n.bbMax.z, __builtin_bit_cast( float, w0 ), __builtin_bit_cast( float, w1 ) );
 	}
 
 	// ---- faces: gather the corners; store a, b - a, c - a (what pt_intersect.cl:98-99 computes) ----
@@ -856,15 +866,13 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dTris, sizeof( float4 ) * tris.size() ) );
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dMats, sizeof( float4 ) * mats.size() ) );
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dLights, sizeof( float4 ) * lights.size() ) );
-	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dHotNodes, sizeof( float4 ) * hot.size() ) );
-	HIP_TRY( ctx, hipMemcpy( ctx->dHotNodes, hot.data(), sizeof( float4 ) * hot.size(), hipMemcpyHostToDevice ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dNodes, nodes.data(), sizeof( float4 ) * nodes.size(), hipMemcpyHostToDevice ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dTris, tris.data(), sizeof( float4 ) * tris.size(), hipMemcpyHostToDevice ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dMats, mats.data(), sizeof( float4 ) * mats.size(), hipMemcpyHostToDevice ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dLights, lights.data(), sizeof( float4 ) * lights.size(), hipMemcpyHostToDevice ) );
 
 	ctx->numHotAvail = numHot;
-	ctx->firstSlot = slotOf[1];
+	ctx->firstRef = recordOf[1];
 	ctx->numNodes = s->num_nodes;
 	ctx->numFaces = s->num_faces;
 	ctx->numMaterials = s->num_materials;
@@ -1104,9 +1112,8 @@ DevParams sceneParams( pbr_ctx* ctx ) {
 	P.guard = ctx->dGuard;
 	P.numNodes = (int) ctx->numNodes;
 	P.numLights = (int) ctx->numLights;
-	P.hotNodes = ctx->dHotNodes;
 	P.numHot = 0;
-	P.firstSlot = ctx->firstSlot;
+	P.firstRef = ctx->firstRef;
 	return P;
 }
 

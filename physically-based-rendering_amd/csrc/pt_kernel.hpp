@@ -39,8 +39,8 @@ using namespace ptm;
 #define M_1_PI_D 0x1.45f306dc9c883p-2
 
 struct DevParams {
-	const float4* nodes;    // 2 x float4 per node: {min.xyz, w0}, {max.xyz, w1} — w0 / w1 are int bits, see decodeNode
-	const float4* hotNodes; // the numHot most-visited nodes (same 32-B records), copied to LDS by every block
+	const float4* nodes;    // the node stream: 2 x float4 per record {min.xy, max.xy}, {min.z, max.z, w0, w1}, see decodeNode;
+	                        // the most-visited nodes first (every block copies records [0, numHot) to LDS)
 	const float4* tris;     // 3 x float4 per face: {a.xyz, e1.x}, {e1.y, e1.z, e2.x, e2.y}, {e2.z, material(int bits), 0, 0}
 	const float4* mats;     // 4 x float4 per material: {d, Ni, p|nu, rough|nv}, {Rs, Rd, 0, 0}, Kd, Ks
 	const float4* lights;   // 3 x float4 per light: pos, rgb, {type, radius, 0, 0}
@@ -61,8 +61,8 @@ struct DevParams {
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
-	int numHot;             // records of hotNodes a block stages in LDS (slot s < numHot is resident)
-	int firstSlot;          // slot of node 1, where every walk starts
+	int numHot;             // records [0, numHot) of the node stream are resident in LDS
+	int firstRef;           // record of node 1, where every walk starts
 	int nFrames, firstCount;
 	int useExplicitWeight;
 	float explicitWeight;
@@ -217,20 +217,21 @@ PT_DEV float triangleT( const DevParams& P, int face, const Ray& ray, float rayT
 // (pt_bvh.cl:107-110; the shadow walk has no `ray.t > tNear` cull, :151-154).
 typedef float f2v __attribute__( ( ext_vector_type( 2 ) ) );
 
+// A node record is laid out for the slab test: n0 = {min.x, min.y, max.x, max.y}, n1 = {min.z, max.z, w0, w1},
+// so that the three register pairs the packed instructions need are the halves of the two 16-B loads.
 template<bool ANYHIT>
-PT_DEV bool boxHit( const float4 lo, const float4 hi, const Ray& ray, const f3 invDir, float rayT, float* tNearOut ) {
-	// ( bb - origin ) * invDir for both planes of an axis; the x/y pairs are written as 2-vectors so
-	// that hipcc emits v_pk_add_f32 / v_pk_mul_f32 (two IEEE operations per instruction, same
-	// rounding as the scalar forms)
+PT_DEV bool boxHit( const float4 n0, const float4 n1, const Ray& ray, const f3 invDir, float rayT, float* tNearOut ) {
+	// ( bb - origin ) * invDir for both planes of an axis, as 2-vectors: v_pk_add_f32 / v_pk_mul_f32
+	// (two IEEE operations per instruction, same rounding as the scalar forms)
 	const f2v oxy = { ray.origin.x, ray.origin.y };
 	const f2v ixy = { invDir.x, invDir.y };
-	const f2v lxy = { lo.x, lo.y };
-	const f2v hxy = { hi.x, hi.y };
+	const f2v lxy = { n0.x, n0.y };
+	const f2v hxy = { n0.z, n0.w };
 	const f2v t1xy = ( lxy - oxy ) * ixy;
 	const f2v t2xy = ( hxy - oxy ) * ixy;
 	const f2v oz = { ray.origin.z, ray.origin.z };
 	const f2v iz = { invDir.z, invDir.z };
-	const f2v bz = { lo.z, hi.z };
+	const f2v bz = { n1.x, n1.y };
 	const f2v tz = ( bz - oz ) * iz;
 	const float t1x = t1xy.x, t1y = t1xy.y, t2x = t2xy.x, t2y = t2xy.y, t1z = tz.x, t2z = tz.y;
 	const float tNear = fmax1( fmax1( fmin1( t1x, t2x ), fmin1( t1y, t2y ) ), fmin1( t1z, t2z ) );
@@ -267,21 +268,25 @@ PT_DEV void testLeaf( const DevParams& P, int face0, int face1, const Ray& ray, 
 	}
 }
 
-// ---- node records and the LDS-resident tree top ------------------------------------------
-// A node is 32 B, {min.xyz, w0}{max.xyz, w1}, in the reference's DFS order (pt_bvh.cl:96-102: a
-// hit continues at index + 1, a miss at the miss link).  pbr_upload_scene re-encodes the two
-// link words so that a walk also knows, without any lookup, whether its NEXT node is one of the
-// hot nodes staged in LDS and in which slot:
-//   container  w0 = 1 << 31 | hitSlot << 12 | missSlot      w1 = miss link (-1: walk ends)
-//   leaf       w0 = face0 | hasSecondFace << 30              w1 = slot of node index + 1
-// with slot 0xFFF = "not staged".  Slots are ranked by expected visit frequency (surface area
-// of the parent box), so a block may stage any prefix [0, numHot) of the ranking.
-#define PT_NO_SLOT 0xFFF
-
+// ---- the node stream and the LDS-resident tree top ------------------------------------------
+// pbr_upload_scene turns the reference's DFS node array (pt_bvh.cl:96-102: a hit continues at
+// index + 1, a miss at the miss link) into a stream of 32-B records with EXPLICIT successors, so
+// that records may be stored in any order:
+//   n0 = {min.x, min.y, max.x, max.y}     n1 = {min.z, max.z, w0, w1}
+//   container  w0 = record to continue at when the box is hit    w1 = ... when it is missed
+//   leaf       w0 = 1 << 31 | hasSecondFace << 30 | face0         w1 = record to continue at (hit or miss)
+// A record reference < 0 ends the walk (the reference's `index > 0 && index < numNodes`, pt_bvh.cl:122).
+// The stream starts with the most-visited nodes, ranked by expected visit frequency (surface area of the
+// parent box); the rest follows in DFS order, so a cold node's hit successor is still the adjacent
+// 32 B.  A block stages any prefix [0, numHot) of the stream in LDS: "is my next node resident, and
+// where" is one compare on the reference itself.
 struct Cursor {
-	int index;   // node index in the global array
-	int slot;    // LDS slot of that node, or >= numHot
+	int ref;   // record in the node stream; < 0: the walk has ended
 };
+
+PT_DEV bool alive( Cursor c ) {
+	return c.ref >= 0;
+}
 
 struct NodeLinks {
 	bool leaf;
@@ -290,37 +295,41 @@ struct NodeLinks {
 };
 
 template<bool USE_LDS>
-PT_DEV void fetchNode( const DevParams& P, const float4* lds, Cursor c, float4* lo, float4* hi ) {
-	if( USE_LDS && c.slot < P.numHot ) {
-		*lo = lds[c.slot * 2 + 0];
-		*hi = lds[c.slot * 2 + 1];
+PT_DEV void fetchNode( const DevParams& P, const float4* lds, Cursor c, float4* n0, float4* n1 ) {
+	if( USE_LDS && c.ref < P.numHot ) {
+		*n0 = lds[c.ref * 2 + 0];
+		*n1 = lds[c.ref * 2 + 1];
 	}
 	else {
-		*lo = P.nodes[c.index * 2 + 0];
-		*hi = P.nodes[c.index * 2 + 1];
+		*n0 = P.nodes[(size_t) c.ref * 2 + 0];
+		*n1 = P.nodes[(size_t) c.ref * 2 + 1];
 	}
 }
 
-PT_DEV NodeLinks decodeNode( Cursor c, const float4 lo, const float4 hi ) {
-	// straight-line selects: both encodings are decoded and the right fields kept
-	const int w0 = __float_as_int( lo.w );
-	const int w1 = __float_as_int( hi.w );
+PT_DEV int leafFace0( int w0 ) {
+	return w0 & 0x3FFFFFFF;
+}
+
+PT_DEV int leafFace1( int w0 ) {
+	return ( w0 & 0x40000000 ) ? ( w0 & 0x3FFFFFFF ) + 1 : -1;
+}
+
+PT_DEV NodeLinks decodeNode( const float4 n1 ) {
+	const int w0 = __float_as_int( n1.z );
+	const int w1 = __float_as_int( n1.w );
 	NodeLinks n;
-	n.leaf = ( w0 >= 0 );
-	n.face0 = w0 & 0x3FFFFFFF;
-	n.face1 = ( w0 & 0x40000000 ) ? n.face0 + 1 : -1;
-	n.onHit.index = c.index + 1;
-	n.onHit.slot = n.leaf ? ( w1 & 0xFFF ) : ( ( w0 >> 12 ) & 0xFFF );
-	n.onMiss.index = n.leaf ? n.onHit.index : w1;
-	n.onMiss.slot = n.leaf ? n.onHit.slot : ( w0 & 0xFFF );
+	n.leaf = ( w0 < 0 );
+	n.face0 = leafFace0( w0 );
+	n.face1 = leafFace1( w0 );
+	n.onHit.ref = n.leaf ? w1 : w0;
+	n.onMiss.ref = w1;
 	return n;
 }
 
 PT_DEV Cursor firstNode( const DevParams& P ) {
 	// the walk starts at node 1 (pt_bvh.cl:84)
 	Cursor c;
-	c.index = 1;
-	c.slot = P.firstSlot;
+	c.ref = P.firstRef;
 	return c;
 }
 
@@ -348,9 +357,9 @@ template<bool ANYHIT, bool LIGHTS, bool USE_LDS>
 PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
 	const f3 invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
 	const float tLight = hit.t;
-	const int numNodes = P.numNodes;
 	Cursor cur = firstNode( P );
 #ifdef PBR_GUARD_TRAV
+	const int numNodes = P.numNodes;
 	int guardSteps = 0;
 #endif
 #ifdef PBR_EXP_STATS
@@ -363,7 +372,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 
 	bool walking = true;   // the walk always visits node 1 (pt_bvh.cl:84-88)
 	unsigned visits = 0;
-	int leafFace0 = 0, leafFace1 = -1;
+	int leafWord = 0;
 	float leafTNear = 0.0f;
 
 	for( ;; ) {
@@ -395,13 +404,14 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 				}
 #endif
 
-				float4 lo, hi;
-				fetchNode<USE_LDS>( P, lds, cur, &lo, &hi );
-				const NodeLinks node = decodeNode( cur, lo, hi );
+				float4 n0, n1;
+				fetchNode<USE_LDS>( P, lds, cur, &n0, &n1 );
+				const int w0 = __float_as_int( n1.z );
+				const int w1 = __float_as_int( n1.w );
 				float tNear;
 #ifdef PBR_EXP_PAD_VALU   // sensitivity probes (scripts/lab.sh): extra work per node visit
 				{
-					float pad = lo.x;
+					float pad = n0.x;
 					for( int k = 0; k < PBR_EXP_PAD_VALU; k++ ) {
 						asm volatile( "v_add_f32 %0, %0, %0" : "+v"( pad ) );
 					}
@@ -410,26 +420,23 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 #ifdef PBR_EXP_PAD_VMEM
 				for( int k = 0; k < PBR_EXP_PAD_VMEM; k++ ) {
 					const volatile float4* vg = (const volatile float4*) P.nodes;
-					const float x = vg[cur.index * 2 + ( k & 1 )].x;
+					const float x = vg[cur.ref * 2 + ( k & 1 )].x;
 					asm volatile( "" :: "v"( x ) );
 				}
 #endif
 
-				if( boxHit<ANYHIT>( lo, hi, ray, invDir, hit.t, &tNear ) ) {
-					cur = node.onHit;
+				// hit container -> w0; miss, or leaf -> w1
+				const bool isHit = boxHit<ANYHIT>( n0, n1, ray, invDir, hit.t, &tNear );
+				const bool isLeaf = ( w0 < 0 );
+				cur.ref = ( isHit && !isLeaf ) ? w0 : w1;
 
-					if( node.leaf ) {
-						parked = true;
-						leafFace0 = node.face0;
-						leafFace1 = node.face1;
-						leafTNear = tNear;
-					}
-				}
-				else {
-					cur = node.onMiss;
+				if( isHit && isLeaf ) {
+					parked = true;
+					leafWord = w0;
+					leafTNear = tNear;
 				}
 
-				walking = ( cur.index > 0 && cur.index < numNodes );
+				walking = alive( cur );
 			} while( walking && !parked && __popcll( __ballot( walking && !parked ) ) > keep );
 		}
 
@@ -444,7 +451,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 				}
 			}
 #endif
-			testLeaf( P, leafFace0, leafFace1, ray, leafTNear, hit, faceTests );
+			testLeaf( P, leafFace0( leafWord ), leafFace1( leafWord ), ray, leafTNear, hit, faceTests );
 
 			if( ANYHIT && hit.t < tLight ) {
 				walking = false;
@@ -472,7 +479,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 // Every block stages the hot nodes once (32 B x numHot, coalesced) before its waves start.
 PT_DEV void stageHotNodes( const DevParams& P, float4* lds ) {
 	for( int i = (int) threadIdx.x; i < P.numHot * 2; i += (int) blockDim.x ) {
-		lds[i] = P.hotNodes[i];
+		lds[i] = P.nodes[i];
 	}
 
 	__syncthreads();
@@ -1486,12 +1493,12 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 		if( mode == MODE_NODE ) {
 			st.dbgNodes++;
 
-			float4 lo, hi;
-			fetchNode<true>( P, lds, w.cur, &lo, &hi );
-			const NodeLinks node = decodeNode( w.cur, lo, hi );
+			float4 n0, n1;
+			fetchNode<true>( P, lds, w.cur, &n0, &n1 );
+			const NodeLinks node = decodeNode( n1 );
 			float tNear;
 
-			if( boxHit<false>( lo, hi, st.ray, w.invDir, w.hit.t, &tNear ) ) {
+			if( boxHit<false>( n0, n1, st.ray, w.invDir, w.hit.t, &tNear ) ) {
 				w.cur = node.onHit;
 
 				if( node.leaf ) {
@@ -1505,7 +1512,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 				w.cur = node.onMiss;
 			}
 
-			if( mode == MODE_NODE && !( w.cur.index > 0 && w.cur.index < numNodes ) ) {
+			if( mode == MODE_NODE && !alive( w.cur ) ) {
 				mode = MODE_SHADE;
 			}
 		}
@@ -1517,7 +1524,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 
 			if( mode == MODE_LEAF && ( nLeaf >= PBR_LEAF_BATCH || nNode == 0 ) ) {
 				testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, w.hit, st.dbgTris );
-				mode = ( w.cur.index > 0 && w.cur.index < numNodes ) ? MODE_NODE : MODE_SHADE;
+				mode = alive( w.cur ) ? MODE_NODE : MODE_SHADE;
 			}
 		}
 
@@ -1632,12 +1639,12 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				visits++;
 				PH_STAT( sNodeIt, sNodeAct )
 
-				float4 lo, hi;
-				fetchNode<true>( P, lds, w.cur, &lo, &hi );
-				const NodeLinks node = decodeNode( w.cur, lo, hi );
+				float4 n0, n1;
+				fetchNode<true>( P, lds, w.cur, &n0, &n1 );
+				const NodeLinks node = decodeNode( n1 );
 				float tNear;
 
-				if( boxHit<false>( lo, hi, st.ray, w.invDir, w.hit.t, &tNear ) ) {
+				if( boxHit<false>( n0, n1, st.ray, w.invDir, w.hit.t, &tNear ) ) {
 					w.cur = node.onHit;
 
 					if( node.leaf ) {
@@ -1651,7 +1658,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 					w.cur = node.onMiss;
 				}
 
-				if( mode == MODE_NODE && !( w.cur.index > 0 && w.cur.index < numNodes ) ) {
+				if( mode == MODE_NODE && !alive( w.cur ) ) {
 					mode = MODE_SHADE;
 				}
 			} while( mode == MODE_NODE && __popcll( __ballot( mode == MODE_NODE ) ) > keep );
@@ -1663,7 +1670,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 		if( mode == MODE_LEAF ) {
 			PH_STAT( sLeafIt, sLeafAct )
 			testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, w.hit, st.dbgTris );
-			mode = ( w.cur.index > 0 && w.cur.index < numNodes ) ? MODE_NODE : MODE_SHADE;
+			mode = alive( w.cur ) ? MODE_NODE : MODE_SHADE;
 		}
 
 		// ---- shade phase --------------------------------------------------------------------

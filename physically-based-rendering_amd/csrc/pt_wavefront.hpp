@@ -167,8 +167,7 @@ __global__ __launch_bounds__( PBR_BLOCK, 8 ) void wfTrace( const DevParams P, co
 	ray.dir = mk3( 0.0f, 0.0f, 1.0f );
 	WalkState w;
 	w.invDir = mk3( 1.0f, 1.0f, 1.0f );
-	w.cur.index = 0;
-	w.cur.slot = PT_NO_SLOT;
+	w.cur.ref = -1;
 	w.hit.t = inff();
 	w.hit.face = 0;
 	w.leafFace0 = -1;
@@ -183,8 +182,8 @@ __global__ __launch_bounds__( PBR_BLOCK, 8 ) void wfTrace( const DevParams P, co
 			nodes++;
 
 			float4 lo, hi;
-			fetchNode<true>( P, lds, w.cur, &lo, &hi );
-			const NodeLinks node = decodeNode( w.cur, lo, hi );
+			fetchNode<true>( P, lds, w.cur, &lo, &hi );   // lo = n0 {min.xy, max.xy}, hi = n1 {min.z, max.z, w0, w1}
+			const NodeLinks node = decodeNode( hi );
 			float tNear;
 
 			if( boxHit<false>( lo, hi, ray, w.invDir, w.hit.t, &tNear ) ) {
@@ -201,7 +200,7 @@ __global__ __launch_bounds__( PBR_BLOCK, 8 ) void wfTrace( const DevParams P, co
 				w.cur = node.onMiss;
 			}
 
-			if( mode == WF_NODE && !( w.cur.index > 0 && w.cur.index < numNodes ) ) {
+			if( mode == WF_NODE && !alive( w.cur ) ) {
 				// the ray has left the tree: publish its hit (pathtracing.cl:259 returns here)
 				W.state[6 * stride + slot] = make_float4( __uint_as_float( nodes ), __uint_as_float( tris ), __int_as_float( w.hit.face ), w.hit.t );
 				mode = WF_FETCH;
@@ -216,7 +215,7 @@ __global__ __launch_bounds__( PBR_BLOCK, 8 ) void wfTrace( const DevParams P, co
 			if( mode == WF_LEAF && ( nLeaf >= PBR_WF_LEAF_BATCH || nNode == 0 ) ) {
 				testLeaf( P, w.leafFace0, w.leafFace1, ray, w.leafTNear, w.hit, tris );
 
-				if( w.cur.index > 0 && w.cur.index < numNodes ) {
+				if( alive( w.cur ) ) {
 					mode = WF_NODE;
 				}
 				else {

@@ -413,6 +413,13 @@ def test_call_sequence_and_validation_errors(pbr, device):
     d.num_nodes = 1
     with pytest.raises(pbr.PbrError, match="root is never tested"):
         device.upload_scene(d)
+    # an array that ends in a container (children outside the array) cannot be walked
+    last = arr["bvh"].copy()
+    last[-1, 3], last[-1, 7] = -1.0, -1.0
+    d = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    d.bvh = last.ctypes.data
+    with pytest.raises(pbr.PbrError, match="last node is a container"):
+        device.upload_scene(d)
 
 
 # ----------------------------------------------------------------------------------------------
