@@ -4,9 +4,12 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scene cornell|sponza|dragon|hairball]
 
 One "step" = one frame = one pass of the hot path over every pixel (SAMPLES = 1 path per pixel,
-the reference's default).  The K timed steps run as ONE fused device launch (pbr_render: the
-running mean stays in registers across frames), after W untimed warm-up frames; scene arrays and
-the accumulated image are resident in HBM before the timed region starts.  Default workload =
+the reference's default).  The K timed steps run as ONE pbr_render call = one path-tracing launch
+over all (pixel, frame) units + one foldFrames launch that applies the running mean in frame order
+(several such pairs only if K frames x 16 B x pixels exceed 16 GiB), after W untimed warm-up
+frames — during which the library also times its four schedules on this scene and keeps the
+fastest (2 frames each, so W >= 8 settles it before the timed region).  Scene arrays and the
+accumulated image are resident in HBM before the timed region starts.  Default workload =
 BASELINE.json configs[1]: Cornell box, 1920x1080, 256 spp, depth 8, 1 GPU.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): 8x8-pixel tiles are dealt
@@ -164,7 +167,9 @@ def main():
     sync()
     t0 = time.perf_counter()
     dev.render(args.warmup, pbr.frame_seeds(args.warmup, args.steps), px, cam)   # synchronous: returns after the launch completed
-    kernel_ms = dev.last_kernel_ms()
+    kernel_ms = dev.last_kernel_ms()            # the whole render: path tracing + foldFrames
+    trace_ms, trace_launches = dev.last_trace()  # the path-tracing launches alone
+    plan, tuned = dev.last_plan()
     if world > 1:
         dev.export_tiles(gather_in.data_ptr())
         if args.backend == "nccl":
@@ -179,7 +184,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     counters = diff(dev.counters(), before)
-    stats = [elapsed, kernel_ms / 1e3, float(counters["nodes"]), float(counters["tris"]), float(counters["hits"]), float(counters["paths"])]
+    stats = [elapsed, trace_ms / trace_launches / 1e3, float(counters["nodes"]), float(counters["tris"]), float(counters["hits"]), float(counters["paths"])]
     if world > 1:
         t = torch.tensor(stats, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
@@ -188,14 +193,15 @@ def main():
         elapsed, kernel_s = float(tmax[0]), float(tmax[1])
         counters = {"nodes": int(t[2]), "tris": int(t[3]), "hits": int(t[4]), "paths": int(t[5])}
     else:
-        kernel_s = kernel_ms / 1e3
+        kernel_s = trace_ms / trace_launches / 1e3   # average duration of one path-tracing launch
 
     if rank == 0:
         samples = w * h * args.steps * int(cfg.samples)
         assert counters["paths"] == samples, (counters, samples)
         algo = algorithmic_bytes(counters, w * h * args.steps)
-        # per launch of the dominant kernel (pathTracing): one launch per rank; the slowest rank's duration
-        achieved = algo / world / kernel_s / 1e9
+        # per launch of the dominant kernel (the path-tracing kernel the auto-tuner settled on): each rank runs
+        # trace_launches of them per render; the slowest rank's average launch duration
+        achieved = algo / world / trace_launches / kernel_s / 1e9
         out = {
             "metric": "Msamples/s (paths/s) @1080p fixed seed; 1/2/4/8 MI355X scaling",
             "value": samples / elapsed / 1e6,
@@ -217,7 +223,7 @@ def main():
                 "seeds": "seed_k = 0.0333 * (k + 1)", "tiles": "8x8 px, tile t -> rank t %% %d" % world,
                 "host_bvh_build_s": round(t_build, 3),
             },
-            "kernel_ms": kernel_s * 1e3,
+            "kernel_ms": kernel_ms, "schedule": plan, "schedule_tuned": tuned >= 0, "trace_launches": trace_launches,
             "per_sample": {
                 "node_visits": counters["nodes"] / samples, "triangle_tests": counters["tris"] / samples,
                 "shaded_hits": counters["hits"] / samples, "algorithmic_bytes": algo / samples,
@@ -225,10 +231,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), samples) or 0) / world or None,
+                "traffic": (recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), samples) or 0) / world / trace_launches or None,
                 "traffic_source": "profiles/r01/pmc_traffic.json (separate rocprofv3 --pmc passes of this workload, scaled to this run's samples)",
-                "kernel": "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
-                "algorithmic_bytes_per_launch": algo / world,
+                "kernel": "ptk::pathTracingPhased" if plan.startswith("phased") else "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
+                "algorithmic_bytes_per_launch": algo / world / trace_launches,
             },
         }
         if world == 1 and args.cpu_seconds > 0:

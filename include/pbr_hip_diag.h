@@ -41,6 +41,11 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int lds_slots, const float* rays8, uint
  * records) so that rocprofv3's FETCH_SIZE / TCC_EA0_RDREQ_* can be interpreted. */
 int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t reads, double* ms_out );
 
+/* Which schedule rendered (the largest chunk of) the last render: "refill-lean", "refill-wide",
+ * "phased-lean", "phased-wide", "tile-*", "batched"; *tuned = index of the schedule the auto-tuner
+ * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
+int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
+
 /* The path-tracing launches of the last render: their summed duration (HIP events around each one)
  * and their number.  A multi-frame render is one launch unless its per-frame result buffer would
  * exceed 16 GiB; pbr_last_kernel_ms covers the whole render, foldFrames launches included. */

@@ -112,6 +112,8 @@ hip.pbr_diag_trace.argtypes = [_vp, _fp, ctypes.c_int, _fp, _ip, _fp, _up]
 hip.pbr_diag_brdf.argtypes = [_vp, _fp, ctypes.c_int, _fp]
 hip.pbr_diag_new_ray.argtypes = [_vp, _fp, ctypes.c_int, _fp]
 hip.pbr_diag_guard_trips.argtypes = [_vp, _up]
+hip.pbr_diag_last_trace.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
+hip.pbr_diag_last_plan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
 
 host.pbrh_last_error.restype = ctypes.c_char_p
 host.pbrh_cfg_set.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
@@ -360,6 +362,18 @@ class Device:
         out = (ctypes.c_uint32 * 3)()
         self._check(hip.pbr_diag_guard_trips(self._ctx, out))
         return [int(v) for v in out]
+
+    def last_trace(self):
+        """(summed duration in ms, number) of the path-tracing launches of the last render."""
+        ms, n = ctypes.c_double(), ctypes.c_uint32()
+        self._check(hip.pbr_diag_last_trace(self._ctx, ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def last_plan(self):
+        """(name of the schedule that rendered the last render, auto-tuner's choice or -1 while measuring)."""
+        name, tuned = ctypes.create_string_buffer(48), ctypes.c_int(-1)
+        self._check(hip.pbr_diag_last_plan(self._ctx, name, 48, ctypes.byref(tuned)))
+        return name.value.decode(), int(tuned.value)
 
     def export_tiles(self, device_ptr):
         self._check(hip.pbr_export_tiles(self._ctx, device_ptr))

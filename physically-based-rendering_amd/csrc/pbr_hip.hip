@@ -50,6 +50,12 @@ struct pbr_ctx {
 	float4* dFull = nullptr;       // all tiles of the frame, filled by pbr_import_tiles
 	float4* dFrameBuf = nullptr;   // frame-parallel launches: {finalColor, focus} per frame and local pixel slot
 	size_t frameBufFrames = 0;
+	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
+	// frames that are rendered anyway, then the fastest one is kept
+	int tunedPlan = -1;
+	double tuneMs[4] = { 0.0, 0.0, 0.0, 0.0 };
+	uint32_t tuneFrames[4] = { 0, 0, 0, 0 };
+	char lastPlan[48] = "";        // name of the plan that rendered the largest chunk of the last render
 	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
 	uint32_t lastTraceLaunches = 0; // ... and how many there were (frame-parallel renders are chunked)
 	float* dSeeds = nullptr;
@@ -146,7 +152,7 @@ template<bool REFILL, int MINW>
 KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 #ifdef PBR_LAB
 	(void) brdf; (void) shadow; (void) lights;
-	return ptk::pathTracing<1, false, false, true, MINW>;
+	return ptk::pathTracing<1, false, false, REFILL, MINW>;
 #else
 	if( brdf == 0 ) {
 		if( lights ) {
@@ -184,43 +190,40 @@ KernelFn pickKernelBatched( uint32_t brdf, bool shadow, bool lights ) {
 #endif
 }
 
-#ifndef PBR_PHASED_MINW
-#define PBR_PHASED_MINW 8
-#endif
-
-KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights ) {
-#ifdef PBR_LAB
-	(void) brdf; (void) shadow; (void) lights;
-	return ptk::pathTracingPhased<1, false, false, PBR_PHASED_MINW>;
-#else
-	if( brdf == 0 ) {
-		if( lights ) {
-			return shadow ? ptk::pathTracingPhased<0, true, true, PBR_PHASED_MINW> : ptk::pathTracingPhased<0, false, true, PBR_PHASED_MINW>;
-		}
-		return ptk::pathTracingPhased<0, false, false, PBR_PHASED_MINW>;
-	}
-
-	if( lights ) {
-		return shadow ? ptk::pathTracingPhased<1, true, true, PBR_PHASED_MINW> : ptk::pathTracingPhased<1, false, true, PBR_PHASED_MINW>;
-	}
-	return ptk::pathTracingPhased<1, false, false, PBR_PHASED_MINW>;
-#endif
-}
-
-// Lane-level refill pays one (wave-aggregated) atomic per finished pixel; below this many
-// frames per launch the tile-synchronous schedule is used instead (pt_kernel.hpp).
-const uint32_t kRefillMinFrames = 4;
-
-// Scenes whose tree does not fit the staged LDS prefix are latency-bound on node fetches: they
-// get the "wide" register budget (pt_kernel.hpp); small scenes the "lean" one.
-const uint32_t kWideMinNodes = 2048;
-
 #ifndef PBR_LEAN_MINW
 #define PBR_LEAN_MINW 4
 #endif
 #ifndef PBR_WIDE_MINW
 #define PBR_WIDE_MINW 8
 #endif
+
+template<int MINW>
+KernelFn pickKernelPhasedMode( uint32_t brdf, bool shadow, bool lights ) {
+#ifdef PBR_LAB
+	(void) brdf; (void) shadow; (void) lights;
+	return ptk::pathTracingPhased<1, false, false, MINW>;
+#else
+	if( brdf == 0 ) {
+		if( lights ) {
+			return shadow ? ptk::pathTracingPhased<0, true, true, MINW> : ptk::pathTracingPhased<0, false, true, MINW>;
+		}
+		return ptk::pathTracingPhased<0, false, false, MINW>;
+	}
+
+	if( lights ) {
+		return shadow ? ptk::pathTracingPhased<1, true, true, MINW> : ptk::pathTracingPhased<1, false, true, MINW>;
+	}
+	return ptk::pathTracingPhased<1, false, false, MINW>;
+#endif
+}
+
+KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) {
+	return wide ? pickKernelPhasedMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelPhasedMode<PBR_LEAN_MINW>( brdf, shadow, lights );
+}
+
+// Register budget when a schedule is forced (PBR_SCHEDULE) without PBR_VARIANT: scenes whose tree does
+// not fit the staged LDS prefix get "wide" (pt_kernel.hpp), small scenes "lean".  Unforced renders are auto-tuned.
+const uint32_t kWideMinNodes = 2048;
 
 KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights, bool refill, bool wide ) {
 	if( wide ) {
@@ -425,71 +428,93 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	const bool lights = ( ctx->numLights > 0 );
 	const bool shadow = ( ctx->cfg.shadow_rays == 1 ) && lights;
-	// experiments / A-B measurements: PBR_SCHEDULE = tile | refill | batched, PBR_VARIANT = lean | wide
+	// experiments / A-B measurements: PBR_SCHEDULE = tile | refill | batched | phased | wavefront, PBR_VARIANT = lean | wide
 	const char* force = std::getenv( "PBR_SCHEDULE" );
 	const char* variant = std::getenv( "PBR_VARIANT" );
-	bool refill = ( nFrames * ctx->cfg.samples >= kRefillMinFrames );
-	bool wide = ( ctx->numNodes >= kWideMinNodes );
+	auto forced = [&]( const char* name ) { return force != nullptr && std::strcmp( force, name ) == 0; };
 
-	if( force != nullptr ) {
-		refill = ( std::strcmp( force, "refill" ) == 0 ) ? true : ( std::strcmp( force, "tile" ) == 0 ) ? false : refill;
-	}
-	if( variant != nullptr ) {
-		wide = ( std::strcmp( variant, "wide" ) == 0 ) ? true : ( std::strcmp( variant, "lean" ) == 0 ) ? false : wide;
-	}
-
-	KernelFn kernel = pickKernel( ctx->cfg.brdf, shadow, lights, refill, wide );
-
-	if( force != nullptr && std::strcmp( force, "batched" ) == 0 ) {
-		kernel = pickKernelBatched( ctx->cfg.brdf, shadow, lights );
-	}
-
-	if( force != nullptr && std::strcmp( force, "phased" ) == 0 ) {
-		kernel = pickKernelPhased( ctx->cfg.brdf, shadow, lights );
-	}
-
-	// the refill / batched / phased kernels take (pixel, frame) units and leave the running mean to foldFrames
-	const bool frameParallel = refill || ( force != nullptr && ( std::strcmp( force, "batched" ) == 0 || std::strcmp( force, "phased" ) == 0 ) );
-
-	if( force != nullptr && std::strcmp( force, "wavefront" ) == 0 && !dof ) {
+	if( forced( "wavefront" ) && !dof ) {
+		std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "wavefront" );
 		return launchWavefront( ctx, P, shadow, lights );
 	}
 
-	// persistent grid: as many blocks as stay resident, never more than there is work for.
-	// LDS: each block stages a prefix of the hot-node ranking; the CU's 160 KB are split between
-	// the blocks the register budget admits.
-	const int blockThreads = PBR_BLOCK;
-	const int wavesPerBlock = blockThreads / 64;
-	int blocksPerCU = 0;
-	HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, blockThreads, 0 ) );
-	blocksPerCU = ( blocksPerCU < 1 ) ? 1 : blocksPerCU;
+	// A plan = kernel + persistent grid + LDS split.  Grid: as many blocks as stay resident, never more
+	// than there is work for.  LDS: each block stages a prefix of the node stream; the CU's 160 KB are
+	// split between the blocks the register budget admits.
+	struct Plan {
+		KernelFn kernel;
+		int blocks, numHot, park, shade;
+		size_t ldsBytes;
+		const char* name;
+	};
 
-	if( const char* cap = std::getenv( "PBR_BLOCKS_PER_CU" ) ) {   // experiments: run below the resident maximum
-		const int want = std::atoi( cap );
-		blocksPerCU = ( want >= 1 && want < blocksPerCU ) ? want : blocksPerCU;
-	}
+	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan ) -> int {
+		const int blockThreads = PBR_BLOCK;
+		const int wavesPerBlock = blockThreads / 64;
+		int blocksPerCU = 0;
+		HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, blockThreads, 0 ) );
+		blocksPerCU = ( blocksPerCU < 1 ) ? 1 : blocksPerCU;
 
-	const size_t ldsPerCU = 160 * 1024;
-	size_t slots = ( ldsPerCU / (size_t) blocksPerCU - 256 ) / 32;
-	slots = std::min<size_t>( slots, ctx->numHotAvail );
+		if( const char* cap = std::getenv( "PBR_BLOCKS_PER_CU" ) ) {   // experiments: run below the resident maximum
+			const int want = std::atoi( cap );
+			blocksPerCU = ( want >= 1 && want < blocksPerCU ) ? want : blocksPerCU;
+		}
 
-	if( const char* cap = std::getenv( "PBR_LDS_SLOTS" ) ) {        // experiments: 0 = no LDS staging
-		slots = std::min<size_t>( slots, (size_t) std::max( 0, std::atoi( cap ) ) );
-	}
+		const size_t ldsPerCU = 160 * 1024;
+		size_t slots = ( ldsPerCU / (size_t) blocksPerCU - 256 ) / 32;
+		slots = std::min<size_t>( slots, ctx->numHotAvail );
 
-	const size_t ldsBytes = slots * 32;
-	HIP_TRY( ctx, hipFuncSetAttribute( (const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes ) );
-	P.numHot = (int) slots;
+		if( const char* cap = std::getenv( "PBR_LDS_SLOTS" ) ) {        // experiments: 0 = no LDS staging
+			slots = std::min<size_t>( slots, (size_t) std::max( 0, std::atoi( cap ) ) );
+		}
 
-	int blocks = ctx->numCUs * blocksPerCU;
-	const int needed = ( ctx->numLocalTiles + wavesPerBlock - 1 ) / wavesPerBlock;
-	blocks = ( blocks > needed ) ? needed : blocks;
-	blocks = ( blocks < 1 ) ? 1 : blocks;
+		HIP_TRY( ctx, hipFuncSetAttribute( (const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ( slots * 32 ) ) );
 
-	if( !frameParallel ) {
-		HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
-		hipLaunchKernelGGL( kernel, dim3( (unsigned) blocks ), dim3( (unsigned) blockThreads ), ldsBytes, ctx->stream, P );
+		int blocks = ctx->numCUs * blocksPerCU;
+		const int needed = ( ctx->numLocalTiles + wavesPerBlock - 1 ) / wavesPerBlock;
+		blocks = ( blocks > needed ) ? needed : blocks;
+		plan->kernel = kernel;
+		plan->blocks = ( blocks < 1 ) ? 1 : blocks;
+		plan->numHot = (int) slots;
+		plan->ldsBytes = slots * 32;
+		plan->park = park;
+		plan->shade = shade;
+		plan->name = name;
+		return PBR_OK;
+	};
+
+	auto run = [&]( const Plan& plan ) -> int {
+		P.numHot = plan.numHot;
+		P.phPark = plan.park;
+		P.phShade = plan.shade;
+		hipLaunchKernelGGL( plan.kernel, dim3( (unsigned) plan.blocks ), dim3( (unsigned) PBR_BLOCK ), plan.ldsBytes, ctx->stream, P );
 		HIP_TRY( ctx, hipGetLastError() );
+		return PBR_OK;
+	};
+
+	if( forced( "tile" ) ) {
+		// tile-synchronous schedule: a wave walks whole 8x8 tiles, the running mean stays in registers
+		bool wide = ( ctx->numNodes >= kWideMinNodes );
+
+		if( variant != nullptr ) {
+			wide = ( std::strcmp( variant, "wide" ) == 0 ) ? true : ( std::strcmp( variant, "lean" ) == 0 ) ? false : wide;
+		}
+
+		Plan plan;
+		const int status = makePlan( pickKernel( ctx->cfg.brdf, shadow, lights, false, wide ), wide ? "tile-wide" : "tile-lean", 0, 0, &plan );
+
+		if( status != PBR_OK ) {
+			return status;
+		}
+
+		HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
+
+		const int ran = run( plan );
+
+		if( ran != PBR_OK ) {
+			return ran;
+		}
+
 		HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
 		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
 
@@ -498,43 +523,114 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		ctx->lastKernelMs = (double) ms;
 		ctx->lastTraceMs = (double) ms;
 		ctx->lastTraceLaunches = 1;
+		std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "%s", plan.name );
 		return PBR_OK;
 	}
 
-	// Frame-parallel: every (pixel, frame) is its own unit of work — the frames of a pixel are
-	// independent up to the running mean (pathtracing.cl:28,255,332) — so the launch ends with
-	// single frames in flight, not with whole pixels; {finalColor, focus} of each go to dFrameBuf
-	// and foldFrames applies setColors in frame order.  The buffer (16 B per pixel and frame) is
-	// capped, longer renders run as several launch pairs.
-	const size_t pixelSlots = (size_t) ctx->numLocalTiles * 64;
-	const size_t frameBytes = sizeof( float4 ) * pixelSlots;
-	size_t chunk = std::max<size_t>( 1, kFrameBufBytes / frameBytes );
-	chunk = std::min<size_t>( chunk, nFrames );
-	// the queue heads count pixel slots x frames of a band in 32 bits
-	chunk = std::min<size_t>( chunk, std::max<size_t>( 1, 0x7FFFFFFFull / ( pixelSlots + 64 * (size_t) P.queueWidth ) ) );
+	// Frame-parallel schedules: every (pixel, frame) is its own unit of work — the frames of a pixel are
+	// independent up to the running mean (pathtracing.cl:28,255,332) — so a launch ends with single
+	// frames in flight, not with whole pixels; {finalColor, focus} of each go to dFrameBuf and
+	// foldFrames applies setColors in frame order.  The buffer (16 B per pixel and frame) is capped,
+	// longer renders run as several launch pairs.
+	//
+	// Which kernel: the lock-step walk ("refill") or the lane state machine ("phased"), each with the
+	// lean (4 waves / SIMD, no spills) or the wide (8 waves / SIMD) register budget.  Which one wins
+	// depends on the scene (1080p: Cornell refill-lean 3470 vs phased-lean 2760 Msamples/s, dragon-class
+	// phased-lean 1380 vs refill-wide 1000), and all of them give the same bits — so the first frames
+	// of a scene + configuration, which have to be rendered anyway, are rendered in turn by each
+	// candidate (kTuneFrames each), timed, and the fastest is kept from then on.
+	const int kPlans = 4;
+	const uint32_t kTuneFrames = 2;
+	Plan plans[kPlans];
+	{
+		const uint32_t brdf = ctx->cfg.brdf;
+		int status = makePlan( pickKernel( brdf, shadow, lights, true, false ), "refill-lean", 0, 0, &plans[0] );
+		status = ( status != PBR_OK ) ? status : makePlan( pickKernel( brdf, shadow, lights, true, true ), "refill-wide", 0, 0, &plans[1] );
+		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2] );
+		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 40, &plans[3] );
 
-	if( const char* cap = std::getenv( "PBR_CHUNK_FRAMES" ) ) {    // experiments / tests: force several launch pairs
-		chunk = std::min<size_t>( chunk, (size_t) std::max( 1, std::atoi( cap ) ) );
+		if( status != PBR_OK ) {
+			return status;
+		}
 	}
 
-	if( ctx->frameBufFrames < chunk ) {
+	int forcedPlan = -1;
+	Plan batchedPlan;
+
+	if( force != nullptr || variant != nullptr ) {
+		bool wide = ( ctx->numNodes >= kWideMinNodes );
+
+		if( variant != nullptr ) {
+			wide = ( std::strcmp( variant, "wide" ) == 0 ) ? true : ( std::strcmp( variant, "lean" ) == 0 ) ? false : wide;
+		}
+
+		forcedPlan = forced( "phased" ) ? ( wide ? 3 : 2 ) : ( wide ? 1 : 0 );
+
+		if( forced( "batched" ) ) {
+			const int made = makePlan( pickKernelBatched( ctx->cfg.brdf, shadow, lights ), "batched", 0, 0, &batchedPlan );
+
+			if( made != PBR_OK ) {
+				return made;
+			}
+		}
+	}
+
+	if( const char* plan = std::getenv( "PBR_PLAN" ) ) {   // experiments: 0..3 = the candidates above, no tuning
+		forcedPlan = std::max( 0, std::min( kPlans - 1, std::atoi( plan ) ) );
+	}
+
+	const size_t pixelSlots = (size_t) ctx->numLocalTiles * 64;
+	const size_t frameBytes = sizeof( float4 ) * pixelSlots;
+	size_t chunkCap = std::max<size_t>( 1, kFrameBufBytes / frameBytes );
+	chunkCap = std::min<size_t>( chunkCap, nFrames );
+	// the queue heads count pixel slots x frames of a band in 32 bits
+	chunkCap = std::min<size_t>( chunkCap, std::max<size_t>( 1, 0x7FFFFFFFull / ( pixelSlots + 64 * (size_t) P.queueWidth ) ) );
+
+	if( const char* cap = std::getenv( "PBR_CHUNK_FRAMES" ) ) {    // experiments / tests: force several launch pairs
+		chunkCap = std::min<size_t>( chunkCap, (size_t) std::max( 1, std::atoi( cap ) ) );
+	}
+
+	if( ctx->frameBufFrames < chunkCap ) {
 		(void) hipFree( ctx->dFrameBuf );
 		ctx->dFrameBuf = nullptr;
 		ctx->frameBufFrames = 0;
-		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dFrameBuf, frameBytes * chunk ) );
-		ctx->frameBufFrames = chunk;
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dFrameBuf, frameBytes * chunkCap ) );
+		ctx->frameBufFrames = chunkCap;
 	}
 
 	P.frameBuf = ctx->dFrameBuf;
 	P.frameStride = (unsigned) pixelSlots;
 	const unsigned foldBlocks = (unsigned) ( ( pixelSlots + 255 ) / 256 );
 	double traceMs = 0.0;
-	uint32_t launches = 0;
+	uint32_t launches = 0, largest = 0;
 
 	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
 
-	for( uint32_t done = 0; done < nFrames; done += (uint32_t) chunk ) {
-		const uint32_t n = std::min<uint32_t>( (uint32_t) chunk, nFrames - done );
+	for( uint32_t done = 0; done < nFrames; ) {
+		// which plan renders this chunk, and how many frames of it
+		int choice = forcedPlan;
+		bool tuning = false;
+
+		if( choice < 0 ) {
+			choice = ctx->tunedPlan;
+
+			if( choice < 0 ) {
+				tuning = true;
+				choice = 0;
+
+				while( choice < kPlans - 1 && ctx->tuneFrames[choice] >= kTuneFrames ) {
+					choice++;
+				}
+			}
+		}
+
+		const Plan& plan = forced( "batched" ) ? batchedPlan : plans[choice];
+		uint32_t n = std::min<uint32_t>( (uint32_t) chunkCap, nFrames - done );
+
+		if( tuning ) {
+			n = std::min<uint32_t>( n, kTuneFrames - ctx->tuneFrames[choice] );
+		}
+
 		P.nFrames = (int) n;
 		P.firstCount = (int) ( firstCount + done );
 		P.seeds = ctx->dSeeds + done;
@@ -544,8 +640,13 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		}
 
 		HIP_TRY( ctx, hipEventRecord( ctx->evTraceStart, ctx->stream ) );
-		hipLaunchKernelGGL( kernel, dim3( (unsigned) blocks ), dim3( (unsigned) blockThreads ), ldsBytes, ctx->stream, P );
-		HIP_TRY( ctx, hipGetLastError() );
+
+		const int ran = run( plan );
+
+		if( ran != PBR_OK ) {
+			return ran;
+		}
+
 		HIP_TRY( ctx, hipEventRecord( ctx->evTraceStop, ctx->stream ) );
 		// the running mean so far: the input image for the first chunk, imageOut after that
 		hipLaunchKernelGGL( ptk::foldFrames, dim3( foldBlocks ), dim3( 256 ), 0, ctx->stream, P,
@@ -557,6 +658,30 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evTraceStart, ctx->evTraceStop ) );
 		traceMs += (double) ms;
 		launches++;
+
+		if( n > largest ) {
+			largest = n;
+			std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "%s", plan.name );
+		}
+
+		if( tuning ) {
+			ctx->tuneMs[choice] += (double) ms;
+			ctx->tuneFrames[choice] += n;
+
+			if( ctx->tuneFrames[kPlans - 1] >= kTuneFrames ) {
+				int best = 0;
+
+				for( int k = 1; k < kPlans; k++ ) {
+					if( ctx->tuneMs[k] / ctx->tuneFrames[k] < ctx->tuneMs[best] / ctx->tuneFrames[best] ) {
+						best = k;
+					}
+				}
+
+				ctx->tunedPlan = best;
+			}
+		}
+
+		done += n;
 	}
 
 	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
@@ -878,6 +1003,9 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	ctx->numMaterials = s->num_materials;
 	ctx->numLights = s->num_lights;
 	ctx->sceneBrdf = s->brdf;
+	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
+	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
+	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
 	ctx->hasScene = true;
 
 	return PBR_OK;
@@ -927,6 +1055,9 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	HIP_TRY( ctx, hipMemset( ctx->dImgDbg, 0, fullBytes ) );
 	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * kCounterSlots ) );
 	HIP_TRY( ctx, hipDeviceSynchronize() );   // the memsets ran on the null stream; launches use ctx->stream
+	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
+	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
+	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
 	ctx->configured = true;
 
 	return PBR_OK;
@@ -1318,6 +1449,20 @@ int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t r
 	float ms = 0.0f;
 	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
 	*ms_out = (double) ms * 1.0;
+	return PBR_OK;
+}
+
+int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned ) {
+	if( ctx == nullptr || name == nullptr || capacity == 0 ) {
+		return fail( ctx, PBR_EINVAL, "diag_last_plan: null argument" );
+	}
+
+	std::snprintf( name, capacity, "%s", ctx->lastPlan );
+
+	if( tuned != nullptr ) {
+		*tuned = ctx->tunedPlan;
+	}
+
 	return PBR_OK;
 }
 

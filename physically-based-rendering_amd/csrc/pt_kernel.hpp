@@ -60,6 +60,7 @@ struct DevParams {
 
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
+	int phPark, phShade;         // phased schedule: lanes that leave a node phase before it ends / lanes that wait before a shade phase runs
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
 	int numHot;             // records [0, numHot) of the node stream are resident in LDS
 	int firstRef;           // record of node 1, where every walk starts
@@ -333,6 +334,123 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 	return c;
 }
 
+// ---- the node phase, hand-scheduled -------------------------------------------------------------
+// One node phase of traverse() (below) for the lanes that are walking: fetch the node (LDS or
+// memory), slab test, follow the hit / miss record, until `keep` or fewer lanes are still walking.
+// Lanes that stop on a hit leaf return parked = 1 with the leaf's w0 word and tNear.
+//
+// Why assembly: compiled from C++, this loop carries its three per-lane conditions (walking,
+// parked, resident in LDS) as 64-bit scalar masks that are merged by ~35 scalar instructions per
+// iteration — and on gfx950 a scalar instruction costs 4.8 cycles of a SIMD's issue time against 2.4
+// for a vector one (scripts/micro/valu_rate.hip), so the compiled loop is bound by the scalar unit
+// (measured: 74 % busy on the Sponza-class scene, vector ALU 55 %).  Written by hand the lanes that
+// leave are simply dropped from EXEC, their registers stay as they were, and 13 scalar
+// instructions remain.  The vector arithmetic is, instruction for instruction, what hipcc emits
+// for boxHit<ANYHIT>() + the record decode (same operations, same operand order, IEEE mode
+// unchanged), so results are bit-identical to the C++ loop, which stays in use for PBR_GUARD builds,
+// for USE_LDS = false and as the statement of what this does.
+// Registers v46-v63 are the block's temporaries: n0 = v[46:49], n1 = v[50:53], the three slab
+// pairs v[54:59], tNear / tFar and scratch v60-v63.
+#if !defined( PBR_GUARD ) && !defined( PBR_EXP_STATS ) && !defined( PBR_NODE_PHASE_CXX )
+#define PT_NODE_PHASE_ASM 1
+
+template<bool ANYHIT>
+PT_DEV void nodePhaseAsm(
+	const DevParams& P, const float4* lds, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep,
+	int& ref, unsigned& visits, int& leafWord, float& leafTNear, int& parked
+) {
+	const unsigned ldsBase = (unsigned) (size_t) lds;   // low half of a generic LDS address = the LDS byte offset
+	const float eps = EPSILON5;
+	keep = __builtin_amdgcn_readfirstlane( keep );       // wave-uniform by construction; make it a scalar register
+	unsigned long long saved, active, parkMask, mA, mB, mH, mC;
+	int count;
+
+#define PT_NODE_PHASE_HEAD \
+		"s_mov_b64 %[saved], exec\n" \
+		"s_mov_b64 %[parkMask], 0\n" \
+	"1:\n" \
+		"v_cmp_gt_i32 vcc, %[numHot], %[ref]\n" \
+		"v_lshl_add_u32 v60, %[ref], 5, %[ldsBase]\n" \
+		"v_lshlrev_b32 v61, 5, %[ref]\n" \
+		"s_mov_b64 %[active], exec\n" \
+		"s_and_b64 exec, %[active], vcc\n" \
+		"ds_read_b128 v[46:49], v60\n" \
+		"ds_read_b128 v[50:53], v60 offset:16\n" \
+		"s_andn2_b64 exec, %[active], vcc\n" \
+		"global_load_dwordx4 v[46:49], v61, %[nodes]\n" \
+		"global_load_dwordx4 v[50:53], v61, %[nodes] offset:16\n" \
+		"s_mov_b64 exec, %[active]\n" \
+		"v_add_u32 %[visits], 1, %[visits]\n" \
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
+		"v_pk_add_f32 v[54:55], v[46:47], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n" \
+		"v_pk_add_f32 v[56:57], v[48:49], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n" \
+		"v_pk_add_f32 v[58:59], v[50:51], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n" \
+		"v_pk_mul_f32 v[54:55], %[ixy], v[54:55]\n" \
+		"v_pk_mul_f32 v[56:57], %[ixy], v[56:57]\n" \
+		"v_pk_mul_f32 v[58:59], %[izz], v[58:59]\n" \
+		"v_min_f32 v60, v54, v56\n" \
+		"v_min_f32 v61, v55, v57\n" \
+		"v_min_f32 v62, v58, v59\n" \
+		"v_max3_f32 v60, v60, v61, v62\n" \
+		"v_max_f32 v61, v54, v56\n" \
+		"v_max_f32 v63, v58, v59\n" \
+		"v_max_f32 v62, v55, v57\n" \
+		"v_min_f32 v63, 0x7f800000, v63\n" \
+		"v_min3_f32 v61, v61, v62, v63\n" \
+		"v_cmp_lt_f32 %[mA], %[eps], v61\n"
+
+#define PT_NODE_PHASE_TAIL \
+		"v_cmp_gt_i32 vcc, 0, v52\n" \
+		"s_andn2_b64 %[mC], %[mH], vcc\n" \
+		"v_cndmask_b32 %[ref], v53, v52, %[mC]\n" \
+		"s_and_b64 %[mH], %[mH], vcc\n" \
+		"s_or_b64 %[parkMask], %[parkMask], %[mH]\n" \
+		"v_cmp_le_i32 vcc, 0, %[ref]\n" \
+		"s_andn2_b64 exec, vcc, %[mH]\n" \
+		"s_bcnt1_i32_b64 %[count], exec\n" \
+		"s_cmp_gt_i32 %[count], %[keep]\n" \
+		"s_cbranch_scc1 1b\n" \
+		"s_mov_b64 exec, %[saved]\n" \
+		"v_cndmask_b32 %[parked], 0, 1, %[parkMask]\n" \
+		"v_mov_b32 %[leafWord], v52\n" \
+		"v_mov_b32 %[leafTNear], v60\n"
+
+#define PT_NODE_PHASE_OPERANDS \
+		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [parked] "=v"( parked ), \
+		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [mB] "=&s"( mB ), [mH] "=&s"( mH ), \
+		  [mC] "=&s"( mC ), [count] "=&s"( count ) \
+		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ), \
+		  [numHot] "s"( P.numHot ), [ldsBase] "s"( ldsBase ), [nodes] "s"( P.nodes ), [eps] "s"( eps ) \
+		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc"
+
+	if( ANYHIT ) {
+		// traverseShadows: no `ray.t > tNear` cull (pt_bvh.cl:151-154)
+		asm volatile(
+			PT_NODE_PHASE_HEAD
+			"v_cmp_le_f32 vcc, v60, v61\n"
+			"s_and_b64 %[mH], %[mA], vcc\n"
+			PT_NODE_PHASE_TAIL
+			PT_NODE_PHASE_OPERANDS
+		);
+	}
+	else {
+		asm volatile(
+			PT_NODE_PHASE_HEAD
+			"v_cmp_gt_f32 %[mB], %[rayT], v60\n"
+			"v_cmp_le_f32 vcc, v60, v61\n"
+			"s_and_b64 %[mH], %[mA], %[mB]\n"
+			"s_and_b64 %[mH], %[mH], vcc\n"
+			PT_NODE_PHASE_TAIL
+			PT_NODE_PHASE_OPERANDS
+		);
+	}
+
+#undef PT_NODE_PHASE_HEAD
+#undef PT_NODE_PHASE_TAIL
+#undef PT_NODE_PHASE_OPERANDS
+}
+#endif
+
 // traverse (pt_bvh.cl:82-123) / traverseShadows (:133-177).  ANYHIT: the shadow variant — no
 // `ray.t > tNear` cull, stops at the first face hit nearer than the light.  Per lane this is
 // exactly the reference's sequence of node visits and face tests.
@@ -370,6 +488,12 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 		traverseLights( P, ray, hit );
 	}
 
+#ifdef PT_NODE_PHASE_ASM
+	const f2v oxy = { ray.origin.x, ray.origin.y };
+	const f2v ozz = { ray.origin.z, ray.origin.z };
+	const f2v ixy = { invDir.x, invDir.y };
+	const f2v izz = { invDir.z, invDir.z };
+#endif
 	bool walking = true;   // the walk always visits node 1 (pt_bvh.cl:84-88)
 	unsigned visits = 0;
 	int leafWord = 0;
@@ -383,7 +507,15 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 			const int entered = __popcll( __ballot( 1 ) );
 			const int leave = ( entered * PBR_PARK_NUM ) >> PBR_PARK_SHIFT;
 			const int keep = entered - ( ( leave < 1 ) ? 1 : leave );
-
+#ifdef PT_NODE_PHASE_ASM
+			if( USE_LDS ) {
+				int parkedFlag;
+				nodePhaseAsm<ANYHIT>( P, lds, oxy, ozz, ixy, izz, hit.t, keep, cur.ref, visits, leafWord, leafTNear, parkedFlag );
+				parked = ( parkedFlag != 0 );
+				walking = alive( cur );
+			}
+			else
+#endif
 			do {
 #ifdef PBR_GUARD_TRAV
 				// a forward-only walk visits each node at most once
@@ -1570,19 +1702,12 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 //
 //   node phase   a tight loop over the lanes that are walking; a lane leaves it when it hits a
 //                leaf (-> LEAF) or its ray has left the tree (-> SHADE); the loop itself ends once
-//                PBR_PH_PARK lanes have left it (or nobody is left)
+//                P.phPark lanes have left it (or nobody is left)
 //   leaf phase   the triangle tests of every lane parked on a leaf, in one go
-//   shade phase  once PBR_PH_SHADE lanes wait for shading (or nothing else can run): shade them,
+//   shade phase  once P.phShade lanes wait for shading (or nothing else can run): shade them,
 //                start their next rays / take their next pixels
 //
 // The node loop carries only the walk state; the path state is untouched between shade phases.
-#ifndef PBR_PH_PARK
-#define PBR_PH_PARK 16
-#endif
-#ifndef PBR_PH_SHADE
-#define PBR_PH_SHADE 24
-#endif
-
 template<int BRDF, bool SHADOW, bool LIGHTS, int MINW>
 __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const DevParams P ) {
 	const float4* lds = gHotNodes;
@@ -1629,12 +1754,32 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 #endif
 		// ---- node phase ---------------------------------------------------------------------
 		if( mode == MODE_NODE ) {
-			const int keep = __popcll( __ballot( 1 ) ) - PBR_PH_PARK;
+			const int keep = __popcll( __ballot( 1 ) ) - P.phPark;
 			unsigned visits = 0;
 
 #ifdef PBR_EXP_STATS
 			{ unsigned dummy = 0; PH_STAT( sNodePh, dummy ) }
 #endif
+#ifdef PT_NODE_PHASE_ASM
+			{
+				// the same hand-scheduled node phase as traverse()
+				const f2v oxy = { st.ray.origin.x, st.ray.origin.y };
+				const f2v ozz = { st.ray.origin.z, st.ray.origin.z };
+				const f2v ixy = { w.invDir.x, w.invDir.y };
+				const f2v izz = { w.invDir.z, w.invDir.z };
+				int leafWord, parkedFlag;
+				nodePhaseAsm<false>( P, lds, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, parkedFlag );
+
+				if( parkedFlag != 0 ) {
+					w.leafFace0 = leafFace0( leafWord );
+					w.leafFace1 = leafFace1( leafWord );
+					mode = MODE_LEAF;
+				}
+				else if( !alive( w.cur ) ) {
+					mode = MODE_SHADE;
+				}
+			}
+#else
 			do {
 				visits++;
 				PH_STAT( sNodeIt, sNodeAct )
@@ -1662,6 +1807,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 					mode = MODE_SHADE;
 				}
 			} while( mode == MODE_NODE && __popcll( __ballot( mode == MODE_NODE ) ) > keep );
+#endif
 
 			st.dbgNodes += visits;
 		}
@@ -1678,7 +1824,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 			const int nShade = __popcll( __ballot( mode == MODE_SHADE ) );
 			const int nNode = __popcll( __ballot( mode == MODE_NODE ) );
 
-			if( mode == MODE_SHADE && ( nShade >= PBR_PH_SHADE || nNode == 0 ) ) {
+			if( mode == MODE_SHADE && ( nShade >= P.phShade || nNode == 0 ) ) {
 				PH_STAT( sShadeIt, sShadeAct )
 				if( shadeStep<BRDF, SHADOW, LIGHTS, true>( P, lds, st, cnt, w.hit ) ) {
 					finishPixel<true>( P, st );

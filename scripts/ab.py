@@ -18,7 +18,7 @@ for job in jobs:
     sc = pbr.HostScene.generate(kind, seed, tris)
     cfg, cam, px = sc.config(W, H), sc.camera(), pbr.pixel_dimension(W, H)
     dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(cfg)
-    dev.render(0, pbr.frame_seeds(0, 4), px, cam)                      # warm-up
+    dev.render(0, pbr.frame_seeds(0, 8), px, cam)                      # warm-up (and schedule auto-tuning: 4 candidates x 2 frames)
     times = []
     for rep in range(2):
         dev.reset_accum()
@@ -29,9 +29,15 @@ for job in jobs:
     img = dev.read_output()
     digest = hashlib.sha1(np.ascontiguousarray(img).tobytes()).hexdigest()[:12]
     best = min(times)
+    import ctypes as _ct
+    plan = _ct.create_string_buffer(48); tuned = _ct.c_int(-2)
+    if hasattr(pbr.hip, "pbr_diag_last_plan"):
+        pbr.hip.pbr_diag_last_plan.argtypes = [_ct.c_void_p, _ct.c_char_p, _ct.c_size_t, _ct.POINTER(_ct.c_int)]
+        pbr.hip.pbr_diag_last_plan(dev._ctx, plan, 48, _ct.byref(tuned))
+    tag2 = tag + " " + plan.value.decode()
     visits = c1["nodes"] - c0["nodes"]
-    print("%-34s %-9s %3d frames  %9.2f ms  %8.1f Msamples/s  %6.1f G visits/s (%5.1f nodes %4.1f tris /sample)  sha1 %s" % (
-        tag, name, frames, best, W * H * frames / best / 1e3, visits / best / 1e6, visits / (W * H * frames),
+    print("%-46s %-9s %3d frames  %9.2f ms  %8.1f Msamples/s  %6.1f G visits/s (%5.1f nodes %4.1f tris /sample)  sha1 %s" % (
+        tag2, name, frames, best, W * H * frames / best / 1e3, visits / best / 1e6, visits / (W * H * frames),
         (c1["tris"] - c0["tris"]) / (W * H * frames), digest), flush=True)
     import ctypes
     raw = (ctypes.c_uint64 * 16)()

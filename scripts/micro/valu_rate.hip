@@ -38,6 +38,27 @@ __global__ __launch_bounds__( 1024 ) void rate( float* out, int iters ) {
 			REP8( asm volatile( "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0"
 				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ), "+v"( a7 ) :: "vcc" ); )
 		}
+		else if( MODE == 6 ) {
+			// 64 scalar ALU instructions on 8 independent chains
+			unsigned s0 = i, s1 = 1, s2 = 2, s3 = 3, s4 = 4, s5 = 5, s6 = 6, s7 = 7;
+			REP8( asm volatile( "s_add_u32 %0, %0, %1\n s_add_u32 %1, %1, %2\n s_add_u32 %2, %2, %3\n s_add_u32 %3, %3, %4\n s_and_b32 %4, %4, %5\n s_or_b32 %5, %5, %6\n s_add_u32 %6, %6, %7\n s_add_u32 %7, %7, %0"
+				: "+s"( s0 ), "+s"( s1 ), "+s"( s2 ), "+s"( s3 ), "+s"( s4 ), "+s"( s5 ), "+s"( s6 ), "+s"( s7 ) :: "scc" ); )
+			a1 += (float) s7;
+		}
+		else if( MODE == 7 ) {
+			// 32 VALU + 32 SALU interleaved: do they overlap?
+			unsigned s0 = i, s1 = 1, s2 = 2, s3 = 3;
+			REP8( asm volatile( "v_add_f32 %0, %0, %0\n s_add_u32 %4, %4, %5\n v_add_f32 %1, %1, %1\n s_add_u32 %5, %5, %6\n v_add_f32 %2, %2, %2\n s_add_u32 %6, %6, %7\n v_add_f32 %3, %3, %3\n s_add_u32 %7, %7, %4"
+				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+s"( s0 ), "+s"( s1 ), "+s"( s2 ), "+s"( s3 ) :: "scc" ); )
+			a5 += (float) s3;
+		}
+		else if( MODE == 8 ) {
+			// 64-bit mask ops as the compiler emits them for divergent control flow
+			unsigned long long m0 = i, m1 = 1, m2 = 2, m3 = 3;
+			REP8( asm volatile( "s_and_b64 %0, %0, %1\n s_or_b64 %1, %1, %2\n s_andn2_b64 %2, %2, %3\n s_xor_b64 %3, %3, %0\n s_and_b64 %0, %0, %1\n s_or_b64 %1, %1, %2\n s_andn2_b64 %2, %2, %3\n s_xor_b64 %3, %3, %0"
+				: "+s"( m0 ), "+s"( m1 ), "+s"( m2 ), "+s"( m3 ) :: "scc" ); )
+			a1 += (float) ( m3 & 1 );
+		}
 		else if( MODE == 4 ) {
 			// 8 random 16-B LDS reads per lane, address chain through the loaded value's zero fields
 			float4 v;
@@ -96,6 +117,9 @@ int main() {
 	run<1>( "v_pk_add_f32", cus, out );
 	run<2>( "v_min3_f32", cus, out );
 	run<3>( "v_cndmask/v_mov", cus, out );
+	run<6>( "s_add/s_and (64 SALU)", cus, out );
+	run<7>( "32 v_add + 32 s_add interleaved", cus, out );
+	run<8>( "s_and_b64 family (64 SALU)", cus, out );
 	run<4>( "ds_read_b128 random dependent", cus, out );
 	run<5>( "ds_read_b128 random x8 indep", cus, out );
 	return 0;
