@@ -376,6 +376,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	DevParams P;
 	std::memset( &P, 0, sizeof( P ) );
+	P.parkEighths = 4;
 	P.nodes = ctx->dNodes;
 	P.firstRef = ctx->firstRef;
 	P.tris = ctx->dTris;
@@ -443,7 +444,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// split between the blocks the register budget admits.
 	struct Plan {
 		KernelFn kernel;
-		int blocks, numHot, park, shade;
+		int blocks, numHot, park, shade, parkEighths;
 		size_t ldsBytes;
 		const char* name;
 	};
@@ -479,6 +480,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		plan->ldsBytes = slots * 32;
 		plan->park = park;
 		plan->shade = shade;
+		plan->parkEighths = ( ctx->numNodes >= kWideMinNodes ) ? 4 : 6;   // see traverse(), pt_kernel.hpp
+
+		if( const char* share = std::getenv( "PBR_PARK_EIGHTHS" ) ) {   // experiments
+			plan->parkEighths = std::max( 0, std::min( 8, std::atoi( share ) ) );
+		}
+
 		plan->name = name;
 		return PBR_OK;
 	};
@@ -487,6 +494,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.numHot = plan.numHot;
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
+		P.parkEighths = plan.parkEighths;
 		hipLaunchKernelGGL( plan.kernel, dim3( (unsigned) plan.blocks ), dim3( (unsigned) PBR_BLOCK ), plan.ldsBytes, ctx->stream, P );
 		HIP_TRY( ctx, hipGetLastError() );
 		return PBR_OK;
@@ -1236,6 +1244,7 @@ struct DevBuf {
 DevParams sceneParams( pbr_ctx* ctx ) {
 	DevParams P;
 	std::memset( &P, 0, sizeof( P ) );
+	P.parkEighths = 4;
 	P.nodes = ctx->dNodes;
 	P.tris = ctx->dTris;
 	P.mats = ctx->dMats;

@@ -60,6 +60,7 @@ struct DevParams {
 
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
+	int parkEighths;             // traverse(): a node phase ends once this many eighths of the lanes that entered it have left it
 	int phPark, phShade;         // phased schedule: lanes that leave a node phase before it ends / lanes that wait before a shade phase runs
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
 	int numHot;             // records [0, numHot) of the node stream are resident in LDS
@@ -459,18 +460,12 @@ PT_DEV void nodePhaseAsm(
 // plain lock-step loop enters the face tests in 30-70 % of its iterations with only 2-7 of the 64
 // lanes standing on a hit leaf — and the face tests are 3-4x as long as the slab test.  So a lane that
 // hits a leaf PARKS (remembers the leaf, stops walking) while the others walk on; once a share
-// PBR_PARK_NUM / 2^PBR_PARK_SHIFT of the lanes that entered the node phase have left it (parked
-// or finished), all parked lanes test their faces together.  With few lanes left the share rounds
+// P.parkEighths / 8 of the lanes that entered the node phase have left it (parked or finished), all
+// parked lanes test their faces together (measured best at 1080p: 6/8 for the Cornell box, whose
+// 35-node tree has a leaf every 5 visits; 4/8 for the 260k - 2M triangle scenes).  With few lanes left the share rounds
 // to one lane, i.e. the plain lock-step walk.  Rejected after measurement (bit-identical, slower):
 // waiting until EVERY lane stands on a leaf (dragon-class 0.65x), and requesting both successors
 // of a node before the slab test (a loss once registers are tight).
-#ifndef PBR_PARK_NUM
-#define PBR_PARK_NUM 1
-#endif
-#ifndef PBR_PARK_SHIFT
-#define PBR_PARK_SHIFT 1
-#endif
-
 template<bool ANYHIT, bool LIGHTS, bool USE_LDS>
 PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
 	const f3 invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
@@ -505,7 +500,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 		// ---- node phase: the lanes that are walking
 		if( walking ) {
 			const int entered = __popcll( __ballot( 1 ) );
-			const int leave = ( entered * PBR_PARK_NUM ) >> PBR_PARK_SHIFT;
+			const int leave = ( entered * P.parkEighths ) >> 3;
 			const int keep = entered - ( ( leave < 1 ) ? 1 : leave );
 #ifdef PT_NODE_PHASE_ASM
 			if( USE_LDS ) {
