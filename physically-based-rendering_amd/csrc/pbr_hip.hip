@@ -53,8 +53,11 @@ struct pbr_ctx {
 	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
 	// frames that are rendered anyway, then the fastest one is kept
 	int tunedPlan = -1;
-	double tuneMs[4] = { 0.0, 0.0, 0.0, 0.0 };
+	double tuneMs[4] = { 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
 	uint32_t tuneFrames[4] = { 0, 0, 0, 0 };
+	int refinePlan[2] = { -1, -1 };                 // refinement: the two fastest again, on longer chunks
+	double refineMs[2] = { 0.0, 0.0 };
+	uint32_t refineFrames[2] = { 0, 0 };
 	char lastPlan[48] = "";        // name of the plan that rendered the largest chunk of the last render
 	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
 	uint32_t lastTraceLaunches = 0; // ... and how many there were (frame-parallel renders are chunked)
@@ -482,6 +485,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		plan->shade = shade;
 		plan->parkEighths = ( ctx->numNodes >= kWideMinNodes ) ? 4 : 6;   // see traverse(), pt_kernel.hpp
 
+		if( const char* v = std::getenv( "PBR_PH_PARK" ) ) {    // experiments: phased thresholds
+			plan->park = std::max( 1, std::min( 64, std::atoi( v ) ) );
+		}
+		if( const char* v = std::getenv( "PBR_PH_SHADE" ) ) {
+			plan->shade = std::max( 1, std::min( 64, std::atoi( v ) ) );
+		}
 		if( const char* share = std::getenv( "PBR_PARK_EIGHTHS" ) ) {   // experiments
 			plan->parkEighths = std::max( 0, std::min( 8, std::atoi( share ) ) );
 		}
@@ -546,16 +555,19 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// depends on the scene (1080p: Cornell refill-lean 3470 vs phased-lean 2760 Msamples/s, dragon-class
 	// phased-lean 1380 vs refill-wide 1000), and all of them give the same bits — so the first frames
 	// of a scene + configuration, which have to be rendered anyway, are rendered in turn by each
-	// candidate (kTuneFrames each), timed, and the fastest is kept from then on.
+	// candidate (kTuneFrames each) and timed; short launches favour the plans with fewer, larger blocks,
+	// so the two fastest are then timed again on kRefineFrames each (alternating) before the faster is kept.
 	const int kPlans = 4;
 	const uint32_t kTuneFrames = 2;
+	const uint32_t kRefineFrames = 16;   // per plan, in alternating chunks of kRefineChunk
+	const uint32_t kRefineChunk = 8;
 	Plan plans[kPlans];
 	{
 		const uint32_t brdf = ctx->cfg.brdf;
 		int status = makePlan( pickKernel( brdf, shadow, lights, true, false ), "refill-lean", 0, 0, &plans[0] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernel( brdf, shadow, lights, true, true ), "refill-wide", 0, 0, &plans[1] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2] );
-		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 40, &plans[3] );
+		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 48, &plans[3] );
 
 		if( status != PBR_OK ) {
 			return status;
@@ -619,10 +631,16 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		int choice = forcedPlan;
 		bool tuning = false;
 
+		int refining = -1;   // index into refinePlan while the two fastest are compared
+
 		if( choice < 0 ) {
 			choice = ctx->tunedPlan;
 
-			if( choice < 0 ) {
+			if( choice < 0 && ctx->refinePlan[0] >= 0 ) {
+				refining = ( ctx->refineFrames[0] <= ctx->refineFrames[1] ) ? 0 : 1;   // A, B, A, B
+				choice = ctx->refinePlan[refining];
+			}
+			else if( choice < 0 ) {
 				tuning = true;
 				choice = 0;
 
@@ -637,6 +655,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 		if( tuning ) {
 			n = std::min<uint32_t>( n, kTuneFrames - ctx->tuneFrames[choice] );
+		}
+		if( refining >= 0 ) {
+			n = std::min<uint32_t>( n, std::min<uint32_t>( kRefineChunk, kRefineFrames - ctx->refineFrames[refining] ) );
 		}
 
 		P.nFrames = (int) n;
@@ -677,15 +698,32 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			ctx->tuneFrames[choice] += n;
 
 			if( ctx->tuneFrames[kPlans - 1] >= kTuneFrames ) {
-				int best = 0;
+				// screening done: the two fastest go on to the refinement
+				auto perFrame = [&]( int k ) { return ctx->tuneMs[k] / ctx->tuneFrames[k]; };
+				int best = 0, second = -1;
 
 				for( int k = 1; k < kPlans; k++ ) {
-					if( ctx->tuneMs[k] / ctx->tuneFrames[k] < ctx->tuneMs[best] / ctx->tuneFrames[best] ) {
+					if( perFrame( k ) < perFrame( best ) ) {
+						second = best;
 						best = k;
+					}
+					else if( second < 0 || perFrame( k ) < perFrame( second ) ) {
+						second = k;
 					}
 				}
 
-				ctx->tunedPlan = best;
+				ctx->refinePlan[0] = best;
+				ctx->refinePlan[1] = second;
+			}
+		}
+
+		if( refining >= 0 ) {
+			ctx->refineMs[refining] += (double) ms;
+			ctx->refineFrames[refining] += n;
+
+			if( ctx->refineFrames[1] >= kRefineFrames ) {
+				const double a = ctx->refineMs[0] / ctx->refineFrames[0], b = ctx->refineMs[1] / ctx->refineFrames[1];
+				ctx->tunedPlan = ( b < a ) ? ctx->refinePlan[1] : ctx->refinePlan[0];
 			}
 		}
 
@@ -1014,6 +1052,9 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
+	ctx->refinePlan[0] = ctx->refinePlan[1] = -1;
+	std::memset( ctx->refineMs, 0, sizeof( ctx->refineMs ) );
+	std::memset( ctx->refineFrames, 0, sizeof( ctx->refineFrames ) );
 	ctx->hasScene = true;
 
 	return PBR_OK;
@@ -1066,6 +1107,9 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
+	ctx->refinePlan[0] = ctx->refinePlan[1] = -1;
+	std::memset( ctx->refineMs, 0, sizeof( ctx->refineMs ) );
+	std::memset( ctx->refineFrames, 0, sizeof( ctx->refineFrames ) );
 	ctx->configured = true;
 
 	return PBR_OK;
