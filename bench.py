@@ -8,7 +8,7 @@ the reference's default).  The K timed steps run as ONE pbr_render call = one pa
 over all (pixel, frame) units + one foldFrames launch that applies the running mean in frame order
 (several such pairs only if K frames x 16 B x pixels exceed 16 GiB), after W untimed warm-up
 frames — during which the library also times its four schedules on this scene and keeps the
-fastest (2 frames each, then the two fastest again on 16 frames each: W >= 40, the default, settles
+fastest (2 frames each, then those within 10 % of the fastest again on 16 frames each: W >= 72, the default, settles
 it before the timed region; with a smaller W the rest of the tuning runs inside the timed frames).  Scene arrays and the
 accumulated image are resident in HBM before the timed region starts.  Default workload =
 BASELINE.json configs[1]: Cornell box, 1920x1080, 256 spp, depth 8, 1 GPU.
@@ -97,7 +97,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=72)
     ap.add_argument("--scene", default="cornell", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)

@@ -55,9 +55,11 @@ struct pbr_ctx {
 	int tunedPlan = -1;
 	double tuneMs[4] = { 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
 	uint32_t tuneFrames[4] = { 0, 0, 0, 0 };
-	int refinePlan[2] = { -1, -1 };                 // refinement: the two fastest again, on longer chunks
-	double refineMs[2] = { 0.0, 0.0 };
-	uint32_t refineFrames[2] = { 0, 0 };
+	int refineCount = 0;                            // refinement: the plans within 10 % of the fastest (at least two) again, on longer chunks
+	int refinePlan[4] = { -1, -1, -1, -1 };
+	uint32_t refineChunks = 0;                      // chunks rendered so far in the refinement
+	double refineMs[4] = { 0.0, 0.0, 0.0, 0.0 };
+	uint32_t refineFrames[4] = { 0, 0, 0, 0 };
 	char lastPlan[48] = "";        // name of the plan that rendered the largest chunk of the last render
 	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
 	uint32_t lastTraceLaunches = 0; // ... and how many there were (frame-parallel renders are chunked)
@@ -556,11 +558,11 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// phased-lean 1380 vs refill-wide 1000), and all of them give the same bits — so the first frames
 	// of a scene + configuration, which have to be rendered anyway, are rendered in turn by each
 	// candidate (kTuneFrames each) and timed; short launches favour the plans with fewer, larger blocks,
-	// so the two fastest are then timed again on kRefineFrames each (alternating) before the faster is kept.
+	// so the plans within 10 % of the fastest (at least two) are timed again on 2 x kRefineChunk frames each, in the
+	// order A B C C B A, before the fastest is kept.
 	const int kPlans = 4;
 	const uint32_t kTuneFrames = 2;
-	const uint32_t kRefineFrames = 16;   // per plan, in alternating chunks of kRefineChunk
-	const uint32_t kRefineChunk = 8;
+	const uint32_t kRefineChunk = 8;     // refinement: two chunks of this many frames per plan
 	Plan plans[kPlans];
 	{
 		const uint32_t brdf = ctx->cfg.brdf;
@@ -636,8 +638,11 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		if( choice < 0 ) {
 			choice = ctx->tunedPlan;
 
-			if( choice < 0 && ctx->refinePlan[0] >= 0 ) {
-				refining = ( ctx->refineFrames[0] <= ctx->refineFrames[1] ) ? 0 : 1;   // A, B, A, B
+			if( choice < 0 && ctx->refineCount > 0 ) {
+				// forward, then backward (A B C C B A): symmetric against a clock that is still ramping up or throttling
+				const uint32_t k = ctx->refineChunks % (uint32_t) ctx->refineCount;
+				const bool backward = ( ( ctx->refineChunks / (uint32_t) ctx->refineCount ) & 1u ) != 0u;
+				refining = backward ? ctx->refineCount - 1 - (int) k : (int) k;
 				choice = ctx->refinePlan[refining];
 			}
 			else if( choice < 0 ) {
@@ -657,7 +662,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			n = std::min<uint32_t>( n, kTuneFrames - ctx->tuneFrames[choice] );
 		}
 		if( refining >= 0 ) {
-			n = std::min<uint32_t>( n, std::min<uint32_t>( kRefineChunk, kRefineFrames - ctx->refineFrames[refining] ) );
+			n = std::min<uint32_t>( n, kRefineChunk );
 		}
 
 		P.nFrames = (int) n;
@@ -693,37 +698,44 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "%s", plan.name );
 		}
 
+		if( ( tuning || refining >= 0 ) && std::getenv( "PBR_TUNE_LOG" ) != nullptr ) {
+			std::fprintf( stderr, "[pbr tune] %s %-12s %u frame(s) %.3f ms = %.3f ms/frame\n", tuning ? "screen" : "refine", plan.name, n, (double) ms, (double) ms / n );
+		}
+
 		if( tuning ) {
 			ctx->tuneMs[choice] += (double) ms;
 			ctx->tuneFrames[choice] += n;
 
 			if( ctx->tuneFrames[kPlans - 1] >= kTuneFrames ) {
-				// screening done: the two fastest go on to the refinement
+				// screening done: every plan within 10 % of the fastest — at least the two fastest — goes on to the refinement
 				auto perFrame = [&]( int k ) { return ctx->tuneMs[k] / ctx->tuneFrames[k]; };
-				int best = 0, second = -1;
+				int order[kPlans] = { 0, 1, 2, 3 };
+				std::sort( order, order + kPlans, [&]( int x, int y ) { return perFrame( x ) < perFrame( y ); } );
+				ctx->refineCount = 0;
 
-				for( int k = 1; k < kPlans; k++ ) {
-					if( perFrame( k ) < perFrame( best ) ) {
-						second = best;
-						best = k;
-					}
-					else if( second < 0 || perFrame( k ) < perFrame( second ) ) {
-						second = k;
+				for( int k = 0; k < kPlans; k++ ) {
+					if( k < 2 || perFrame( order[k] ) <= 1.10 * perFrame( order[0] ) ) {
+						ctx->refinePlan[ctx->refineCount++] = order[k];
 					}
 				}
-
-				ctx->refinePlan[0] = best;
-				ctx->refinePlan[1] = second;
 			}
 		}
 
 		if( refining >= 0 ) {
 			ctx->refineMs[refining] += (double) ms;
 			ctx->refineFrames[refining] += n;
+			ctx->refineChunks++;
 
-			if( ctx->refineFrames[1] >= kRefineFrames ) {
-				const double a = ctx->refineMs[0] / ctx->refineFrames[0], b = ctx->refineMs[1] / ctx->refineFrames[1];
-				ctx->tunedPlan = ( b < a ) ? ctx->refinePlan[1] : ctx->refinePlan[0];
+			if( ctx->refineChunks >= 2u * (uint32_t) ctx->refineCount ) {
+				int best = 0;
+
+				for( int k = 1; k < ctx->refineCount; k++ ) {
+					if( ctx->refineMs[k] / ctx->refineFrames[k] < ctx->refineMs[best] / ctx->refineFrames[best] ) {
+						best = k;
+					}
+				}
+
+				ctx->tunedPlan = ctx->refinePlan[best];
 			}
 		}
 
@@ -1052,7 +1064,8 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
-	ctx->refinePlan[0] = ctx->refinePlan[1] = -1;
+	ctx->refineCount = 0;
+	ctx->refineChunks = 0;
 	std::memset( ctx->refineMs, 0, sizeof( ctx->refineMs ) );
 	std::memset( ctx->refineFrames, 0, sizeof( ctx->refineFrames ) );
 	ctx->hasScene = true;
@@ -1107,7 +1120,8 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
-	ctx->refinePlan[0] = ctx->refinePlan[1] = -1;
+	ctx->refineCount = 0;
+	ctx->refineChunks = 0;
 	std::memset( ctx->refineMs, 0, sizeof( ctx->refineMs ) );
 	std::memset( ctx->refineFrames, 0, sizeof( ctx->refineFrames ) );
 	ctx->configured = true;
