@@ -863,6 +863,17 @@ static void traverseLights( const ctx_t* c, ray4* ray ) {
 static uint32_t* g_node_hist = 0;
 void orc_debug_set_node_hist( uint32_t* hist ) { g_node_hist = hist; }
 
+/* Analysis aid (scripts/layout_study.py): the sequence of node indices the closest-hit walk visits,
+ * appended to log[0 .. capacity); *count is the running length.  Single-threaded use only. */
+static int32_t* g_visit_log = 0;
+static uint64_t g_visit_cap = 0;
+static uint64_t* g_visit_count = 0;
+void orc_debug_set_visit_log( int32_t* log, uint64_t capacity, uint64_t* count ) {
+	g_visit_log = log;
+	g_visit_cap = capacity;
+	g_visit_count = count;
+}
+
 /* traverse, pt_bvh.cl:82-123 */
 static void traverse( ctx_t* c, ray4* ray ) {
 	const v3 invDir = V3( det_rcp( ray->dir.x ), det_rcp( ray->dir.y ), det_rcp( ray->dir.z ) );
@@ -875,6 +886,9 @@ static void traverse( ctx_t* c, ray4* ray ) {
 		c->dbg_nodes += 1.0f;
 		if( g_node_hist ) {
 			__atomic_fetch_add( &g_node_hist[index], 1u, __ATOMIC_RELAXED );
+		}
+		if( g_visit_log && *g_visit_count < g_visit_cap ) {
+			g_visit_log[( *g_visit_count )++] = index;
 		}
 		const orc_bvh_node node = c->scene->bvh[index];
 		const int currentIndex = index;
