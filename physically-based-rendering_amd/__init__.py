@@ -139,6 +139,7 @@ host.pbrh_pt_destroy.restype = None
 host.pbrh_pt_init.argtypes = [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32]
 host.pbrh_pt_generate_image.argtypes = [_vp, _fp, _fp]
 host.pbrh_pt_generate_images.argtypes = [_vp, ctypes.c_uint32, _fp]
+host.pbrh_cl_adaptor_render.argtypes = [_vp, ctypes.c_uint32, ctypes.c_float, _fp, _fp]
 host.pbrh_pt_set_focus.argtypes = [_vp, ctypes.c_int, ctypes.c_int]
 host.pbrh_pt_reset_sample_count.argtypes = [_vp]
 host.pbrh_pt_sample_count.argtypes = [_vp]
@@ -215,6 +216,16 @@ class HostScene:
 
     def __del__(self):
         self.close()
+
+    def render_through_cl_adaptor(self, frames, seed_step=0.0333):
+        """Drive the `CL` look-alike (host/cl_adaptor.h) the way the reference's PathTracer drives CL, at the
+        configured window size (cfg window.width / window.height); returns (image, debug), row 0 = bottom."""
+        w, h = int(cfg_get("window.width")), int(cfg_get("window.height"))
+        image = np.empty((h, w, 4), np.float32)
+        debug = np.empty((h, w, 4), np.float32)
+        if host.pbrh_cl_adaptor_render(self._h, frames, seed_step, image.ctypes.data_as(_fp), debug.ctypes.data_as(_fp)) != 0:
+            raise PbrError(host.pbrh_last_error().decode())
+        return image, debug
 
     def config(self, width, height):
         cfg = Config()

@@ -21,7 +21,7 @@ HIP_LIB = os.path.join(CSRC, "libpbrhip.so")
 HIP_GUARD_LIB = os.path.join(CSRC, "libpbrhip_guard.so")   # same source, -DPBR_GUARD: every device loop bounded
 HOST_LIB = os.path.join(HOST, "libpbrhost.so")
 
-HOST_SOURCES = ["Cfg.cpp", "model_io.cpp", "bvh_builder.cpp", "scene_gen.cpp", "path_tracer.cpp", "host_capi.cpp"]
+HOST_SOURCES = ["Cfg.cpp", "model_io.cpp", "bvh_builder.cpp", "scene_gen.cpp", "path_tracer.cpp", "cl_adaptor.cpp", "host_capi.cpp"]
 
 
 def _hipcc():
@@ -68,7 +68,7 @@ def build_host(force=False):
         return HOST_LIB
     cmd = [
         "g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra",
-        "-I", INCLUDE, "-I", HOST,
+        "-I", INCLUDE, "-I", HOST, "-I", "/opt/rocm/include",   # <CL/cl.h> for the cl_* types of host/cl_adaptor.h
         *[os.path.join(HOST, f) for f in HOST_SOURCES],
         "-o", HOST_LIB, "-L", CSRC, "-lpbrhip", "-Wl,-rpath,$ORIGIN/../csrc",
     ]

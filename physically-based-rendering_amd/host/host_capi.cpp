@@ -10,6 +10,7 @@
 #include "Cfg.h"
 #include "bvh_builder.h"
 #include "model_io.h"
+#include "cl_adaptor.h"
 #include "path_tracer.h"
 #include "scene_gen.h"
 
@@ -264,6 +265,90 @@ void* pbrh_pt_context( void* tracer ) {
 
 void pbrh_pt_camera( void* tracer, pbr_camera* out ) {
 	*out = static_cast<HostTracer*>( tracer )->pt.camera();
+}
+
+
+// ---- the CL look-alike, driven the way the reference's PathTracer drives CL ---------------------
+// (PathTracer.cpp:136-230 initOpenCLBuffers + initKernelArgs, :59-71 generateImage, :43-52 clPathTracing),
+// with the fixed seed sequence seedStep * ( n + 1 ).  Renders `frames` frames of `scene` at the
+// configured window size and returns the last accumulated image and debug image.
+int pbrh_cl_adaptor_render( void* scene, uint32_t frames, float seedStep, float* image, float* debug ) {
+	HostScene* s = static_cast<HostScene*>( scene );
+
+	try {
+		Cfg& cfg = Cfg::get();
+		const uint32_t width = cfg.value<uint32_t>( Cfg::WINDOW_WIDTH );
+		const uint32_t height = cfg.value<uint32_t>( Cfg::WINDOW_HEIGHT );
+		const SceneBuffers& b = s->buffers;
+		CL cl( true );
+		char msg[128];
+
+		// initOpenCLBuffers_BVH / _Faces / _Materials / _Lights / _Textures
+		cl_mem bufBVH = cl.createBuffer( b.bvh, sizeof( pbr_bvh_node ) * b.bvh.size() );
+		std::snprintf( msg, sizeof( msg ), "%lu", (unsigned long) b.bvh.size() );
+		cl.setReplacement( "#BVH_NUM_NODES#", msg );
+		cl_mem bufFacesV = cl.createBuffer( b.facesV, sizeof( pbr_uint4 ) * b.facesV.size() );
+		cl_mem bufFacesN = cl.createBuffer( b.facesN, sizeof( pbr_uint4 ) * b.facesN.size() );
+		cl_mem bufVertices = cl.createBuffer( b.vertices, sizeof( pbr_float4 ) * b.vertices.size() );
+		cl_mem bufNormals = cl.createBuffer( b.normals, sizeof( pbr_float4 ) * b.normals.size() );
+		cl_mem bufMaterials = ( b.brdf == 0 )
+			? cl.createBuffer( b.materialsSchlick, sizeof( pbr_material_schlick ) * b.materialsSchlick.size() )
+			: cl.createBuffer( b.materialsSA, sizeof( pbr_material_sa ) * b.materialsSA.size() );
+		std::snprintf( msg, sizeof( msg ), "(float4)( %f, %f, %f, 0.0f )", b.skyLight[0], b.skyLight[1], b.skyLight[2] );
+		cl.setReplacement( "#SKY_LIGHT#", msg );
+		cl_mem bufLights = cl.createBuffer( b.lights, sizeof( pbr_light ) * b.lights.size() );
+		std::snprintf( msg, sizeof( msg ), "%lu", (unsigned long) b.numLights );
+		cl.setReplacement( "#NUM_LIGHTS#", msg );
+
+		std::vector<cl_float> textureOut( (size_t) width * height * 4, 0.0f );
+		std::vector<cl_float> textureDebug( (size_t) width * height * 4, 0.0f );
+		cl_mem bufTextureIn = cl.createImage2DReadOnly( width, height, &textureOut[0] );
+		cl_mem bufTextureOut = cl.createImage2DWriteOnly( width, height );
+		cl_mem bufTextureDebug = cl.createImage2DWriteOnly( width, height );
+
+		cl.loadProgram( "source/opencl/pathtracing.cl" );
+		cl_kernel kernel = cl.createKernel( "pathTracing" );
+
+		// initKernelArgs
+		cl_float pxDim = PathTracer::pixelDimension( width, height, cfg.value<float>( Cfg::PERS_FOV ) );
+		pbr_camera cam;
+		pbrh_scene_camera( scene, &cam );
+		cl_uint i = 2;
+		cl.setKernelArg( kernel, i++, sizeof( cl_float ), &pxDim );
+		cl.setKernelArg( kernel, i++, sizeof( pbr_camera ), &cam );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufBVH );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufFacesV );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufFacesN );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufVertices );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufNormals );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufMaterials );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufLights );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufTextureIn );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufTextureOut );
+		cl.setKernelArg( kernel, i++, sizeof( cl_mem ), &bufTextureDebug );
+
+		// generateImage x frames
+		for( uint32_t n = 0; n < frames; n++ ) {
+			cl.updateImageReadOnly( bufTextureIn, width, height, &textureOut[0] );
+			cl_float timeSinceStart = seedStep * (float) ( n + 1 );
+			cl_float pixelWeight = (float) n / (float) ( n + 1 );
+			cl.setKernelArg( kernel, 0, sizeof( cl_float ), &timeSinceStart );
+			cl.setKernelArg( kernel, 1, sizeof( cl_float ), &pixelWeight );
+			cl.setKernelArg( kernel, 3, sizeof( pbr_camera ), &cam );
+			cl.execute( kernel );
+			cl.finish();
+			cl.readImageOutput( bufTextureOut, width, height, &textureOut[0] );
+			cl.readImageOutput( bufTextureDebug, width, height, &textureDebug[0] );
+		}
+
+		std::memcpy( image, textureOut.data(), textureOut.size() * sizeof( float ) );
+		std::memcpy( debug, textureDebug.data(), textureDebug.size() * sizeof( float ) );
+		return 0;
+	}
+	catch( const std::exception& e ) {
+		gError = e.what();
+		return -1;
+	}
 }
 
 }  // extern "C"

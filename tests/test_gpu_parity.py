@@ -362,6 +362,24 @@ def test_path_tracer_driver_matches_device_calls(pbr, oracle, gpu_device):
     pt2.close()
 
 
+@pytest.mark.parametrize("cfg", [{"render.max_depth": 4}, {"render.max_depth": 3, "render.brdf": 0, "render.samples": 2}])
+def test_cl_adaptor_driven_like_the_reference(pbr, oracle, gpu_device, cfg):
+    """host/cl_adaptor.h: class CL with the reference's public methods over the C ABI, driven by the exact
+    call sequence of the reference's PathTracer (createBuffer x 7, setReplacement, images, loadProgram,
+    createKernel, setKernelArg, then per frame updateImageReadOnly / execute / readImageOutput x 2)."""
+    w, h = 64, 40
+    sc = make_scene(pbr, **dict(cfg, **{"window.width": w, "window.height": h}))
+    config, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    # #SKY_LIGHT# travels as text printed with %f (PathTracer.cpp:466-472): the adaptor reads what the OpenCL compiler would
+    for k in range(3):
+        config.sky_light[k] = float(np.float32(float("%f" % config.sky_light[k])))
+    ref = oracle.Renderer(sc.desc, config, threads=8)
+    want = ref.render(0, pbr.frame_seeds(0, 5), px, cam)
+    image, debug = sc.render_through_cl_adaptor(5)
+    assert same_values(image, want), describe_mismatch(image, want)
+    assert same_values(debug, ref.debug)
+
+
 # ----------------------------------------------------------------------------------------------
 # error behaviour of the boundary
 # ----------------------------------------------------------------------------------------------
