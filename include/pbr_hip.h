@@ -138,6 +138,12 @@ int pbr_render( pbr_ctx* ctx, uint32_t first_sample_count, uint32_t n_frames, co
 int pbr_read_output( pbr_ctx* ctx, float* rgba );
 int pbr_read_debug( pbr_ctx* ctx, float* rgba );
 
+/* The display step the reference leaves to GL (shader/pathtracing.frag:11-15 writes the linear colour to an
+ * 8-bit framebuffer): imageOut as width x height RGBA8, each channel floor( clamp( c, 0, 1 ) * 255 + 0.5 ), NaN -> 0,
+ * alpha 255, converted on the device (4 B instead of 16 B per pixel over PCIe).  top_row_first = 0: row 0 is the
+ * bottom of the image, as pbr_read_output and GL have it; 1: top row first, as image files want it. */
+int pbr_read_display( pbr_ctx* ctx, uint8_t* rgba8, int top_row_first );
+
 int pbr_get_counters( pbr_ctx* ctx, pbr_counters* out );
 /* CL::getKernelTimes (source/CL.cpp:480-488): device time of the last launch, HIP events. */
 double pbr_last_kernel_ms( const pbr_ctx* ctx );

@@ -97,6 +97,7 @@ hip.pbr_accumulate.argtypes = [_vp]
 hip.pbr_render.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32, _fp, ctypes.c_float, ctypes.POINTER(Camera)]
 hip.pbr_read_output.argtypes = [_vp, _fp]
 hip.pbr_read_debug.argtypes = [_vp, _fp]
+hip.pbr_read_display.argtypes = [_vp, ctypes.c_void_p, ctypes.c_int]
 hip.pbr_read_full.argtypes = [_vp, _fp]
 hip.pbr_get_counters.argtypes = [_vp, ctypes.POINTER(Counters)]
 hip.pbr_last_kernel_ms.argtypes = [_vp]
@@ -323,6 +324,12 @@ class Device:
 
     def read_full(self):
         return self._read(hip.pbr_read_full)
+
+    def read_display(self, top_row_first=False):
+        """imageOut as (H, W, 4) uint8 — what the reference's GL viewer shows (clamped linear colour)."""
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        self._check(hip.pbr_read_display(self._ctx, out.ctypes.data, 1 if top_row_first else 0))
+        return out
 
     def counters(self):
         c = Counters()

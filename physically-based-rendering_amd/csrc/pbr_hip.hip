@@ -1207,6 +1207,29 @@ int pbr_read_output( pbr_ctx* ctx, float* rgba ) {
 	return readTiled( ctx, ctx->dImgOut, rgba, (int) ctx->cfg.tile_world, (int) ctx->cfg.tile_rank );
 }
 
+int pbr_read_display( pbr_ctx* ctx, uint8_t* rgba8, int top_row_first ) {
+	if( ctx == nullptr ) {
+		return PBR_EINVAL;
+	}
+	if( !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "read before pbr_configure" );
+	}
+	if( rgba8 == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "read: null destination" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	const dim3 block( 64, 4 );
+	const dim3 grid( ( ctx->cfg.width + 63 ) / 64, ( ctx->cfg.height + 3 ) / 4 );
+	// dRows (16 B per pixel) doubles as the 4-B-per-pixel staging buffer
+	hipLaunchKernelGGL( ptk::displayRGBA8, grid, block, 0, ctx->stream, (const float4*) ctx->dImgOut, (uchar4*) ctx->dRows,
+		(int) ctx->cfg.width, (int) ctx->cfg.height, ctx->tilesX, (int) ctx->cfg.tile_world, (int) ctx->cfg.tile_rank, top_row_first ? 1 : 0 );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipMemcpyAsync( rgba8, ctx->dRows, (size_t) 4 * ctx->cfg.width * ctx->cfg.height, hipMemcpyDeviceToHost, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	return PBR_OK;
+}
+
 int pbr_read_debug( pbr_ctx* ctx, float* rgba ) {
 	if( ctx == nullptr ) {
 		return PBR_EINVAL;

@@ -1910,6 +1910,37 @@ __global__ void untile( const float4* tiles, float4* rows, int width, int height
 	rows[(size_t) y * (size_t) width + (size_t) x] = v;
 }
 
+// The display step after the path: what shader/pathtracing.frag:11-15 puts on an
+// 8-bit GL framebuffer — the linear colour, clamped to [0, 1], alpha 1 — as RGBA8, value = floor( c * 255 + 0.5 ).
+// rowStep = +1: row 0 is the bottom of the image (GL, like pbr_read_output); -1: top row first (image files).
+__global__ void displayRGBA8( const float4* tiles, uchar4* rows, int width, int height, int tilesX, int tileWorld, int tileRank, int topRowFirst ) {
+	const int x = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
+	const int y = (int) ( blockIdx.y * blockDim.y + threadIdx.y );
+
+	if( x >= width || y >= height ) {
+		return;
+	}
+
+	const int tileGlobal = ( y >> 3 ) * tilesX + ( x >> 3 );
+	float4 v = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+
+	if( tileGlobal % tileWorld == tileRank ) {
+		const int tileLocal = tileGlobal / tileWorld;
+		v = tiles[(size_t) tileLocal * 64 + (size_t) ( ( y & 7 ) * 8 + ( x & 7 ) )];
+	}
+
+	// fmax / fmin drop a NaN operand: NaN -> 0
+	const float r = fmin1( fmax1( v.x, 0.0f ), 1.0f );
+	const float g = fmin1( fmax1( v.y, 0.0f ), 1.0f );
+	const float b = fmin1( fmax1( v.z, 0.0f ), 1.0f );
+	const int outRow = topRowFirst ? ( height - 1 - y ) : y;
+	rows[(size_t) outRow * (size_t) width + (size_t) x] = make_uchar4(
+		(unsigned char) (int) __builtin_floorf( r * 255.0f + 0.5f ),
+		(unsigned char) (int) __builtin_floorf( g * 255.0f + 0.5f ),
+		(unsigned char) (int) __builtin_floorf( b * 255.0f + 0.5f ),
+		255 );
+}
+
 // row-major W x H -> tile-major local tiles
 __global__ void retile( const float4* rows, float4* tiles, int width, int numLocalTiles, int tilesX, int tileWorld, int tileRank ) {
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;

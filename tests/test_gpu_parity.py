@@ -380,6 +380,25 @@ def test_cl_adaptor_driven_like_the_reference(pbr, oracle, gpu_device, cfg):
     assert same_values(debug, ref.debug)
 
 
+def test_display_step_is_the_clamped_linear_image(pbr, device):
+    """pbr_read_display: what shader/pathtracing.frag puts on an 8-bit framebuffer, converted on the device."""
+    sc = make_scene(pbr, **{"render.max_depth": 3})
+    w, h = 72, 40
+    device.upload_scene(sc.desc)
+    device.configure(sc.config(w, h))
+    rng = np.random.default_rng(5)
+    img = rng.uniform(-0.5, 1.5, (h, w, 4)).astype(np.float32)
+    img[3, 5, 0], img[4, 6, 1], img[0, 0, 2] = np.nan, np.inf, -np.inf
+    device.write_input(img)
+    device.render_frame(0.0333, 1.0, pbr.pixel_dimension(w, h), sc.camera())     # weight 1: imageOut ~ the injected image
+    lin = device.read_output()
+    assert np.isnan(lin[3, 5, 0]) and lin[4, 6, 1] == np.inf and (lin[..., :3] > 1.0).any() and (lin[..., :3] < 0.0).any()
+    want = np.floor(np.clip(np.nan_to_num(lin[..., :3], nan=0.0, posinf=1.0, neginf=0.0), 0.0, 1.0).astype(np.float32) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    got = device.read_display()
+    assert np.array_equal(got[..., :3], want) and (got[..., 3] == 255).all()
+    assert np.array_equal(device.read_display(top_row_first=True), got[::-1])
+
+
 # ----------------------------------------------------------------------------------------------
 # error behaviour of the boundary
 # ----------------------------------------------------------------------------------------------
