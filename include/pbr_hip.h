@@ -138,6 +138,15 @@ int pbr_render( pbr_ctx* ctx, uint32_t first_sample_count, uint32_t n_frames, co
 int pbr_read_output( pbr_ctx* ctx, float* rgba );
 int pbr_read_debug( pbr_ctx* ctx, float* rgba );
 
+/* Depth of field with tile sharding.  Every pixel reads the previous-frame distance (.w) of the focus pixel
+ * cam->focusPoint (pathtracing.cl:58-65) — the one cross-pixel dependency of the path — and with tile_world > 1 that
+ * pixel's tile lives on one rank only.  Per frame: every rank calls pbr_get_focus_depth( x, y ); the rank with
+ * *owned = 1 broadcasts *t (one float: ncclBroadcast / MPI_Bcast); every rank passes it to pbr_set_focus_depth and
+ * then calls pbr_render_frame with the same camera.  The value is consumed by that frame.  With tile_world = 1 none of
+ * this is needed (the kernel reads the pixel itself). */
+int pbr_get_focus_depth( pbr_ctx* ctx, int x, int y, float* t, int* owned );
+int pbr_set_focus_depth( pbr_ctx* ctx, float t );
+
 /* The display step the reference leaves to GL (shader/pathtracing.frag:11-15 writes the linear colour to an
  * 8-bit framebuffer): imageOut as width x height RGBA8, each channel floor( clamp( c, 0, 1 ) * 255 + 0.5 ), NaN -> 0,
  * alpha 255, converted on the device (4 B instead of 16 B per pixel over PCIe).  top_row_first = 0: row 0 is the

@@ -98,6 +98,8 @@ hip.pbr_render.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32, _fp, ctypes.c_
 hip.pbr_read_output.argtypes = [_vp, _fp]
 hip.pbr_read_debug.argtypes = [_vp, _fp]
 hip.pbr_read_display.argtypes = [_vp, ctypes.c_void_p, ctypes.c_int]
+hip.pbr_get_focus_depth.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+hip.pbr_set_focus_depth.argtypes = [_vp, ctypes.c_float]
 hip.pbr_read_full.argtypes = [_vp, _fp]
 hip.pbr_get_counters.argtypes = [_vp, ctypes.POINTER(Counters)]
 hip.pbr_last_kernel_ms.argtypes = [_vp]
@@ -324,6 +326,15 @@ class Device:
 
     def read_full(self):
         return self._read(hip.pbr_read_full)
+
+    def get_focus_depth(self, x, y):
+        """(previous-frame distance of pixel (x, y), whether this rank owns its tile) — DOF with tile sharding."""
+        t, owned = ctypes.c_float(), ctypes.c_int()
+        self._check(hip.pbr_get_focus_depth(self._ctx, x, y, ctypes.byref(t), ctypes.byref(owned)))
+        return float(t.value), bool(owned.value)
+
+    def set_focus_depth(self, t):
+        self._check(hip.pbr_set_focus_depth(self._ctx, t))
 
     def read_display(self, top_row_first=False):
         """imageOut as (H, W, 4) uint8 — what the reference's GL viewer shows (clamped linear colour)."""

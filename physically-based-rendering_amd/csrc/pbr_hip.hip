@@ -48,6 +48,8 @@ struct pbr_ctx {
 	float4* dImgDbg = nullptr;
 	float4* dRows = nullptr;       // W x H row-major staging for read-back / write_input
 	float4* dFull = nullptr;       // all tiles of the frame, filled by pbr_import_tiles
+	bool focusGiven = false;       // pbr_set_focus_depth: the focus pixel's previous-frame distance for the next frame
+	float focusDepth = 0.0f;
 	float4* dFrameBuf = nullptr;   // frame-parallel launches: {finalColor, focus} per frame and local pixel slot
 	size_t frameBufFrames = 0;
 	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
@@ -362,8 +364,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	if( dof && nFrames > 1 ) {
 		return fail( ctx, PBR_EINVAL, "depth of field reads the previous frame of another pixel: render one frame per call" );
 	}
-	if( dof && ctx->cfg.tile_world > 1 ) {
-		return fail( ctx, PBR_EINVAL, "depth of field needs the focus pixel's tile on this device (tile_world must be 1)" );
+	if( dof && ctx->cfg.tile_world > 1 && !ctx->focusGiven ) {
+		return fail( ctx, PBR_EINVAL, "depth of field with tile sharding: the focus pixel's tile may live on another rank — pass its previous-frame distance with pbr_set_focus_depth (owner: pbr_get_focus_depth) before every frame" );
 	}
 
 	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
@@ -406,6 +408,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	P.focusX = cam->focusPoint[0];
 	P.focusY = cam->focusPoint[1];
+	P.focusGiven = ( dof && ctx->focusGiven ) ? 1 : 0;
+	P.focusDepth = ctx->focusDepth;
+	ctx->focusGiven = false;   // one frame's worth: the next frame needs the next distance
 	P.lenseFocal = cam->lense[0];
 	P.lenseAperture = cam->lense[1];
 	P.width = (int) ctx->cfg.width;
@@ -1205,6 +1210,43 @@ int pbr_read_output( pbr_ctx* ctx, float* rgba ) {
 		return PBR_EINVAL;
 	}
 	return readTiled( ctx, ctx->dImgOut, rgba, (int) ctx->cfg.tile_world, (int) ctx->cfg.tile_rank );
+}
+
+int pbr_get_focus_depth( pbr_ctx* ctx, int x, int y, float* t, int* owned ) {
+	if( ctx == nullptr || t == nullptr || owned == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "get_focus_depth: null argument" );
+	}
+	if( !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "get_focus_depth before pbr_configure" );
+	}
+
+	// CLAMP_TO_EDGE, as the sampler of getPreviousFocus has it (pathtracing.cl:58-65)
+	const int fx = std::max( 0, std::min( (int) ctx->cfg.width - 1, x ) );
+	const int fy = std::max( 0, std::min( (int) ctx->cfg.height - 1, y ) );
+	const int tile = ( fy >> 3 ) * ctx->tilesX + ( fx >> 3 );
+	*t = 0.0f;
+	*owned = ( tile % (int) ctx->cfg.tile_world == (int) ctx->cfg.tile_rank ) ? 1 : 0;
+
+	if( *owned ) {
+		const size_t slot = (size_t) ( tile / (int) ctx->cfg.tile_world ) * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) );
+		float4 pixel;
+		HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+		HIP_TRY( ctx, hipMemcpyAsync( &pixel, ctx->dImgIn + slot, sizeof( pixel ), hipMemcpyDeviceToHost, ctx->stream ) );
+		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+		*t = pixel.w;
+	}
+
+	return PBR_OK;
+}
+
+int pbr_set_focus_depth( pbr_ctx* ctx, float t ) {
+	if( ctx == nullptr ) {
+		return PBR_EINVAL;
+	}
+
+	ctx->focusGiven = true;
+	ctx->focusDepth = t;
+	return PBR_OK;
 }
 
 int pbr_read_display( pbr_ctx* ctx, uint8_t* rgba8, int top_row_first ) {

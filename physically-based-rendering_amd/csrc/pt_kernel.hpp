@@ -56,6 +56,8 @@ struct DevParams {
 
 	float eye[3], cw[3], cu[3], cv[3];
 	int focusX, focusY;
+	int focusGiven;         // tile sharding: the focus pixel's previous-frame distance comes from the caller (focusDepth) ...
+	float focusDepth;       // ... because its tile may live on another rank (pbr_set_focus_depth)
 	float lenseFocal, lenseAperture;
 
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
@@ -1076,7 +1078,7 @@ PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneC
 		const int fy = ( P.focusY > P.height - 1 ) ? P.height - 1 : P.focusY;
 		const int ft = ( fy >> 3 ) * P.tilesX + ( fx >> 3 );
 		st.tObject = FP ? P.imgIn[slot].w : st.accW;
-		st.tFocus = P.imgIn[(size_t) ft * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) )].w;
+		st.tFocus = P.focusGiven ? P.focusDepth : P.imgIn[(size_t) ft * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) )].w;
 	}
 
 	st.frame = (int) frame;

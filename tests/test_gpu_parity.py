@@ -270,6 +270,41 @@ def test_depth_of_field_frame_by_frame(pbr, oracle, device):
     assert not same_values(plain, ref.image)                       # the lens did something
 
 
+def test_depth_of_field_across_tile_shards(pbr, oracle, gpu_device):
+    """DOF with tile sharding: the focus pixel's tile lives on one rank; its previous-frame distance is handed
+    round per frame (pbr_get_focus_depth on the owner -> broadcast -> pbr_set_focus_depth everywhere)."""
+    sc = make_scene(pbr, **{"render.max_depth": 3})
+    w, h, world = 64, 48, 3
+    cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    cam.focusPoint[0], cam.focusPoint[1] = 37, 22
+    ref = oracle.Renderer(sc.desc, cfg, threads=8)
+    ranks = []
+    for r in range(world):
+        dev = pbr.Device(gpu_device)
+        c = pbr.Config.from_buffer_copy(cfg)
+        c.tile_world, c.tile_rank = world, r
+        dev.upload_scene(sc.desc)
+        dev.configure(c)
+        ranks.append(dev)
+    with pytest.raises(pbr.PbrError, match="pbr_set_focus_depth"):
+        ranks[0].render_frame(0.0333, 0.0, px, cam)
+    for k, seed in enumerate(pbr.frame_seeds(0, 4)):
+        weight = float(np.float32(k) / np.float32(k + 1))
+        ref.image = ref.render_frame(float(seed), weight, px, cam)
+        owners = [dev.get_focus_depth(37, 22) for dev in ranks]
+        assert sum(owned for _, owned in owners) == 1
+        depth = [t for t, owned in owners if owned][0]              # the "broadcast"
+        got = np.zeros((h, w, 4), np.float32)
+        for dev in ranks:
+            dev.set_focus_depth(depth)
+            dev.render_frame(float(seed), weight, px, cam)
+            got += dev.read_output()                                  # other ranks' tiles read 0
+            dev.accumulate()
+        assert same_values(got, ref.image), "frame %d: %s" % (k, describe_mismatch(got, ref.image))
+    for dev in ranks:
+        dev.close()
+
+
 def test_write_input_and_explicit_weights(pbr, oracle, device):
     """CL::updateImageReadOnly + arbitrary pixelWeight: the reference's host ping-pong."""
     sc = make_scene(pbr)
