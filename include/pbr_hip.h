@@ -127,7 +127,8 @@ int pbr_render_frame( pbr_ctx* ctx, float seed, float pixelWeight, float pxDim, 
 int pbr_accumulate( pbr_ctx* ctx );
 
 /* n_frames x { pbr_render_frame( seeds[k], n/(n+1) with n = first_sample_count + k ) ;
- * pbr_accumulate } in ONE launch with the accumulator in registers — bit-identical to the
+ * pbr_accumulate } as one launch over all (pixel, frame) units + one launch that folds the frames into the
+ * running mean in frame order — bit-identical to the
  * frame-by-frame sequence.  Needs cam->focusPoint < 0 (depth of field reads another pixel's
  * previous-frame value, pathtracing.cl:58-65): returns PBR_EINVAL otherwise.  The result is
  * left in imageOut AND imageIn (ready to continue). */
@@ -137,6 +138,17 @@ int pbr_render( pbr_ctx* ctx, uint32_t first_sample_count, uint32_t n_frames, co
  * only this rank's tiles are meaningful (others read 0). */
 int pbr_read_output( pbr_ctx* ctx, float* rgba );
 int pbr_read_debug( pbr_ctx* ctx, float* rgba );
+
+/* Opt-in fast BVH build on the device: a linear BVH (Morton order, binary radix
+ * tree, at most 2 faces per leaf) emitted in the reference's flat format — what BVH::getNodes + the packing loops of
+ * PathTracer::initOpenCLBuffers_BVH / _Faces (PathTracer.cpp:238-352) produce: `nodes_out` in depth-first order with
+ * miss links, `facesV_out` / `facesN_out` = the input faces re-ordered into leaf order.  NOT the reference's builder
+ * (accelstructures/BVH.cpp, replicated on the host in host/bvh_builder.cpp): same format, different tree, so images agree
+ * statistically, not bit for bit.  All pointers are host memory; nodes_out needs pbr_bvh_node_capacity( num_faces ) entries.
+ * pbr_last_kernel_ms then reports the device time of the build. */
+uint32_t pbr_bvh_node_capacity( uint32_t num_faces );
+int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertices, const pbr_uint4* facesV, const pbr_uint4* facesN,
+                   uint32_t num_faces, pbr_bvh_node* nodes_out, uint32_t* num_nodes_out, pbr_uint4* facesV_out, pbr_uint4* facesN_out );
 
 /* Depth of field with tile sharding.  Every pixel reads the previous-frame distance (.w) of the focus pixel
  * cam->focusPoint (pathtracing.cl:58-65) — the one cross-pixel dependency of the path — and with tile_world > 1 that

@@ -98,6 +98,9 @@ hip.pbr_render.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32, _fp, ctypes.c_
 hip.pbr_read_output.argtypes = [_vp, _fp]
 hip.pbr_read_debug.argtypes = [_vp, _fp]
 hip.pbr_read_display.argtypes = [_vp, ctypes.c_void_p, ctypes.c_int]
+hip.pbr_bvh_node_capacity.argtypes = [ctypes.c_uint32]
+hip.pbr_bvh_node_capacity.restype = ctypes.c_uint32
+hip.pbr_build_bvh.argtypes = [_vp, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p, ctypes.c_void_p]
 hip.pbr_get_focus_depth.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
 hip.pbr_set_focus_depth.argtypes = [_vp, ctypes.c_float]
 hip.pbr_read_full.argtypes = [_vp, _fp]
@@ -254,6 +257,8 @@ class HostScene:
         return {
             "bvh": self._array(d.bvh, d.num_nodes, np.float32, 8),
             "facesV": self._array(d.facesV, d.num_faces, np.uint32, 4),
+            "facesN": self._array(d.facesN, d.num_faces, np.uint32, 4),
+            "normals": self._array(d.normals, d.num_normals, np.float32, 4),
             "vertices": self._array(d.vertices, d.num_vertices, np.float32, 4),
             "materials": self._array(d.materials, d.num_materials, np.float32, mat_floats),
             "lights": self._array(d.lights, max(1, d.num_lights), np.float32, 12),
@@ -326,6 +331,20 @@ class Device:
 
     def read_full(self):
         return self._read(hip.pbr_read_full)
+
+    def build_bvh(self, vertices, facesV, facesN):
+        """pbr_build_bvh: linear BVH on the device.  vertices (n, 4) float32, facesV / facesN (m, 4) uint32 ->
+        (nodes (k, 8) float32 in the reference's flat format, facesV and facesN in leaf order)."""
+        vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 4)
+        facesV = np.ascontiguousarray(facesV, np.uint32).reshape(-1, 4)
+        facesN = np.ascontiguousarray(facesN, np.uint32).reshape(-1, 4)
+        m = facesV.shape[0]
+        nodes = np.zeros((int(hip.pbr_bvh_node_capacity(m)), 8), np.float32)
+        outV, outN = np.empty_like(facesV), np.empty_like(facesN)
+        count = ctypes.c_uint32()
+        self._check(hip.pbr_build_bvh(self._ctx, vertices.ctypes.data, vertices.shape[0], facesV.ctypes.data, facesN.ctypes.data, m,
+                                      nodes.ctypes.data, ctypes.byref(count), outV.ctypes.data, outN.ctypes.data))
+        return nodes[:count.value].copy(), outV, outN
 
     def get_focus_depth(self, x, y):
         """(previous-frame distance of pixel (x, y), whether this rank owns its tile) — DOF with tile sharding."""

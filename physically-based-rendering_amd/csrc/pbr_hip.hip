@@ -16,6 +16,7 @@
 #include "pbr_hip_diag.h"
 #include "pt_kernel.hpp"
 #include "pt_wavefront.hpp"
+#include "bvh_build.hpp"
 
 using ptk::DevParams;
 using ptk::WfParams;
@@ -1381,6 +1382,129 @@ DevParams sceneParams( pbr_ctx* ctx ) {
 }
 
 }  // namespace
+
+uint32_t pbr_bvh_node_capacity( uint32_t num_faces ) {
+	const uint32_t leaves = ( num_faces + 1 ) / 2;
+	return ( leaves < 2 ) ? 2u : 2u * leaves - 1u;
+}
+
+// Linear BVH on the device (csrc/bvh_build.hpp): Morton keys, radix sort, binary radix tree, bottom-up boxes,
+// depth-first flattening into the reference's node format.
+int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertices, const pbr_uint4* facesV, const pbr_uint4* facesN,
+                   uint32_t num_faces, pbr_bvh_node* nodes_out, uint32_t* num_nodes_out, pbr_uint4* facesV_out, pbr_uint4* facesN_out ) {
+	if( ctx == nullptr || ctx->stream == nullptr ) {
+		return PBR_EINVAL;
+	}
+	if( vertices == nullptr || facesV == nullptr || facesN == nullptr || nodes_out == nullptr || num_nodes_out == nullptr || facesV_out == nullptr || facesN_out == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "build_bvh: null argument" );
+	}
+	if( num_faces == 0 || num_vertices == 0 || num_faces > ( 1u << 24 ) ) {
+		return fail( ctx, PBR_EINVAL, "build_bvh: needs 1 .. 2^24 faces and at least one vertex" );
+	}
+
+	for( uint32_t f = 0; f < num_faces; f++ ) {
+		if( facesV[f].x >= num_vertices || facesV[f].y >= num_vertices || facesV[f].z >= num_vertices ) {
+			return fail( ctx, PBR_EINVAL, "build_bvh: face %u: vertex index out of range", f );
+		}
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	const uint32_t leaves = ( num_faces + 1 ) / 2;
+	const uint32_t treeNodes = 2 * leaves - 1;
+	DevBuf dVertices, dFacesV, dFacesN, dKeys, dKeysSorted, dBounds, dLeft, dRight, dParent, dSize, dArrived, dBoxMin, dBoxMax, dNodes, dFacesVOut, dFacesNOut, dTemp;
+	HIP_TRY( ctx, dVertices.alloc( sizeof( pbr_float4 ) * num_vertices ) );
+	HIP_TRY( ctx, dFacesV.alloc( sizeof( pbr_uint4 ) * num_faces ) );
+	HIP_TRY( ctx, dFacesN.alloc( sizeof( pbr_uint4 ) * num_faces ) );
+	HIP_TRY( ctx, dKeys.alloc( sizeof( unsigned long long ) * num_faces ) );
+	HIP_TRY( ctx, dKeysSorted.alloc( sizeof( unsigned long long ) * num_faces ) );
+	HIP_TRY( ctx, dBounds.alloc( sizeof( float ) * 8 ) );
+	HIP_TRY( ctx, dLeft.alloc( sizeof( int ) * treeNodes ) );
+	HIP_TRY( ctx, dRight.alloc( sizeof( int ) * treeNodes ) );
+	HIP_TRY( ctx, dParent.alloc( sizeof( int ) * treeNodes ) );
+	HIP_TRY( ctx, dSize.alloc( sizeof( unsigned ) * treeNodes ) );
+	HIP_TRY( ctx, dArrived.alloc( sizeof( unsigned ) * treeNodes ) );
+	HIP_TRY( ctx, dBoxMin.alloc( sizeof( float4 ) * treeNodes ) );
+	HIP_TRY( ctx, dBoxMax.alloc( sizeof( float4 ) * treeNodes ) );
+	HIP_TRY( ctx, dNodes.alloc( sizeof( pbr_bvh_node ) * treeNodes ) );
+	HIP_TRY( ctx, dFacesVOut.alloc( sizeof( pbr_uint4 ) * num_faces ) );
+	HIP_TRY( ctx, dFacesNOut.alloc( sizeof( pbr_uint4 ) * num_faces ) );
+
+	HIP_TRY( ctx, hipMemcpyAsync( dVertices.p, vertices, sizeof( pbr_float4 ) * num_vertices, hipMemcpyHostToDevice, ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpyAsync( dFacesV.p, facesV, sizeof( pbr_uint4 ) * num_faces, hipMemcpyHostToDevice, ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpyAsync( dFacesN.p, facesN, sizeof( pbr_uint4 ) * num_faces, hipMemcpyHostToDevice, ctx->stream ) );
+	// order-preserving unsigned images of +inf (minima) and -inf (maxima), see ptb::atomicMinFloat
+	const unsigned bounds[8] = { 0xFF800000u, 0xFF800000u, 0xFF800000u, 0u, 0x007FFFFFu, 0x007FFFFFu, 0x007FFFFFu, 0u };
+	HIP_TRY( ctx, hipMemcpyAsync( dBounds.p, bounds, sizeof( bounds ), hipMemcpyHostToDevice, ctx->stream ) );
+	HIP_TRY( ctx, hipMemsetAsync( dParent.p, 0xFF, sizeof( int ) * treeNodes, ctx->stream ) );
+	HIP_TRY( ctx, hipMemsetAsync( dArrived.p, 0, sizeof( unsigned ) * treeNodes, ctx->stream ) );
+
+	ptb::BuildArrays B;
+	B.vertices = (const pbr_float4*) dVertices.p;
+	B.facesV = (const pbr_uint4*) dFacesV.p;
+	B.facesN = (const pbr_uint4*) dFacesN.p;
+	B.numFaces = num_faces;
+	B.numLeaves = leaves;
+	B.keys = (unsigned long long*) dKeys.p;
+	B.keysSorted = (unsigned long long*) dKeysSorted.p;
+	B.sceneMin = (float*) dBounds.p;
+	B.sceneMax = (float*) dBounds.p + 4;
+	B.left = (int*) dLeft.p;
+	B.right = (int*) dRight.p;
+	B.parent = (int*) dParent.p;
+	B.size = (unsigned*) dSize.p;
+	B.arrived = (unsigned*) dArrived.p;
+	B.boxMin = (float4*) dBoxMin.p;
+	B.boxMax = (float4*) dBoxMax.p;
+	B.nodesOut = (pbr_bvh_node*) dNodes.p;
+	B.facesVOut = (pbr_uint4*) dFacesVOut.p;
+	B.facesNOut = (pbr_uint4*) dFacesNOut.p;
+
+	const unsigned threads = 256;
+	const unsigned faceBlocks = ( num_faces + threads - 1 ) / threads;
+	const unsigned leafBlocks = ( leaves + threads - 1 ) / threads;
+	const unsigned nodeBlocks = ( treeNodes + threads - 1 ) / threads;
+
+	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
+	hipLaunchKernelGGL( ptb::centroidBounds, dim3( faceBlocks ), dim3( threads ), 0, ctx->stream, B );
+	hipLaunchKernelGGL( ptb::mortonKeys, dim3( faceBlocks ), dim3( threads ), 0, ctx->stream, B );
+	HIP_TRY( ctx, hipGetLastError() );
+
+	size_t tempBytes = 0;
+	HIP_TRY( ctx, hipcub::DeviceRadixSort::SortKeys( nullptr, tempBytes, B.keys, B.keysSorted, (int) num_faces, 0, 62, ctx->stream ) );
+	HIP_TRY( ctx, dTemp.alloc( tempBytes ) );
+	HIP_TRY( ctx, hipcub::DeviceRadixSort::SortKeys( dTemp.p, tempBytes, B.keys, B.keysSorted, (int) num_faces, 0, 62, ctx->stream ) );
+
+	if( leaves > 1 ) {
+		hipLaunchKernelGGL( ptb::radixTree, dim3( leafBlocks ), dim3( threads ), 0, ctx->stream, B );
+	}
+
+	hipLaunchKernelGGL( ptb::boxesBottomUp, dim3( leafBlocks ), dim3( threads ), 0, ctx->stream, B );
+	hipLaunchKernelGGL( ptb::flatten, dim3( nodeBlocks ), dim3( threads ), 0, ctx->stream, B );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
+
+	// a single leaf has no container above it, but the walk starts at node 1 (pt_bvh.cl:84): give it a root
+	pbr_bvh_node* firstTreeNode = ( leaves == 1 ) ? nodes_out + 1 : nodes_out;
+	HIP_TRY( ctx, hipMemcpyAsync( firstTreeNode, dNodes.p, sizeof( pbr_bvh_node ) * treeNodes, hipMemcpyDeviceToHost, ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpyAsync( facesV_out, dFacesVOut.p, sizeof( pbr_uint4 ) * num_faces, hipMemcpyDeviceToHost, ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpyAsync( facesN_out, dFacesNOut.p, sizeof( pbr_uint4 ) * num_faces, hipMemcpyDeviceToHost, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+
+	if( leaves == 1 ) {
+		nodes_out[0] = nodes_out[1];
+		nodes_out[0].bbMin.w = -1.0f;
+		nodes_out[0].bbMax.w = -1.0f;
+		*num_nodes_out = 2;
+	}
+	else {
+		*num_nodes_out = treeNodes;
+	}
+
+	float ms = 0.0f;
+	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
+	ctx->lastKernelMs = (double) ms;
+	return PBR_OK;
+}
 
 int pbr_diag_math( pbr_ctx* ctx, int op, const float* x, const float* y, int n, float* out ) {
 	if( ctx == nullptr || ctx->stream == nullptr || x == nullptr || out == nullptr || n <= 0 ) {

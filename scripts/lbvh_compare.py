@@ -1,0 +1,34 @@
+"""Device-built linear BVH vs the host replica of the reference's builder: build time and render rate.
+usage: python scripts/lbvh_compare.py [scene ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pbr_loader
+pbr = pbr_loader.load()
+SCENES = {"cornell": ("cornell", 1, 0, 8), "sponza": ("sponza", 2, 260000, 3), "dragon": ("dragon", 1, 870000, 3), "hairball": ("hairball", 3, 2000000, 3)}
+W, H, FRAMES = 1920, 1080, 16
+for name in (sys.argv[1:] or ["sponza", "dragon", "hairball"]):
+    kind, seed, tris, depth = SCENES[name]
+    pbr.cfg_reset(); pbr.cfg_set(**{"render.max_depth": depth})
+    t0 = time.perf_counter(); sc = pbr.HostScene.generate(kind, seed, tris); host_s = time.perf_counter() - t0
+    arr = sc.arrays()
+    dev = pbr.Device(0)
+    t0 = time.perf_counter(); nodes, fv, fn = dev.build_bvh(arr["vertices"], arr["facesV"], arr["facesN"]); wall = time.perf_counter() - t0
+    build_ms = dev.last_kernel_ms()
+    cfg, cam, px = sc.config(W, H), sc.camera(), pbr.pixel_dimension(W, H)
+    rates = {}
+    for label, desc in (("host SAH replica", sc.desc), ("device LBVH", None)):
+        if desc is None:
+            desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
+            desc.bvh, desc.num_nodes, desc.facesV, desc.facesN = nodes.ctypes.data, nodes.shape[0], fv.ctypes.data, fn.ctypes.data
+        dev.upload_scene(desc); dev.configure(cfg)
+        dev.render(0, pbr.frame_seeds(0, 72), px, cam)
+        dev.reset_accum(); c0 = dev.counters()
+        dev.render(0, pbr.frame_seeds(0, FRAMES), px, cam)
+        c1 = dev.counters(); ms = dev.last_kernel_ms()
+        rates[label] = (W * H * FRAMES / ms / 1e3, (c1["nodes"] - c0["nodes"]) / (W * H * FRAMES), dev.last_plan()[0])
+    print("%-9s %8d faces: host build (scene generation + SAH replica) %.1f s; device LBVH %.2f ms on the device, %.0f ms with transfers, %d nodes" % (
+        name, arr["facesV"].shape[0], host_s, build_ms, wall * 1e3, nodes.shape[0]))
+    for label, (rate, visits, plan) in rates.items():
+        print("    %-18s %8.1f Msamples/s  %6.1f node visits/sample  (%s)" % (label, rate, visits, plan))
+    dev.close()

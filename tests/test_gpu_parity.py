@@ -415,6 +415,89 @@ def test_cl_adaptor_driven_like_the_reference(pbr, oracle, gpu_device, cfg):
     assert same_values(debug, ref.debug)
 
 
+def check_flat_tree(nodes, facesV_out, facesV_in, vertices):
+    """Structural invariants of the reference's flat format for a tree with <= 2 faces per leaf."""
+    n = nodes.shape[0]
+    leaf = nodes[:, 3] >= 0
+    assert not leaf[0] and nodes[0, 3] == -1
+    # every face exactly once, in leaf order
+    first = nodes[leaf, 3].astype(np.int64)
+    second = nodes[leaf, 7].astype(np.int64)
+    assert ((second == -1) | (second == first + 1)).all()
+    covered = np.sort(np.concatenate([first, second[second >= 0]]))
+    assert np.array_equal(covered, np.arange(facesV_in.shape[0]))
+    key = lambda f: np.sort(f.view([("", f.dtype)] * 4).ravel())
+    assert np.array_equal(key(np.ascontiguousarray(facesV_out)), key(np.ascontiguousarray(facesV_in)))      # a permutation of the input
+    # depth-first order: a container's subtree is [i + 1, end) with end = its miss link, or the enclosing end
+    end = np.empty(n, np.int64)
+    stack = [n]
+    for i in range(n):
+        while stack and i >= stack[-1]:
+            stack.pop()
+        enclosing = stack[-1] if stack else n
+        if leaf[i]:
+            end[i] = i + 1
+        else:
+            link = int(nodes[i, 7])
+            assert link == -1 or i + 1 < link <= n
+            end[i] = link if link != -1 else enclosing
+            assert end[i] <= enclosing
+            stack.append(end[i])
+    # boxes: a leaf's box is the exact bound of its faces, a container's the bound of its subtree's leaves
+    tri = vertices[facesV_out[:, :3].astype(np.int64), :3]                    # (m, 3, 3)
+    flo, fhi = tri.min(1), tri.max(1)
+    for i in np.nonzero(leaf)[0][:4000]:
+        f0, f1 = int(nodes[i, 3]), int(nodes[i, 7])
+        lo, hi = flo[f0], fhi[f0]
+        if f1 >= 0:
+            lo, hi = np.minimum(lo, flo[f1]), np.maximum(hi, fhi[f1])
+        assert np.array_equal(nodes[i, 0:3], lo) and np.array_equal(nodes[i, 4:7], hi)
+    for i in np.nonzero(~leaf)[0][1:2000]:
+        sub = np.arange(i + 1, end[i])
+        sub = sub[leaf[sub]]
+        assert np.array_equal(nodes[i, 0:3], nodes[sub, 0:3].min(0)) and np.array_equal(nodes[i, 4:7], nodes[sub, 4:7].max(0))
+
+
+@pytest.mark.parametrize("kind,triangles", [("cornell", 0), ("sponza", 6000), ("hairball", 30001)])
+def test_device_bvh_build_emits_the_reference_format(pbr, oracle, device, kind, triangles):
+    """pbr_build_bvh: the linear BVH built on the device is a valid tree in the reference's flat format
+    (structure, exact boxes, every face once); HIP and oracle agree bit for bit when both walk it; and the
+    hits are the geometric closest hits (brute force)."""
+    sc = make_scene(pbr, kind, 5, triangles, **{"render.max_depth": 3})
+    arr = sc.arrays()
+    nodes, fv, fn = device.build_bvh(arr["vertices"], arr["facesV"], arr["facesN"])
+    check_flat_tree(nodes, fv, arr["facesV"], arr["vertices"])
+    again, fv2, _ = device.build_bvh(arr["vertices"], arr["facesV"], arr["facesN"])
+    assert np.array_equal(again, nodes) and np.array_equal(fv2, fv)            # deterministic
+    desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    desc.bvh, desc.num_nodes = nodes.ctypes.data, nodes.shape[0]
+    desc.facesV, desc.facesN = fv.ctypes.data, fn.ctypes.data
+    got, want, ref = both_render(pbr, oracle, device, sc, 64, 40, 3, desc=desc)
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert device.counters() == ref.counter_dict()
+    # closest hits against brute force over all triangles
+    rng = np.random.default_rng(3)
+    v = arr["vertices"][:, :3]
+    rays = np.zeros((300, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(v.min(0), v.max(0), (300, 3))
+    d = rng.normal(size=(300, 3)); rays[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    t, face, _, _ = device.diag_trace(rays)
+    tri = v[fv[:, :3].astype(np.int64)].astype(np.float64)
+    a, e1, e2 = tri[:, 0], tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    for k in range(rays.shape[0]):
+        o, dd = rays[k, 0:3].astype(np.float64), rays[k, 3:6].astype(np.float64)
+        p = np.cross(dd, e2); det = (e1 * p).sum(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / det
+            tv = o - a; u = (tv * p).sum(1) * inv
+            q = np.cross(tv, e1); vv = (q * dd).sum(1) * inv
+            tt = (e2 * q).sum(1) * inv
+        ok = (u >= -1e-6) & (vv >= -1e-6) & (u + vv <= 1 + 1e-6) & (tt > 1e-4) & np.isfinite(tt)
+        best = tt[ok].min() if ok.any() else np.inf
+        if np.isfinite(best) or np.isfinite(t[k]):
+            assert abs(float(t[k]) - best) <= 1e-3 * max(1.0, best), (k, float(t[k]), best)
+
+
 def test_display_step_is_the_clamped_linear_image(pbr, device):
     """pbr_read_display: what shader/pathtracing.frag puts on an 8-bit framebuffer, converted on the device."""
     sc = make_scene(pbr, **{"render.max_depth": 3})
