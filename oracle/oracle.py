@@ -32,7 +32,7 @@ class OrcConfig(ctypes.Structure):
         ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("brdf", ctypes.c_int32),
         ("shadow_rays", ctypes.c_int32), ("max_depth", ctypes.c_int32), ("max_added_depth", ctypes.c_int32),
         ("samples", ctypes.c_int32), ("num_nodes", ctypes.c_int32), ("num_lights", ctypes.c_int32),
-        ("anti_aliasing", ctypes.c_float), ("sky_light", ctypes.c_float * 4),
+        ("anti_aliasing", ctypes.c_float), ("sky_light", ctypes.c_float * 4), ("phong_tessellation", ctypes.c_float),
     ]
 
 
@@ -41,6 +41,7 @@ class OrcScene(ctypes.Structure):
         ("bvh", ctypes.c_void_p), ("facesV", ctypes.c_void_p), ("vertices", ctypes.c_void_p),
         ("materials", ctypes.c_void_p), ("lights", ctypes.c_void_p),
         ("num_faces", ctypes.c_uint32), ("num_vertices", ctypes.c_uint32), ("num_materials", ctypes.c_uint32),
+        ("facesN", ctypes.c_void_p), ("normals", ctypes.c_void_p), ("num_normals", ctypes.c_uint32),
     ]
 
 
@@ -99,11 +100,13 @@ def scene_and_config(desc, cfg):
     s = OrcScene()
     s.bvh, s.facesV, s.vertices, s.materials, s.lights = desc.bvh, desc.facesV, desc.vertices, desc.materials, desc.lights
     s.num_faces, s.num_vertices, s.num_materials = desc.num_faces, desc.num_vertices, desc.num_materials
+    s.facesN, s.normals, s.num_normals = desc.facesN, desc.normals, desc.num_normals
     c = OrcConfig()
     c.width, c.height, c.brdf = cfg.width, cfg.height, cfg.brdf
     c.shadow_rays, c.max_depth, c.max_added_depth, c.samples = cfg.shadow_rays, cfg.max_depth, cfg.max_added_depth, cfg.samples
     c.num_nodes, c.num_lights = desc.num_nodes, desc.num_lights
     c.anti_aliasing = cfg.anti_aliasing
+    c.phong_tessellation = getattr(cfg, "phong_tessellation", 0.0)
     for k in range(4):
         c.sky_light[k] = cfg.sky_light[k]
     return s, c

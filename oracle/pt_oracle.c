@@ -5,9 +5,8 @@
  *
  * Follows /root/reference/source/opencl/{pathtracing,pt_utils,pt_rgb,pt_brdf,
  * pt_intersect,pt_bvh}.cl one function at a time; every function cites the
- * file:line it restates.  Phong tessellation (pt_phongtess.cl, PHONGTESS=1) is
- * not restated: the reference's default config never compiles it in
- * (config.json:105) and its own CHANGELOG calls it buggy.
+ * file:line it restates, pt_phongtess.cl (PHONGTESS=1, off in the reference's
+ * config.json:105) included.
  *
  * Build: gcc -O2 -std=c11 -ffp-contract=off -mfma -fopenmp -shared -fPIC
  */
@@ -45,6 +44,7 @@
  *   native_tan           = det_sin / det_cos
  *   acos, atan           = single-precision minimax forms below (<= 4 / <= 5 ulp)
  *   pow                  = exp2(y * log2(x)) evaluated in binary64 (<= 1 ulp)
+ *   cbrt                 = sign(x) * exp2(log2(|x|) / 3) evaluated in binary64 (<= 1 ulp)
  * Double-typed literals in the reference (M_PI, M_PI_2, M_1_PI: the kernels were
  * written for a device with cl_khr_fp64) promote the surrounding expression to
  * binary64 exactly as C does; the result is rounded once where the reference
@@ -246,6 +246,17 @@ static float det_pow( float x, float y ) {
 	t = ( t < -160.0 ) ? -160.0 : t;
 
 	return sign * (float) det_exp2_d( t );
+}
+
+/* cbrt (solveCubic, pt_utils.cl:153): through the binary64 log2 / exp2 of det_pow */
+static float det_cbrt( float x ) {
+	const float ax = fabsf( x );
+
+	if( x != x || ax == 0.0f || ax == ORC_INF ) {
+		return x;
+	}
+
+	return copysignf( (float) det_exp2_d( det_log2_d( (double) ax ) / 3.0 ), x );
 }
 
 static inline float det_fract( float x ) {
@@ -798,12 +809,272 @@ static v3 flatTriAndRayIntersect( v3 a, v3 b, v3 c, const ray4* ray, float* t, f
 	return v3_normalize( v3_cross( edge1, edge2 ) );
 }
 
-/* checkFaceIntersection, pt_intersect.cl:142-176 (PHONGTESS == 0) */
-static v3 checkFaceIntersection( const ctx_t* c, const ray4* ray, int fIndex, float* t, float tNear ) {
+/* ------------------------------------------------------------------------- */
+/* pt_phongtess.cl + its helpers in pt_utils.cl (PHONGTESS == 1)              */
+/* ------------------------------------------------------------------------- */
+
+/* solveCubic, pt_utils.cl:108-199: a0 x^3 + a1 x^2 + a2 x + a3 = 0, returns the number of real roots in x[] */
+static int solveCubic( float a0, float a1, float a2, float a3, float x[3] ) {
+	const float THIRD = 0.3333333333f;
+	const float THIRD_HALF = 0.1666666666f;
+	float w, p, q, dis, phi;
+
+	if( fabsf( a0 ) > 0.0f ) {
+		w = det_div( a1, a0 ) * THIRD;
+		p = det_div( a2, a0 ) * THIRD - w * w;
+		p = p * p * p;
+		q = 0.5f * det_div( a2 * w - a3, a0 ) - w * w * w;
+		dis = q * q + p;
+
+		if( dis < 0.0f ) {
+			phi = det_acos( det_clamp( det_div( q, det_sqrt( -p ) ), -1.0f, 1.0f ) );
+			p = 2.0f * det_pow( -p, THIRD_HALF );
+
+			/* ( phi + 2.0f * M_PI ) * THIRD: M_PI is a double literal, the sum and product are binary64 */
+			const float u[3] = {
+				p * det_cos( phi * THIRD ) - w,
+				p * det_cos( (float) ( ( (double) phi + (double) 2.0f * M_PI_D ) * (double) THIRD ) ) - w,
+				p * det_cos( (float) ( ( (double) phi + (double) 4.0f * M_PI_D ) * (double) THIRD ) ) - w
+			};
+
+			x[0] = fminf( u[0], fminf( u[1], u[2] ) );
+			x[1] = fmaxf( fminf( u[0], u[1] ), fmaxf( fminf( u[0], u[2] ), fminf( u[1], u[2] ) ) );
+			x[2] = fmaxf( u[0], fmaxf( u[1], u[2] ) );
+
+			for( int k = 0; k < 3; k++ ) {
+				x[k] -= det_div(
+					a3 + x[k] * ( a2 + x[k] * ( a1 + x[k] * a0 ) ),
+					a2 + x[k] * ( 2.0f * a1 + x[k] * 3.0f * a0 )
+				);
+			}
+
+			return 3;
+		}
+
+		dis = det_sqrt( dis );
+		x[0] = det_cbrt( q + dis ) + det_cbrt( q - dis ) - w;
+		x[0] -= det_div(
+			a3 + x[0] * ( a2 + x[0] * ( a1 + x[0] * a0 ) ),
+			a2 + x[0] * ( 2.0f * a1 + x[0] * 3.0f * a0 )
+		);
+
+		return 1;
+	}
+	else if( fabsf( a1 ) > 0.0f ) {
+		p = 0.5f * det_div( a2, a1 );
+		dis = p * p - det_div( a3, a1 );
+
+		if( dis >= 0.0f ) {
+			const float dis_sqrt = det_sqrt( dis );
+			x[0] = -p - dis_sqrt;
+			x[1] = -p + dis_sqrt;
+			x[0] -= det_div( a3 + x[0] * ( a2 + x[0] * a1 ), a2 + x[0] * 2.0f * a1 );
+			x[1] -= det_div( a3 + x[1] * ( a2 + x[1] * a1 ), a2 + x[1] * 2.0f * a1 );
+			return 2;
+		}
+	}
+	else if( fabsf( a2 ) > 0.0f ) {
+		x[0] = det_div( -a3, a2 );
+		return 1;
+	}
+
+	return 0;
+}
+
+/* projectOnPlane, pt_utils.cl:397-399 */
+static inline v3 projectOnPlane( v3 q, v3 p, v3 n ) {
+	return v3_sub( q, v3_scale( n, v3_dot( v3_sub( q, p ), n ) ) );
+}
+
+/* phongTessellation, pt_phongtess.cl:14-26 */
+static v3 phongTessellation( v3 P1, v3 P2, v3 P3, v3 N1, v3 N2, v3 N3, float u, float v, float w, float alpha ) {
+	const v3 pBary = v3_add( v3_add( v3_scale( P1, u ), v3_scale( P2, v ) ), v3_scale( P3, w ) );
+	const v3 pTessellated = v3_add(
+		v3_add( v3_scale( projectOnPlane( pBary, P1, N1 ), u ), v3_scale( projectOnPlane( pBary, P2, N2 ), v ) ),
+		v3_scale( projectOnPlane( pBary, P3, N3 ), w )
+	);
+
+	return v3_add( v3_scale( pBary, 1.0f - alpha ), v3_scale( pTessellated, alpha ) );
+}
+
+/* getTriangleNormalS / getTriangleNormal / getTriangleReflectionVec / getPhongTessNormal, pt_utils.cl:231-294 */
+static v3 getPhongTessNormal(
+	v3 an, v3 bn, v3 cn, v3 rayDir, float u, float v, float w, v3 C1, v3 C2, v3 C3, v3 E12, v3 E20
+) {
+	const v3 du = v3_add( v3_add( v3_scale( C3, w - u ), v3_scale( v3_sub( C1, C2 ), v ) ), E20 );
+	const v3 dv = v3_sub( v3_add( v3_scale( C2, w - v ), v3_scale( v3_sub( C1, C3 ), u ) ), E12 );
+	const v3 ns = v3_normalize( v3_cross( du, dv ) );
+	const v3 np = v3_normalize( v3_add( v3_add( v3_scale( an, u ), v3_scale( bn, v ) ), v3_scale( cn, w ) ) );
+	const v3 r = v3_sub( rayDir, v3_scale( v3_scale( np, 2.0f ), v3_dot( rayDir, np ) ) );
+
+	return ( v3_dot( ns, r ) < 0.0f ) ? ns : np;
+}
+
+/* phongTessTriAndRayIntersect, pt_phongtess.cl:56-212 (after Ogaki & Tokuyoshi, "Direct Ray Tracing of Phong
+ * Tessellation"); getPlanesFromRay (pt_utils.cl:208-218) and getBestRayDomain (pt_phongtess.cl:35-44) inlined */
+static v3 phongTessTriAndRayIntersect(
+	v3 P1, v3 P2, v3 P3, v3 N1, v3 N2, v3 N3, const ray4* ray, float* t, float tNear, float tFar, float alpha
+) {
+	v3 normal = V3( 0.0f, 0.0f, 0.0f );
+	*t = ORC_INF;
+
+	const v3 E01 = v3_sub( P2, P1 );
+	const v3 E12 = v3_sub( P3, P2 );
+	const v3 E20 = v3_sub( P1, P3 );
+	const v3 C1 = v3_scale( v3_sub( v3_scale( N2, v3_dot( N2, E01 ) ), v3_scale( N1, v3_dot( N1, E01 ) ) ), alpha );
+	const v3 C2 = v3_scale( v3_sub( v3_scale( N3, v3_dot( N3, E12 ) ), v3_scale( N2, v3_dot( N2, E12 ) ) ), alpha );
+	const v3 C3 = v3_scale( v3_sub( v3_scale( N1, v3_dot( N1, E20 ) ), v3_scale( N3, v3_dot( N3, E20 ) ) ), alpha );
+
+	const v3 n1 = v3_normalize( v3_cross( ray->origin, ray->dir ) );
+	const v3 n2 = v3_normalize( v3_cross( n1, ray->dir ) );
+	const float o1 = v3_dot( n1, ray->origin );
+	const float o2 = v3_dot( n2, ray->origin );
+	const v3 C123 = v3_sub( v3_sub( C1, C2 ), C3 );
+
+	const float a = v3_dot( v3_neg( n1 ), C3 );
+	const float b = v3_dot( v3_neg( n1 ), C2 );
+	const float c = v3_dot( n1, P3 ) - o1;
+	const float d = v3_dot( n1, C123 ) * 0.5f;
+	const float e = v3_dot( n1, v3_add( C3, E20 ) ) * 0.5f;
+	const float f = v3_dot( n1, v3_sub( C2, E12 ) ) * 0.5f;
+	const float l = v3_dot( v3_neg( n2 ), C3 );
+	const float m = v3_dot( v3_neg( n2 ), C2 );
+	const float n = v3_dot( n2, P3 ) - o2;
+	const float o = v3_dot( n2, C123 ) * 0.5f;
+	const float p = v3_dot( n2, v3_add( C3, E20 ) ) * 0.5f;
+	const float q = v3_dot( n2, v3_sub( C2, E12 ) ) * 0.5f;
+
+	float xs[3] = { -1.0f, -1.0f, -1.0f };
+	const float a3 = ( l*m*n + 2.0f*o*p*q ) - ( l*q*q + m*p*p + n*o*o );
+	const float a2 = ( a*m*n + l*b*n + l*m*c + 2.0f*( d*p*q + o*e*q + o*p*f ) ) -
+	                 ( a*q*q + b*p*p + c*o*o + 2.0f*( l*f*q + m*e*p + n*d*o ) );
+	const float a1 = ( a*b*n + a*m*c + l*b*c + 2.0f*( o*e*f + d*e*q + d*p*f ) ) -
+	                 ( l*f*f + m*e*e + n*d*d + 2.0f*( a*f*q + b*e*p + c*d*o ) );
+	const float a0 = ( a*b*c + 2.0f*d*e*f ) - ( a*f*f + b*e*e + c*d*d );
+	const int numCubicRoots = solveCubic( a0, a1, a2, a3, xs );
+
+	if( numCubicRoots == 0 ) {
+		return normal;
+	}
+
+	float x = 0.0f;
+	float determinant = ORC_INF;
+	float mA, mB, mC, mD, mE, mF;
+
+	for( int i = 0; i < numCubicRoots; i++ ) {
+		mA = a * xs[i] + l;
+		mB = b * xs[i] + m;
+		mD = d * xs[i] + o;
+		const float tmp = mD * mD - mA * mB;
+		x = ( determinant > tmp ) ? xs[i] : x;
+		determinant = fminf( determinant, tmp );
+	}
+
+	if( 0.0f >= determinant ) {
+		return normal;
+	}
+
+	const v3 ad = V3( fabsf( ray->dir.x ), fabsf( ray->dir.y ), fabsf( ray->dir.z ) );
+	int domain = ( ad.y > ad.z ) ? 1 : 2;
+
+	if( ad.x > ad.y ) {
+		domain = ( ad.x > ad.z ) ? 0 : 2;
+	}
+
+	mA = a * x + l;
+	mB = b * x + m;
+	mC = c * x + n;
+	mD = d * x + o;
+	mE = e * x + p;
+	mF = f * x + q;
+
+	const int AlessB = fabsf( mA ) < fabsf( mB );
+	const float mBorA = AlessB ? mB : mA;
+	mA = det_div( mA, mBorA );
+	mB = det_div( mB, mBorA );
+	mC = det_div( mC, mBorA );
+	mD = det_div( mD, mBorA );
+	mE = det_div( mE, mBorA );
+	mF = det_div( mF, mBorA );
+
+	const float mAorB = AlessB ? mA : mB;
+	const float mEorF = AlessB ? 2.0f * mE : 2.0f * mF;
+	const float mForE = AlessB ? mF : mE;
+	const float ab = AlessB ? a : b;
+	const float ba = AlessB ? b : a;
+	const float ef = AlessB ? e : f;
+	const float fe = AlessB ? f : e;
+
+	const float sqrtAorB = det_sqrt( mD * mD - mAorB );
+	const float sqrtC = det_sqrt( mForE * mForE - mC );
+	const float lab1 = mD + sqrtAorB;
+	const float lab2 = mD - sqrtAorB;
+	float lc1 = mForE + sqrtC;
+	float lc2 = mForE - sqrtC;
+
+	if( fabsf( mEorF - lab1 * lc1 - lab2 * lc2 ) < fabsf( mEorF - lab1 * lc2 - lab2 * lc1 ) ) {
+		const float tmp = lc1;
+		lc1 = lc2;
+		lc2 = tmp;
+	}
+
+	for( int loop = 0; loop < 2; loop++ ) {
+		const float g = ( loop == 0 ) ? -lab1 : -lab2;
+		const float h = ( loop == 0 ) ? -lc1 : -lc2;
+		const float c0 = ab + g * ( 2.0f * d + ba * g );
+		const float c1 = 2.0f * ( h * ( d + ba * g ) + ef + fe * g );
+		const float c2 = h * ( ba * h + 2.0f * fe ) + c;
+		const int numResults = solveCubic( 0.0f, c0, c1, c2, xs );
+
+		for( int i = 0; i < numResults; i++ ) {
+			float u = xs[i];
+			float v = g * u + h;
+			const float w = 1.0f - u - v;
+
+			if( u < 0.0f || v < 0.0f || w < 0.0f ) {
+				continue;
+			}
+
+			if( !AlessB ) {
+				const float tmp = u;
+				u = v;
+				v = tmp;
+			}
+
+			const v3 pTessellated = v3_sub( phongTessellation( P1, P2, P3, N1, N2, N3, u, v, w, alpha ), ray->origin );
+			const float num = ( domain == 0 ) ? pTessellated.x : ( domain == 1 ) ? pTessellated.y : pTessellated.z;
+			const float den = ( domain == 0 ) ? ray->dir.x : ( domain == 1 ) ? ray->dir.y : ray->dir.z;
+			const float tParam = det_div( num, den );
+
+			if( tParam >= fabsf( tNear ) && tParam <= fminf( *t, fminf( ray->t, tFar ) ) ) {
+				*t = tParam;
+				normal = getPhongTessNormal( N1, N2, N3, ray->dir, u, v, w, C1, C2, C3, E12, E20 );
+			}
+		}
+	}
+
+	return normal;
+}
+
+/* checkFaceIntersection, pt_intersect.cl:142-176: with PHONGTESS == 1 a face whose three vertex normals are
+ * equal (component-wise ==) still takes the flat test */
+static v3 checkFaceIntersection( const ctx_t* c, const ray4* ray, int fIndex, float* t, float tNear, float tFar ) {
 	const orc_uint4 fv = c->scene->facesV[fIndex];
 	const v3 a = v3_from4( c->scene->vertices[fv.x] );
 	const v3 b = v3_from4( c->scene->vertices[fv.y] );
 	const v3 cc = v3_from4( c->scene->vertices[fv.z] );
+
+	if( c->cfg->phong_tessellation > 0.0f ) {
+		const orc_uint4 fn = c->scene->facesN[fIndex];
+		const v3 an = v3_from4( c->scene->normals[fn.x] );
+		const v3 bn = v3_from4( c->scene->normals[fn.y] );
+		const v3 cn = v3_from4( c->scene->normals[fn.z] );
+		const int allEqual = an.x == bn.x && an.y == bn.y && an.z == bn.z && bn.x == cn.x && bn.y == cn.y && bn.z == cn.z;
+
+		if( !allEqual ) {
+			return phongTessTriAndRayIntersect( a, b, cc, an, bn, cn, ray, t, tNear, tFar, c->cfg->phong_tessellation );
+		}
+	}
 
 	return flatTriAndRayIntersect( a, b, cc, ray, t, tNear );
 }
@@ -814,8 +1085,8 @@ static v3 checkFaceIntersection( const ctx_t* c, const ray4* ray, int fIndex, fl
 /* ------------------------------------------------------------------------- */
 
 /* intersectFace, pt_bvh.cl:10-24 */
-static void intersectFace( ctx_t* c, ray4* ray, int faceIndex, float* t, float tNear ) {
-	const v3 normal = checkFaceIntersection( c, ray, faceIndex, t, tNear );
+static void intersectFace( ctx_t* c, ray4* ray, int faceIndex, float* t, float tNear, float tFar ) {
+	const v3 normal = checkFaceIntersection( c, ray, faceIndex, t, tNear, tFar );
 
 	if( ray->t > *t ) {
 		ray->normal = normal;
@@ -827,16 +1098,16 @@ static void intersectFace( ctx_t* c, ray4* ray, int faceIndex, float* t, float t
 }
 
 /* intersectFaces, pt_bvh.cl:35-46 */
-static void intersectFaces( ctx_t* c, ray4* ray, const orc_bvh_node* node, float tNear ) {
+static void intersectFaces( ctx_t* c, ray4* ray, const orc_bvh_node* node, float tNear, float tFar ) {
 	float t = ORC_INF;
 
-	intersectFace( c, ray, (int) node->bbMin.w, &t, tNear );
+	intersectFace( c, ray, (int) node->bbMin.w, &t, tNear, tFar );
 
 	if( node->bbMax.w == -1.0f ) {
 		return;
 	}
 
-	intersectFace( c, ray, (int) node->bbMax.w, &t, tNear );
+	intersectFace( c, ray, (int) node->bbMax.w, &t, tNear, tFar );
 }
 
 /* traverseLights, pt_bvh.cl:54-74 */
@@ -910,7 +1181,7 @@ static void traverse( ctx_t* c, ray4* ray ) {
 		index = currentIndex + 1;
 
 		if( node.bbMin.w >= 0.0f ) {
-			intersectFaces( c, ray, &node, tNear );
+			intersectFaces( c, ray, &node, tNear, tFar );
 		}
 	} while( index > 0 && index < numNodes );
 }
@@ -949,7 +1220,7 @@ static void traverseShadows( ctx_t* c, ray4* ray ) {
 		}
 
 		if( node.bbMin.w >= 0.0f ) {
-			intersectFaces( c, ray, &node, tNear );
+			intersectFaces( c, ray, &node, tNear, tFar );
 
 			if( ray->t < tLight ) {
 				break;

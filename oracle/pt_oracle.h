@@ -76,6 +76,7 @@ typedef struct {
 	int32_t num_lights;         /* NUM_LIGHTS */
 	float anti_aliasing;        /* ANTI_ALIASING */
 	float sky_light[4];         /* SKY_LIGHT */
+	float phong_tessellation;   /* PHONGTESS_ALPHA; PHONGTESS = ( > 0 ) as CL::setValues derives it (CL.cpp:651) */
 } orc_config;
 
 typedef struct {
@@ -85,6 +86,9 @@ typedef struct {
 	const void* materials;      /* orc_material_schlick[] or orc_material_sa[] by cfg.brdf */
 	const orc_light* lights;
 	uint32_t num_faces, num_vertices, num_materials;
+	const orc_uint4* facesN;    /* normal indices per face; only read when cfg.phong_tessellation > 0 */
+	const orc_float4* normals;
+	uint32_t num_normals;
 } orc_scene;
 
 /* Traversal counters summed over the rendered pixels:

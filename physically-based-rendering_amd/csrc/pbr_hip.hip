@@ -33,6 +33,7 @@ struct pbr_ctx {
 	bool hasScene = false;
 	float4* dNodes = nullptr;
 	float4* dTris = nullptr;
+	float4* dTriPN = nullptr;      // exact vertices + vertex normals per face (Phong tessellation); null if the normal indices are unusable
 	float4* dMats = nullptr;
 	float4* dLights = nullptr;
 	uint32_t numHotAvail = 0;      // records at the head of the node stream that are ranked for LDS staging
@@ -107,6 +108,8 @@ int fail( pbr_ctx* ctx, int code, const char* fmt, ... ) {
 void freeScene( pbr_ctx* ctx ) {
 	(void) hipFree( ctx->dNodes );
 	(void) hipFree( ctx->dTris );
+	(void) hipFree( ctx->dTriPN );
+	ctx->dTriPN = nullptr;
 	(void) hipFree( ctx->dMats );
 	(void) hipFree( ctx->dLights );
 	ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dLights = nullptr;
@@ -156,23 +159,23 @@ typedef void ( *KernelFn )( const DevParams );
 
 // PBR_LAB (experiments only, scripts/lab.sh): instantiate just the variants the four bench scenes run,
 // so that an A/B build of the library takes seconds.  Never defined for the product build.
-template<bool REFILL, int MINW>
+template<bool REFILL, int MINW, bool PHONG = false>
 KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 #ifdef PBR_LAB
 	(void) brdf; (void) shadow; (void) lights;
-	return ptk::pathTracing<1, false, false, REFILL, MINW>;
+	return ptk::pathTracing<1, false, false, REFILL, MINW, PHONG>;
 #else
 	if( brdf == 0 ) {
 		if( lights ) {
-			return shadow ? ptk::pathTracing<0, true, true, REFILL, MINW> : ptk::pathTracing<0, false, true, REFILL, MINW>;
+			return shadow ? ptk::pathTracing<0, true, true, REFILL, MINW, PHONG> : ptk::pathTracing<0, false, true, REFILL, MINW, PHONG>;
 		}
-		return ptk::pathTracing<0, false, false, REFILL, MINW>;
+		return ptk::pathTracing<0, false, false, REFILL, MINW, PHONG>;
 	}
 
 	if( lights ) {
-		return shadow ? ptk::pathTracing<1, true, true, REFILL, MINW> : ptk::pathTracing<1, false, true, REFILL, MINW>;
+		return shadow ? ptk::pathTracing<1, true, true, REFILL, MINW, PHONG> : ptk::pathTracing<1, false, true, REFILL, MINW, PHONG>;
 	}
-	return ptk::pathTracing<1, false, false, REFILL, MINW>;
+	return ptk::pathTracing<1, false, false, REFILL, MINW, PHONG>;
 #endif
 }
 
@@ -232,6 +235,11 @@ KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) 
 // Register budget when a schedule is forced (PBR_SCHEDULE) without PBR_VARIANT: scenes whose tree does
 // not fit the staged LDS prefix get "wide" (pt_kernel.hpp), small scenes "lean".  Unforced renders are auto-tuned.
 const uint32_t kWideMinNodes = 2048;
+
+// PHONGTESS == 1: the refill schedule in the wide budget only (the long cubic solve spills either way)
+KernelFn pickKernelPhong( uint32_t brdf, bool shadow, bool lights ) {
+	return pickKernelMode<true, PBR_WIDE_MINW, true>( brdf, shadow, lights );
+}
 
 KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights, bool refill, bool wide ) {
 	if( wide ) {
@@ -388,6 +396,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	P.nodes = ctx->dNodes;
 	P.firstRef = ctx->firstRef;
 	P.tris = ctx->dTris;
+	P.triPN = ctx->dTriPN;
+	P.phongAlpha = ctx->cfg.phong_tessellation;
 	P.mats = ctx->dMats;
 	P.lights = ctx->dLights;
 	P.imgIn = ctx->dImgIn;
@@ -444,6 +454,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	const char* force = std::getenv( "PBR_SCHEDULE" );
 	const char* variant = std::getenv( "PBR_VARIANT" );
 	auto forced = [&]( const char* name ) { return force != nullptr && std::strcmp( force, name ) == 0; };
+
+	const bool phong = ( ctx->cfg.phong_tessellation > 0.0f );
+
+	if( phong && ( ctx->dTriPN == nullptr || forced( "tile" ) || forced( "phased" ) || forced( "batched" ) || forced( "wavefront" ) ) ) {
+		return fail( ctx, PBR_EINVAL, "Phong tessellation runs in the refill schedule only and needs a scene with usable vertex normals" );
+	}
 
 	if( forced( "wavefront" ) && !dof ) {
 		std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "wavefront" );
@@ -605,6 +621,17 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	if( const char* plan = std::getenv( "PBR_PLAN" ) ) {   // experiments: 0..3 = the candidates above, no tuning
 		forcedPlan = std::max( 0, std::min( kPlans - 1, std::atoi( plan ) ) );
+	}
+
+	if( phong ) {
+		// one plan: the Phong-tessellation build of the refill kernel takes the place of refill-wide
+		const int made = makePlan( pickKernelPhong( ctx->cfg.brdf, shadow, lights ), "refill-wide-phong", 0, 0, &plans[1] );
+
+		if( made != PBR_OK ) {
+			return made;
+		}
+
+		forcedPlan = 1;
 	}
 
 	const size_t pixelSlots = (size_t) ctx->numLocalTiles * 64;
@@ -1018,6 +1045,36 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 		tris[(size_t) f * 3 + 2] = make_float4( e2z, __builtin_bit_cast( float, material ), 0.0f, 0.0f );
 	}
 
+	// ---- Phong tessellation input: the exact corners and their vertex normals, gathered per face ----
+	// (pt_intersect.cl:146-157 gathers them through facesV / facesN per test).  The default flat test never reads
+	// facesN, so scenes whose normal indices are unusable stay valid; they just cannot be configured with PHONGTESS.
+	std::vector<float4> triPN;
+	{
+		bool usable = ( s->facesN != nullptr && s->normals != nullptr && s->num_normals > 0 );
+
+		for( uint32_t f = 0; usable && f < s->num_faces; f++ ) {
+			const pbr_uint4& fn = s->facesN[f];
+			usable = ( fn.x < s->num_normals && fn.y < s->num_normals && fn.z < s->num_normals );
+		}
+
+		if( usable ) {
+			triPN.resize( (size_t) s->num_faces * 6 );
+
+			for( uint32_t f = 0; f < s->num_faces; f++ ) {
+				const pbr_uint4& fv = s->facesV[f];
+				const pbr_uint4& fn = s->facesN[f];
+				const uint32_t vi[3] = { fv.x, fv.y, fv.z }, ni[3] = { fn.x, fn.y, fn.z };
+
+				for( int k = 0; k < 3; k++ ) {
+					const pbr_float4& v = s->vertices[vi[k]];
+					const pbr_float4& n = s->normals[ni[k]];
+					triPN[(size_t) f * 6 + k] = make_float4( v.x, v.y, v.z, 0.0f );
+					triPN[(size_t) f * 6 + 3 + k] = make_float4( n.x, n.y, n.z, 0.0f );
+				}
+			}
+		}
+	}
+
 	// ---- materials: one 64-byte shape for both BRDFs ----
 	std::vector<float4> mats( (size_t) s->num_materials * 4 );
 
@@ -1057,6 +1114,11 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dLights, sizeof( float4 ) * lights.size() ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dNodes, nodes.data(), sizeof( float4 ) * nodes.size(), hipMemcpyHostToDevice ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dTris, tris.data(), sizeof( float4 ) * tris.size(), hipMemcpyHostToDevice ) );
+
+	if( !triPN.empty() ) {
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dTriPN, sizeof( float4 ) * triPN.size() ) );
+		HIP_TRY( ctx, hipMemcpy( ctx->dTriPN, triPN.data(), sizeof( float4 ) * triPN.size(), hipMemcpyHostToDevice ) );
+	}
 	HIP_TRY( ctx, hipMemcpy( ctx->dMats, mats.data(), sizeof( float4 ) * mats.size(), hipMemcpyHostToDevice ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dLights, lights.data(), sizeof( float4 ) * lights.size(), hipMemcpyHostToDevice ) );
 
@@ -1095,8 +1157,8 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	if( cfg->max_depth == 0 || cfg->samples == 0 ) {
 		return fail( ctx, PBR_EINVAL, "max_depth and samples must be >= 1" );
 	}
-	if( cfg->phong_tessellation > 0.0f ) {
-		return fail( ctx, PBR_EINVAL, "Phong tessellation (pt_phongtess.cl) is not built" );
+	if( cfg->phong_tessellation > 0.0f && ctx->hasScene && ctx->dTriPN == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "Phong tessellation needs vertex normals: the uploaded scene's facesN / normals are missing or out of range" );
 	}
 	if( cfg->tile_world == 0 || cfg->tile_rank >= cfg->tile_world ) {
 		return fail( ctx, PBR_EINVAL, "tile_rank must be < tile_world, tile_world >= 1" );

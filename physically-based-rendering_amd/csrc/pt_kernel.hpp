@@ -42,6 +42,7 @@ struct DevParams {
 	const float4* nodes;    // the node stream: 2 x float4 per record {min.xy, max.xy}, {min.z, max.z, w0, w1}, see decodeNode;
 	                        // the most-visited nodes first (every block copies records [0, numHot) to LDS)
 	const float4* tris;     // 3 x float4 per face: {a.xyz, e1.x}, {e1.y, e1.z, e2.x, e2.y}, {e2.z, material(int bits), 0, 0}
+	const float4* triPN;    // Phong tessellation only: 6 x float4 per face {a, b, c, an, bn, cn} (exact vertices and vertex normals)
 	const float4* mats;     // 4 x float4 per material: {d, Ni, p|nu, rough|nv}, {Rs, Rd, 0, 0}, Kd, Ks
 	const float4* lights;   // 3 x float4 per light: pos, rgb, {type, radius, 0, 0}
 	const float4* imgIn;    // tile-major, local tiles
@@ -62,6 +63,7 @@ struct DevParams {
 
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
+	float phongAlpha;            // PHONGTESS_ALPHA (kernels built with PHONG = true only)
 	int parkEighths;             // traverse(): a node phase ends once this many eighths of the lanes that entered it have left it
 	int phPark, phShade;         // phased schedule: lanes that leave a node phase before it ends / lanes that wait before a shade phase runs
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
@@ -87,6 +89,7 @@ struct Material {
 struct Hit {
 	float t;
 	int face;      // >= 0 face index; < 0: light -(i+1) (only with t == INF)
+	f3 normal;     // PHONG kernels only: ray.normal of the reference (pt_bvh.cl:18); the others recompute it from `face`
 };
 
 PT_DEV f3 ld3( const float* p ) { return mk3( p[0], p[1], p[2] ); }
@@ -224,7 +227,7 @@ typedef float f2v __attribute__( ( ext_vector_type( 2 ) ) );
 // A node record is laid out for the slab test: n0 = {min.x, min.y, max.x, max.y}, n1 = {min.z, max.z, w0, w1},
 // so that the three register pairs the packed instructions need are the halves of the two 16-B loads.
 template<bool ANYHIT>
-PT_DEV bool boxHit( const float4 n0, const float4 n1, const Ray& ray, const f3 invDir, float rayT, float* tNearOut ) {
+PT_DEV bool boxHit( const float4 n0, const float4 n1, const Ray& ray, const f3 invDir, float rayT, float* tNearOut, float* tFarOut = nullptr ) {
 	// ( bb - origin ) * invDir for both planes of an axis, as 2-vectors: v_pk_add_f32 / v_pk_mul_f32
 	// (two IEEE operations per instruction, same rounding as the scalar forms)
 	const f2v oxy = { ray.origin.x, ray.origin.y };
@@ -242,6 +245,10 @@ PT_DEV bool boxHit( const float4 n0, const float4 n1, const Ray& ray, const f3 i
 	const float tFar = fmin1( fmin1( fmax1( t1x, t2x ), fmax1( t1y, t2y ) ), fmin1( fmax1( t1z, t2z ), inff() ) );
 	*tNearOut = tNear;
 
+	if( tFarOut != nullptr ) {
+		*tFarOut = tFar;
+	}
+
 	bool isNodeHit = ( tNear <= tFar ) && ( tFar > EPSILON5 );
 
 	if( !ANYHIT ) {
@@ -251,8 +258,291 @@ PT_DEV bool boxHit( const float4 n0, const float4 n1, const Ray& ray, const f3 i
 	return isNodeHit;
 }
 
+// ---- Phong tessellation (pt_phongtess.cl, PHONGTESS == 1; kernels built with PHONG = true) ----------------
+
+// solveCubic, pt_utils.cl:108-199: a0 x^3 + a1 x^2 + a2 x + a3 = 0, returns the number of real roots in x[]
+PT_DEV int solveCubic( float a0, float a1, float a2, float a3, float x[3] ) {
+	const float THIRD = 0.3333333333f;
+	const float THIRD_HALF = 0.1666666666f;
+	float w, p, q, dis, phi;
+
+	if( __builtin_fabsf( a0 ) > 0.0f ) {
+		w = ( a1 / a0 ) * THIRD;
+		p = ( a2 / a0 ) * THIRD - w * w;
+		p = p * p * p;
+		q = 0.5f * ( ( a2 * w - a3 ) / a0 ) - w * w * w;
+		dis = q * q + p;
+
+		if( dis < 0.0f ) {
+			phi = acos1( fmin1( fmax1( q / sqrt1( -p ), -1.0f ), 1.0f ) );
+			p = 2.0f * pow1( -p, THIRD_HALF );
+
+			// ( phi + 2.0f * M_PI ) * THIRD: M_PI is a double literal, the sum and product are binary64
+			const float u0 = p * cos1( phi * THIRD ) - w;
+			const float u1 = p * cos1( (float) ( ( (double) phi + (double) 2.0f * M_PI_D ) * (double) THIRD ) ) - w;
+			const float u2 = p * cos1( (float) ( ( (double) phi + (double) 4.0f * M_PI_D ) * (double) THIRD ) ) - w;
+
+			x[0] = fmin1( u0, fmin1( u1, u2 ) );
+			x[1] = fmax1( fmin1( u0, u1 ), fmax1( fmin1( u0, u2 ), fmin1( u1, u2 ) ) );
+			x[2] = fmax1( u0, fmax1( u1, u2 ) );
+
+			for( int k = 0; k < 3; k++ ) {
+				x[k] -= ( a3 + x[k] * ( a2 + x[k] * ( a1 + x[k] * a0 ) ) ) / ( a2 + x[k] * ( 2.0f * a1 + x[k] * 3.0f * a0 ) );
+			}
+
+			return 3;
+		}
+
+		dis = sqrt1( dis );
+		x[0] = cbrt1( q + dis ) + cbrt1( q - dis ) - w;
+		x[0] -= ( a3 + x[0] * ( a2 + x[0] * ( a1 + x[0] * a0 ) ) ) / ( a2 + x[0] * ( 2.0f * a1 + x[0] * 3.0f * a0 ) );
+
+		return 1;
+	}
+	else if( __builtin_fabsf( a1 ) > 0.0f ) {
+		p = 0.5f * ( a2 / a1 );
+		dis = p * p - a3 / a1;
+
+		if( dis >= 0.0f ) {
+			const float disSqrt = sqrt1( dis );
+			x[0] = -p - disSqrt;
+			x[1] = -p + disSqrt;
+			x[0] -= ( a3 + x[0] * ( a2 + x[0] * a1 ) ) / ( a2 + x[0] * 2.0f * a1 );
+			x[1] -= ( a3 + x[1] * ( a2 + x[1] * a1 ) ) / ( a2 + x[1] * 2.0f * a1 );
+			return 2;
+		}
+	}
+	else if( __builtin_fabsf( a2 ) > 0.0f ) {
+		x[0] = -a3 / a2;
+		return 1;
+	}
+
+	return 0;
+}
+
+// projectOnPlane, pt_utils.cl:397-399
+PT_DEV f3 projectOnPlane( f3 q, f3 p, f3 n ) {
+	return q - n * dot( q - p, n );
+}
+
+// phongTessellation, pt_phongtess.cl:14-26
+PT_DEV f3 phongTessellation( f3 P1, f3 P2, f3 P3, f3 N1, f3 N2, f3 N3, float u, float v, float w, float alpha ) {
+	const f3 pBary = ( P1 * u + P2 * v ) + P3 * w;
+	const f3 pTessellated = ( projectOnPlane( pBary, P1, N1 ) * u + projectOnPlane( pBary, P2, N2 ) * v ) + projectOnPlane( pBary, P3, N3 ) * w;
+	return pBary * ( 1.0f - alpha ) + pTessellated * alpha;
+}
+
+// getTriangleNormalS / getTriangleNormal / getTriangleReflectionVec / getPhongTessNormal, pt_utils.cl:231-294
+PT_DEV f3 getPhongTessNormal( f3 an, f3 bn, f3 cn, f3 rayDir, float u, float v, float w, f3 C1, f3 C2, f3 C3, f3 E12, f3 E20 ) {
+	const f3 du = ( C3 * ( w - u ) + ( C1 - C2 ) * v ) + E20;
+	const f3 dv = ( C2 * ( w - v ) + ( C1 - C3 ) * u ) - E12;
+	const f3 ns = normalize( cross( du, dv ) );
+	const f3 np = normalize( ( an * u + bn * v ) + cn * w );
+	const f3 r = rayDir - ( np * 2.0f ) * dot( rayDir, np );
+	return ( dot( ns, r ) < 0.0f ) ? ns : np;
+}
+
+// phongTessTriAndRayIntersect, pt_phongtess.cl:56-212 (after Ogaki & Tokuyoshi, "Direct Ray Tracing of Phong
+// Tessellation"); getPlanesFromRay (pt_utils.cl:208-218) and getBestRayDomain (pt_phongtess.cl:35-44) inlined.
+// Returns t (INF: no hit) and the normal at the hit.
+PT_DEV float phongTessTriAndRayIntersect(
+	f3 P1, f3 P2, f3 P3, f3 N1, f3 N2, f3 N3, const Ray& ray, float rayT, float tNear, float tFar, float alpha, f3* normalOut
+) {
+	f3 normal = mk3( 0.0f, 0.0f, 0.0f );
+	float t = inff();
+	*normalOut = normal;
+
+	const f3 E01 = P2 - P1;
+	const f3 E12 = P3 - P2;
+	const f3 E20 = P1 - P3;
+	const f3 C1 = ( N2 * dot( N2, E01 ) - N1 * dot( N1, E01 ) ) * alpha;
+	const f3 C2 = ( N3 * dot( N3, E12 ) - N2 * dot( N2, E12 ) ) * alpha;
+	const f3 C3 = ( N1 * dot( N1, E20 ) - N3 * dot( N3, E20 ) ) * alpha;
+
+	const f3 n1 = normalize( cross( ray.origin, ray.dir ) );
+	const f3 n2 = normalize( cross( n1, ray.dir ) );
+	const float o1 = dot( n1, ray.origin );
+	const float o2 = dot( n2, ray.origin );
+	const f3 C123 = ( C1 - C2 ) - C3;
+
+	const float a = dot( -n1, C3 );
+	const float b = dot( -n1, C2 );
+	const float c = dot( n1, P3 ) - o1;
+	const float d = dot( n1, C123 ) * 0.5f;
+	const float e = dot( n1, C3 + E20 ) * 0.5f;
+	const float f = dot( n1, C2 - E12 ) * 0.5f;
+	const float l = dot( -n2, C3 );
+	const float m = dot( -n2, C2 );
+	const float n = dot( n2, P3 ) - o2;
+	const float o = dot( n2, C123 ) * 0.5f;
+	const float p = dot( n2, C3 + E20 ) * 0.5f;
+	const float q = dot( n2, C2 - E12 ) * 0.5f;
+
+	float xs[3] = { -1.0f, -1.0f, -1.0f };
+	const float a3 = ( l*m*n + 2.0f*o*p*q ) - ( l*q*q + m*p*p + n*o*o );
+	const float a2 = ( a*m*n + l*b*n + l*m*c + 2.0f*( d*p*q + o*e*q + o*p*f ) ) -
+	                 ( a*q*q + b*p*p + c*o*o + 2.0f*( l*f*q + m*e*p + n*d*o ) );
+	const float a1 = ( a*b*n + a*m*c + l*b*c + 2.0f*( o*e*f + d*e*q + d*p*f ) ) -
+	                 ( l*f*f + m*e*e + n*d*d + 2.0f*( a*f*q + b*e*p + c*d*o ) );
+	const float a0 = ( a*b*c + 2.0f*d*e*f ) - ( a*f*f + b*e*e + c*d*d );
+	const int numCubicRoots = solveCubic( a0, a1, a2, a3, xs );
+
+	if( numCubicRoots == 0 ) {
+		return t;
+	}
+
+	float x = 0.0f;
+	float determinant = inff();
+	float mA, mB, mC, mD, mE, mF;
+
+	for( int i = 0; i < numCubicRoots; i++ ) {
+		mA = a * xs[i] + l;
+		mB = b * xs[i] + m;
+		mD = d * xs[i] + o;
+		const float tmp = mD * mD - mA * mB;
+		x = ( determinant > tmp ) ? xs[i] : x;
+		determinant = fmin1( determinant, tmp );
+	}
+
+	if( 0.0f >= determinant ) {
+		return t;
+	}
+
+	const f3 ad = mk3( __builtin_fabsf( ray.dir.x ), __builtin_fabsf( ray.dir.y ), __builtin_fabsf( ray.dir.z ) );
+	int domain = ( ad.y > ad.z ) ? 1 : 2;
+
+	if( ad.x > ad.y ) {
+		domain = ( ad.x > ad.z ) ? 0 : 2;
+	}
+
+	mA = a * x + l;
+	mB = b * x + m;
+	mC = c * x + n;
+	mD = d * x + o;
+	mE = e * x + p;
+	mF = f * x + q;
+
+	const bool AlessB = __builtin_fabsf( mA ) < __builtin_fabsf( mB );
+	const float mBorA = AlessB ? mB : mA;
+	mA = mA / mBorA;
+	mB = mB / mBorA;
+	mC = mC / mBorA;
+	mD = mD / mBorA;
+	mE = mE / mBorA;
+	mF = mF / mBorA;
+
+	const float mAorB = AlessB ? mA : mB;
+	const float mEorF = AlessB ? 2.0f * mE : 2.0f * mF;
+	const float mForE = AlessB ? mF : mE;
+	const float ab = AlessB ? a : b;
+	const float ba = AlessB ? b : a;
+	const float ef = AlessB ? e : f;
+	const float fe = AlessB ? f : e;
+
+	const float sqrtAorB = sqrt1( mD * mD - mAorB );
+	const float sqrtC = sqrt1( mForE * mForE - mC );
+	const float lab1 = mD + sqrtAorB;
+	const float lab2 = mD - sqrtAorB;
+	float lc1 = mForE + sqrtC;
+	float lc2 = mForE - sqrtC;
+
+	if( __builtin_fabsf( mEorF - lab1 * lc1 - lab2 * lc2 ) < __builtin_fabsf( mEorF - lab1 * lc2 - lab2 * lc1 ) ) {
+		const float tmp = lc1;
+		lc1 = lc2;
+		lc2 = tmp;
+	}
+
+	for( int loop = 0; loop < 2; loop++ ) {
+		const float g = ( loop == 0 ) ? -lab1 : -lab2;
+		const float h = ( loop == 0 ) ? -lc1 : -lc2;
+		const float c0 = ab + g * ( 2.0f * d + ba * g );
+		const float c1 = 2.0f * ( h * ( d + ba * g ) + ef + fe * g );
+		const float c2 = h * ( ba * h + 2.0f * fe ) + c;
+		const int numResults = solveCubic( 0.0f, c0, c1, c2, xs );
+
+		for( int i = 0; i < numResults; i++ ) {
+			float u = xs[i];
+			float v = g * u + h;
+			const float w = 1.0f - u - v;
+
+			if( u < 0.0f || v < 0.0f || w < 0.0f ) {
+				continue;
+			}
+
+			if( !AlessB ) {
+				const float tmp = u;
+				u = v;
+				v = tmp;
+			}
+
+			const f3 pTessellated = phongTessellation( P1, P2, P3, N1, N2, N3, u, v, w, alpha ) - ray.origin;
+			const float num = ( domain == 0 ) ? pTessellated.x : ( domain == 1 ) ? pTessellated.y : pTessellated.z;
+			const float den = ( domain == 0 ) ? ray.dir.x : ( domain == 1 ) ? ray.dir.y : ray.dir.z;
+			const float tParam = num / den;
+
+			if( tParam >= __builtin_fabsf( tNear ) && tParam <= fmin1( t, fmin1( rayT, tFar ) ) ) {
+				t = tParam;
+				normal = getPhongTessNormal( N1, N2, N3, ray.dir, u, v, w, C1, C2, C3, E12, E20 );
+			}
+		}
+	}
+
+	*normalOut = normal;
+	return t;
+}
+
+// checkFaceIntersection with PHONGTESS == 1 (pt_intersect.cl:142-176): a face whose three vertex normals are equal
+// takes the flat test (on the pre-gathered record; its normal is the geometric one)
+PT_DEV float phongFaceT( const DevParams& P, int face, const Ray& ray, float rayT, float tNear, float tFar, f3* normalOut ) {
+	const float4 pa = P.triPN[(size_t) face * 6 + 0], pb = P.triPN[(size_t) face * 6 + 1], pc = P.triPN[(size_t) face * 6 + 2];
+	const float4 na = P.triPN[(size_t) face * 6 + 3], nb = P.triPN[(size_t) face * 6 + 4], nc = P.triPN[(size_t) face * 6 + 5];
+	const bool allEqual = na.x == nb.x && na.y == nb.y && na.z == nb.z && nb.x == nc.x && nb.y == nc.y && nb.z == nc.z;
+
+	if( allEqual ) {
+		const float t = triangleT( P, face, ray, rayT, tNear );
+		const float4 r0 = P.tris[face * 3 + 0];
+		const float4 r1 = P.tris[face * 3 + 1];
+		const float4 r2 = P.tris[face * 3 + 2];
+		// flatTriAndRayIntersect returns the zero vector with t = INF; the normal is only kept for t < ray.t anyway
+		*normalOut = normalize( cross( mk3( r0.w, r1.x, r1.y ), mk3( r1.z, r1.w, r2.x ) ) );
+		return t;
+	}
+
+	return phongTessTriAndRayIntersect(
+		mk3( pa.x, pa.y, pa.z ), mk3( pb.x, pb.y, pb.z ), mk3( pc.x, pc.y, pc.z ),
+		mk3( na.x, na.y, na.z ), mk3( nb.x, nb.y, nb.z ), mk3( nc.x, nc.y, nc.z ),
+		ray, rayT, tNear, tFar, P.phongAlpha, normalOut );
+}
+
 // intersectFaces / intersectFace, pt_bvh.cl:10-46, for one hit leaf
-PT_DEV void testLeaf( const DevParams& P, int face0, int face1, const Ray& ray, float tNear, Hit& hit, unsigned& faceTests ) {
+template<bool PHONG = false>
+PT_DEV void testLeaf( const DevParams& P, int face0, int face1, const Ray& ray, float tNear, float tFar, Hit& hit, unsigned& faceTests ) {
+	if( PHONG ) {
+		f3 normal;
+		float t = phongFaceT( P, face0, ray, hit.t, tNear, tFar, &normal );
+		faceTests++;
+
+		if( hit.t > t ) {
+			hit.t = t;
+			hit.face = face0;
+			hit.normal = normal;
+		}
+
+		if( face1 != -1 ) {
+			t = phongFaceT( P, face1, ray, hit.t, tNear, tFar, &normal );
+			faceTests++;
+
+			if( hit.t > t ) {
+				hit.t = t;
+				hit.face = face1;
+				hit.normal = normal;
+			}
+		}
+
+		return;
+	}
+
+	(void) tFar;
 	float t = triangleT( P, face0, ray, hit.t, tNear );
 	faceTests++;
 
@@ -340,7 +630,7 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 // ---- the node phase, hand-scheduled -------------------------------------------------------------
 // One node phase of traverse() (below) for the lanes that are walking: fetch the node (LDS or
 // memory), slab test, follow the hit / miss record, until `keep` or fewer lanes are still walking.
-// Lanes that stop on a hit leaf return parked = 1 with the leaf's w0 word and tNear.
+// Lanes that stop on a hit leaf return parked = 1 with the leaf's w0 word, tNear and tFar.
 //
 // Why assembly: compiled from C++, this loop carries its three per-lane conditions (walking,
 // parked, resident in LDS) as 64-bit scalar masks that are merged by ~35 scalar instructions per
@@ -360,7 +650,7 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 template<bool ANYHIT>
 PT_DEV void nodePhaseAsm(
 	const DevParams& P, const float4* lds, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep,
-	int& ref, unsigned& visits, int& leafWord, float& leafTNear, int& parked
+	int& ref, unsigned& visits, int& leafWord, float& leafTNear, float& leafTFar, int& parked
 ) {
 	const unsigned ldsBase = (unsigned) (size_t) lds;   // low half of a generic LDS address = the LDS byte offset
 	const float eps = EPSILON5;
@@ -416,10 +706,11 @@ PT_DEV void nodePhaseAsm(
 		"s_mov_b64 exec, %[saved]\n" \
 		"v_cndmask_b32 %[parked], 0, 1, %[parkMask]\n" \
 		"v_mov_b32 %[leafWord], v52\n" \
-		"v_mov_b32 %[leafTNear], v60\n"
+		"v_mov_b32 %[leafTNear], v60\n" \
+		"v_mov_b32 %[leafTFar], v61\n"
 
 #define PT_NODE_PHASE_OPERANDS \
-		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [parked] "=v"( parked ), \
+		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [leafTFar] "=v"( leafTFar ), [parked] "=v"( parked ), \
 		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [mB] "=&s"( mB ), [mH] "=&s"( mH ), \
 		  [mC] "=&s"( mC ), [count] "=&s"( count ) \
 		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ), \
@@ -468,7 +759,7 @@ PT_DEV void nodePhaseAsm(
 // to one lane, i.e. the plain lock-step walk.  Rejected after measurement (bit-identical, slower):
 // waiting until EVERY lane stands on a leaf (dragon-class 0.65x), and requesting both successors
 // of a node before the slab test (a loss once registers are tight).
-template<bool ANYHIT, bool LIGHTS, bool USE_LDS>
+template<bool ANYHIT, bool LIGHTS, bool USE_LDS, bool PHONG = false>
 PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
 	const f3 invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
 	const float tLight = hit.t;
@@ -494,7 +785,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 	bool walking = true;   // the walk always visits node 1 (pt_bvh.cl:84-88)
 	unsigned visits = 0;
 	int leafWord = 0;
-	float leafTNear = 0.0f;
+	float leafTNear = 0.0f, leafTFar = 0.0f;   // tFar: Phong tessellation only (pt_phongtess.cl:202)
 
 	for( ;; ) {
 		bool parked = false;
@@ -507,7 +798,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 #ifdef PT_NODE_PHASE_ASM
 			if( USE_LDS ) {
 				int parkedFlag;
-				nodePhaseAsm<ANYHIT>( P, lds, oxy, ozz, ixy, izz, hit.t, keep, cur.ref, visits, leafWord, leafTNear, parkedFlag );
+				nodePhaseAsm<ANYHIT>( P, lds, oxy, ozz, ixy, izz, hit.t, keep, cur.ref, visits, leafWord, leafTNear, leafTFar, parkedFlag );
 				parked = ( parkedFlag != 0 );
 				walking = alive( cur );
 			}
@@ -537,7 +828,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 				fetchNode<USE_LDS>( P, lds, cur, &n0, &n1 );
 				const int w0 = __float_as_int( n1.z );
 				const int w1 = __float_as_int( n1.w );
-				float tNear;
+				float tNear, tFar;
 #ifdef PBR_EXP_PAD_VALU   // sensitivity probes (scripts/lab.sh): extra work per node visit
 				{
 					float pad = n0.x;
@@ -555,7 +846,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 #endif
 
 				// hit container -> w0; miss, or leaf -> w1
-				const bool isHit = boxHit<ANYHIT>( n0, n1, ray, invDir, hit.t, &tNear );
+				const bool isHit = boxHit<ANYHIT>( n0, n1, ray, invDir, hit.t, &tNear, &tFar );
 				const bool isLeaf = ( w0 < 0 );
 				cur.ref = ( isHit && !isLeaf ) ? w0 : w1;
 
@@ -563,6 +854,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 					parked = true;
 					leafWord = w0;
 					leafTNear = tNear;
+					leafTFar = tFar;
 				}
 
 				walking = alive( cur );
@@ -580,7 +872,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 				}
 			}
 #endif
-			testLeaf( P, leafFace0( leafWord ), leafFace1( leafWord ), ray, leafTNear, hit, faceTests );
+			testLeaf<PHONG>( P, leafFace0( leafWord ), leafFace1( leafWord ), ray, leafTNear, leafTFar, hit, faceTests );
 
 			if( ANYHIT && hit.t < tLight ) {
 				walking = false;
@@ -1115,7 +1407,7 @@ PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
 // shade the hit, and — when the path / frame ends — fold it into the running mean and start the
 // next path.  Returns true when the pixel has had all P.nFrames frames; otherwise st.ray is the
 // next ray to trace.
-template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false>
 PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt, const Hit hit ) {
 	// references keep the shading code below in the reference's vocabulary
 	Ray& ray = st.ray;
@@ -1148,6 +1440,10 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 		else {
 			int mtlIndex;
 			f3 normal = faceNormal( P, hit.face, &mtlIndex );
+
+			if( PHONG ) {
+				normal = hit.normal;   // ray.normal as intersectFace stored it (pt_bvh.cl:18): the Phong normal on curved faces
+			}
 			const Material mtl = loadMaterial( P, mtlIndex );
 			totHits++;
 
@@ -1187,7 +1483,7 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 						lh.t = tLight;
 						lh.face = 0;
 						unsigned unusedNodes = 0;
-						traverse<true, LIGHTS, true>( P, lds, lightRay, lh, unusedNodes, dbgTris );
+						traverse<true, LIGHTS, true, PHONG>( P, lds, lightRay, lh, unusedNodes, dbgTris );
 						lightDir = lightRay.dir;
 
 						if( lh.t >= tLight ) {
@@ -1309,13 +1605,14 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 }
 
 // One bounce of the lane's current path: traverse (pathtracing.cl:259), then shadeStep.
-template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false>
 PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt ) {
 	Hit hit;
 	hit.t = inff();
 	hit.face = 0;
-	traverse<false, LIGHTS, true>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
-	return shadeStep<BRDF, SHADOW, LIGHTS, FP>( P, lds, st, cnt, hit );
+	hit.normal = mk3( 0.0f, 0.0f, 0.0f );
+	traverse<false, LIGHTS, true, PHONG>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
+	return shadeStep<BRDF, SHADOW, LIGHTS, FP, PHONG>( P, lds, st, cnt, hit );
 }
 
 // ---- the pixel-slot queue ----------------------------------------------------------------
@@ -1424,7 +1721,7 @@ PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, u
 
 extern __shared__ float4 gHotNodes[];
 
-template<int BRDF, bool SHADOW, bool LIGHTS, bool REFILL, int MINW>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool REFILL, int MINW, bool PHONG = false>
 __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParams P ) {
 	const float4* lds = gHotNodes;
 #ifdef PBR_EXP_TAIL   // lab only: how much of the launch do waves spend finished, waiting for the last one?
@@ -1461,7 +1758,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 				break;
 			}
 #endif
-			if( stepPixel<BRDF, SHADOW, LIGHTS, true>( P, lds, st, cnt ) ) {
+			if( stepPixel<BRDF, SHADOW, LIGHTS, true, PHONG>( P, lds, st, cnt ) ) {
 				finishPixel<true>( P, st );
 
 				if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
@@ -1495,7 +1792,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 			const long long guardMax = (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1;
 #endif
 
-			while( !stepPixel<BRDF, SHADOW, LIGHTS>( P, lds, st, cnt ) ) {
+			while( !stepPixel<BRDF, SHADOW, LIGHTS, false, PHONG>( P, lds, st, cnt ) ) {
 #ifdef PBR_GUARD_PATH
 				if( ++guardSteps > guardMax ) {
 					atomicAdd( &P.guard[1], 1u );
@@ -1652,7 +1949,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 			const int nNode = __popcll( __ballot( mode == MODE_NODE ) );
 
 			if( mode == MODE_LEAF && ( nLeaf >= PBR_LEAF_BATCH || nNode == 0 ) ) {
-				testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, w.hit, st.dbgTris );
+				testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
 				mode = alive( w.cur ) ? MODE_NODE : MODE_SHADE;
 			}
 		}
@@ -1765,7 +2062,8 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				const f2v ixy = { w.invDir.x, w.invDir.y };
 				const f2v izz = { w.invDir.z, w.invDir.z };
 				int leafWord, parkedFlag;
-				nodePhaseAsm<false>( P, lds, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, parkedFlag );
+				float unusedTFar;
+				nodePhaseAsm<false>( P, lds, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
 
 				if( parkedFlag != 0 ) {
 					w.leafFace0 = leafFace0( leafWord );
@@ -1812,7 +2110,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 		// ---- leaf phase ---------------------------------------------------------------------
 		if( mode == MODE_LEAF ) {
 			PH_STAT( sLeafIt, sLeafAct )
-			testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, w.hit, st.dbgTris );
+			testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
 			mode = alive( w.cur ) ? MODE_NODE : MODE_SHADE;
 		}
 

@@ -241,4 +241,17 @@ PT_DEV float pow1( float x, float y ) {
 	return sign * (float) exp2_d( t );
 }
 
+// cbrt (solveCubic, pt_utils.cl:153): through the binary64 log2 / exp2 of pow1
+PT_DEV float cbrt1( float x ) {
+	const float ax = __builtin_fabsf( x );
+
+	if( x != x || ax == 0.0f || ax == inff() ) {
+		return x;
+	}
+
+	return __builtin_copysignf( (float) exp2_d( log2_d( (double) ax ) / 3.0 ), x );
+}
+
+PT_DEV float cos1( float x ) { float s, c; sincos( x, &s, &c ); return c; }
+
 }  // namespace ptm

@@ -213,7 +213,7 @@ __global__ __launch_bounds__( PBR_BLOCK, 8 ) void wfTrace( const DevParams P, co
 			const int nNode = __popcll( __ballot( mode == WF_NODE ) );
 
 			if( mode == WF_LEAF && ( nLeaf >= PBR_WF_LEAF_BATCH || nNode == 0 ) ) {
-				testLeaf( P, w.leafFace0, w.leafFace1, ray, w.leafTNear, w.hit, tris );
+				testLeaf( P, w.leafFace0, w.leafFace1, ray, w.leafTNear, 0.0f, w.hit, tris );
 
 				if( alive( w.cur ) ) {
 					mode = WF_NODE;

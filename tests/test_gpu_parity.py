@@ -498,6 +498,70 @@ def test_device_bvh_build_emits_the_reference_format(pbr, oracle, device, kind, 
             assert abs(float(t[k]) - best) <= 1e-3 * max(1.0, best), (k, float(t[k]), best)
 
 
+def smooth_scene(pbr, tmp_path, **cfg):
+    """A UV sphere with per-vertex normals (curved: Phong tessellation applies) on a flat floor (three equal
+    normals per face: the flat test applies), written as OBJ / MTL and loaded through the host loader + BVH."""
+    rings, segs = 10, 16
+    verts, norms, faces = [], [], []
+    for i in range(rings + 1):
+        th = np.pi * i / rings
+        for j in range(segs):
+            ph = 2 * np.pi * j / segs
+            n = np.array([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)])
+            verts.append(0.6 * n + [0.0, 0.75, 0.0]); norms.append(n)
+    for i in range(rings):
+        for j in range(segs):
+            a, b = i * segs + j, i * segs + (j + 1) % segs
+            c, d = a + segs, b + segs
+            if i > 0:
+                faces.append((a, b, c))
+            if i < rings - 1:
+                faces.append((b, d, c))
+    lines = ["mtllib s.mtl", "o Ball"]
+    lines += ["v %.9g %.9g %.9g" % tuple(v) for v in verts]
+    lines += ["vn %.9g %.9g %.9g" % tuple(n) for n in norms]
+    lines += ["usemtl Shiny"] + ["f %d//%d %d//%d %d//%d" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1) for a, b, c in faces]
+    k, kn = len(verts), len(norms)
+    lines += ["o Floor", "v -2 0 -2", "v 2 0 -2", "v 2 0 2", "v -2 0 2", "vn 0 1 0", "usemtl Matte",
+              "f %d//%d %d//%d %d//%d" % (k + 1, kn + 1, k + 3, kn + 1, k + 2, kn + 1),
+              "f %d//%d %d//%d %d//%d" % (k + 1, kn + 1, k + 4, kn + 1, k + 3, kn + 1)]
+    (tmp_path / "s.obj").write_text("\n".join(lines) + "\n")
+    (tmp_path / "s.mtl").write_text("newmtl Shiny\nKd 0.8 0.3 0.2\nKs 0.9 0.9 0.9\nnu 200\nnv 200\nRs 0.4\nRd 0.6\n\nnewmtl Matte\nKd 0.6 0.6 0.7\n\nnewmtl sky_light\nKd 0.9 0.95 1.0\n")
+    pbr.cfg_reset()
+    pbr.cfg_set(**cfg)
+    return pbr.HostScene.load_obj(str(tmp_path) + "/", "s.obj")
+
+
+@pytest.mark.parametrize("brdf", [1, 0])
+def test_phong_tessellation_bit_exact(pbr, oracle, device, tmp_path, brdf):
+    """K19 (pt_phongtess.cl, PHONGTESS = 1): curved faces are intersected as Phong-tessellated patches (cubic +
+    quadratics), flat ones as triangles; hits carry the patch normal into the shading."""
+    sc = smooth_scene(pbr, tmp_path, **{"render.max_depth": 4, "render.brdf": brdf, "render.phong_tessellation": 0.6})
+    arr = sc.arrays()
+    tri_n = arr["normals"][arr["facesN"][:, :3].astype(np.int64), :3]
+    curved = ~(np.all(tri_n[:, 0] == tri_n[:, 1], axis=1) & np.all(tri_n[:, 1] == tri_n[:, 2], axis=1))
+    assert curved.sum() > 200 and (~curved).sum() >= 2
+    w, h = 64, 48
+    cfg = sc.config(w, h)
+    assert cfg.phong_tessellation == np.float32(0.6)
+    got, want, ref = both_render(pbr, oracle, device, sc, w, h, 4, cfg=cfg)
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert same_values(device.read_debug(), ref.debug)
+    assert device.counters() == ref.counter_dict()
+    assert device.last_plan()[0] == "refill-wide-phong"
+    # the tessellation changes the picture: the same scene with PHONGTESS off renders differently
+    flat = sc.config(w, h)
+    flat.phong_tessellation = 0.0
+    plain = oracle.Renderer(sc.desc, flat, threads=8).render(0, pbr.frame_seeds(0, 4), pbr.pixel_dimension(w, h), sc.camera())
+    assert not same_values(plain, want)
+    with pytest.raises(pbr.PbrError, match="refill schedule only"):
+        os.environ["PBR_SCHEDULE"] = "phased"
+        try:
+            device.render(0, pbr.frame_seeds(0, 1), pbr.pixel_dimension(w, h), sc.camera())
+        finally:
+            del os.environ["PBR_SCHEDULE"]
+
+
 def test_display_step_is_the_clamped_linear_image(pbr, device):
     """pbr_read_display: what shader/pathtracing.frag puts on an 8-bit framebuffer, converted on the device."""
     sc = make_scene(pbr, **{"render.max_depth": 3})
@@ -535,8 +599,7 @@ def test_call_sequence_and_validation_errors(pbr, device):
         device.configure(cfg)
     cfg = sc.config(64, 64)
     cfg.phong_tessellation = 0.5
-    with pytest.raises(pbr.PbrError, match="Phong"):
-        device.configure(cfg)
+    device.configure(cfg)                                    # Phong tessellation is built (K19); flat scenes just never take its path
     cfg = sc.config(64, 64)
     cfg.brdf = 0
     device.configure(cfg)
