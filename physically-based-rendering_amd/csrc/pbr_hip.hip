@@ -1021,7 +1021,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	}
 
 	// ---- faces: gather the corners; store a, b - a, c - a (what pt_intersect.cl:98-99 computes) ----
-	std::vector<float4> tris( (size_t) s->num_faces * 3 );
+	std::vector<float4> tris( (size_t) ( s->num_faces + 1 ) * 3, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );   // + 1: testLeaf reads face + 1 ahead
 
 	for( uint32_t f = 0; f < s->num_faces; f++ ) {
 		const pbr_uint4& fv = s->facesV[f];

@@ -186,11 +186,24 @@ PT_DEV void traverseLights( const DevParams& P, const Ray& ray, Hit& hit ) {
 	}
 }
 
+// One pre-gathered face record (48 B; the array is padded by one record, so face + 1 is always readable)
+struct TriRecord {
+	float4 r0, r1, r2;
+};
+
+PT_DEV TriRecord loadTri( const DevParams& P, int face ) {
+	TriRecord r;
+	r.r0 = P.tris[face * 3 + 0];
+	r.r1 = P.tris[face * 3 + 1];
+	r.r2 = P.tris[face * 3 + 2];
+	return r;
+}
+
 // flatTriAndRayIntersect, pt_intersect.cl:92-129, on the pre-gathered record.  Returns t or INF.
-PT_DEV float triangleT( const DevParams& P, int face, const Ray& ray, float rayT, float tNear ) {
-	const float4 r0 = P.tris[face * 3 + 0];
-	const float4 r1 = P.tris[face * 3 + 1];
-	const float4 r2 = P.tris[face * 3 + 2];
+PT_DEV float triangleT( const TriRecord& rec, const Ray& ray, float rayT, float tNear ) {
+	const float4 r0 = rec.r0;
+	const float4 r1 = rec.r1;
+	const float4 r2 = rec.r2;
 	const f3 a = mk3( r0.x, r0.y, r0.z );
 	const f3 edge1 = mk3( r0.w, r1.x, r1.y );
 	const f3 edge2 = mk3( r1.z, r1.w, r2.x );
@@ -499,10 +512,9 @@ PT_DEV float phongFaceT( const DevParams& P, int face, const Ray& ray, float ray
 	const bool allEqual = na.x == nb.x && na.y == nb.y && na.z == nb.z && nb.x == nc.x && nb.y == nc.y && nb.z == nc.z;
 
 	if( allEqual ) {
-		const float t = triangleT( P, face, ray, rayT, tNear );
-		const float4 r0 = P.tris[face * 3 + 0];
-		const float4 r1 = P.tris[face * 3 + 1];
-		const float4 r2 = P.tris[face * 3 + 2];
+		const TriRecord rec = loadTri( P, face );
+		const float t = triangleT( rec, ray, rayT, tNear );
+		const float4 r0 = rec.r0, r1 = rec.r1, r2 = rec.r2;
 		// flatTriAndRayIntersect returns the zero vector with t = INF; the normal is only kept for t < ray.t anyway
 		*normalOut = normalize( cross( mk3( r0.w, r1.x, r1.y ), mk3( r1.z, r1.w, r2.x ) ) );
 		return t;
@@ -515,7 +527,8 @@ PT_DEV float phongFaceT( const DevParams& P, int face, const Ray& ray, float ray
 }
 
 // intersectFaces / intersectFace, pt_bvh.cl:10-46, for one hit leaf
-template<bool PHONG = false>
+// EAGER: request the second face's record before testing the first (12 more registers: kernels with the lean budget)
+template<bool PHONG = false, bool EAGER = false>
 PT_DEV void testLeaf( const DevParams& P, int face0, int face1, const Ray& ray, float tNear, float tFar, Hit& hit, unsigned& faceTests ) {
 	if( PHONG ) {
 		f3 normal;
@@ -543,7 +556,17 @@ PT_DEV void testLeaf( const DevParams& P, int face0, int face1, const Ray& ray, 
 	}
 
 	(void) tFar;
-	float t = triangleT( P, face0, ray, hit.t, tNear );
+	// EAGER: both records are requested before the first test — a leaf's second face is the next record (the
+	// reference's leaf order), so its fetch overlaps the first face's arithmetic instead of following it
+	// (+2..4 % at 4 waves / SIMD; at 8 the 12 extra registers cost more than the latency)
+	const TriRecord first = loadTri( P, face0 );
+	TriRecord second;
+
+	if( EAGER ) {
+		second = loadTri( P, face0 + 1 );
+	}
+
+	float t = triangleT( first, ray, hit.t, tNear );
 	faceTests++;
 
 	if( hit.t > t ) {
@@ -552,7 +575,11 @@ PT_DEV void testLeaf( const DevParams& P, int face0, int face1, const Ray& ray, 
 	}
 
 	if( face1 != -1 ) {
-		t = triangleT( P, face1, ray, hit.t, tNear );
+		if( !EAGER ) {
+			second = loadTri( P, face1 );
+		}
+
+		t = triangleT( second, ray, hit.t, tNear );
 		faceTests++;
 
 		if( hit.t > t ) {
@@ -759,7 +786,7 @@ PT_DEV void nodePhaseAsm(
 // to one lane, i.e. the plain lock-step walk.  Rejected after measurement (bit-identical, slower):
 // waiting until EVERY lane stands on a leaf (dragon-class 0.65x), and requesting both successors
 // of a node before the slab test (a loss once registers are tight).
-template<bool ANYHIT, bool LIGHTS, bool USE_LDS, bool PHONG = false>
+template<bool ANYHIT, bool LIGHTS, bool USE_LDS, bool PHONG = false, bool EAGER = false>
 PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
 	const f3 invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
 	const float tLight = hit.t;
@@ -872,7 +899,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 				}
 			}
 #endif
-			testLeaf<PHONG>( P, leafFace0( leafWord ), leafFace1( leafWord ), ray, leafTNear, leafTFar, hit, faceTests );
+			testLeaf<PHONG, EAGER>( P, leafFace0( leafWord ), leafFace1( leafWord ), ray, leafTNear, leafTFar, hit, faceTests );
 
 			if( ANYHIT && hit.t < tLight ) {
 				walking = false;
@@ -1407,7 +1434,7 @@ PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
 // shade the hit, and — when the path / frame ends — fold it into the running mean and start the
 // next path.  Returns true when the pixel has had all P.nFrames frames; otherwise st.ray is the
 // next ray to trace.
-template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false>
 PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt, const Hit hit ) {
 	// references keep the shading code below in the reference's vocabulary
 	Ray& ray = st.ray;
@@ -1483,7 +1510,7 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 						lh.t = tLight;
 						lh.face = 0;
 						unsigned unusedNodes = 0;
-						traverse<true, LIGHTS, true, PHONG>( P, lds, lightRay, lh, unusedNodes, dbgTris );
+						traverse<true, LIGHTS, true, PHONG, EAGER>( P, lds, lightRay, lh, unusedNodes, dbgTris );
 						lightDir = lightRay.dir;
 
 						if( lh.t >= tLight ) {
@@ -1605,14 +1632,14 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 }
 
 // One bounce of the lane's current path: traverse (pathtracing.cl:259), then shadeStep.
-template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false>
 PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt ) {
 	Hit hit;
 	hit.t = inff();
 	hit.face = 0;
 	hit.normal = mk3( 0.0f, 0.0f, 0.0f );
-	traverse<false, LIGHTS, true, PHONG>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
-	return shadeStep<BRDF, SHADOW, LIGHTS, FP, PHONG>( P, lds, st, cnt, hit );
+	traverse<false, LIGHTS, true, PHONG, EAGER>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
+	return shadeStep<BRDF, SHADOW, LIGHTS, FP, PHONG, EAGER>( P, lds, st, cnt, hit );
 }
 
 // ---- the pixel-slot queue ----------------------------------------------------------------
@@ -1758,7 +1785,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 				break;
 			}
 #endif
-			if( stepPixel<BRDF, SHADOW, LIGHTS, true, PHONG>( P, lds, st, cnt ) ) {
+			if( stepPixel<BRDF, SHADOW, LIGHTS, true, PHONG, ( MINW <= 4 )>( P, lds, st, cnt ) ) {
 				finishPixel<true>( P, st );
 
 				if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
@@ -1792,7 +1819,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 			const long long guardMax = (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1;
 #endif
 
-			while( !stepPixel<BRDF, SHADOW, LIGHTS, false, PHONG>( P, lds, st, cnt ) ) {
+			while( !stepPixel<BRDF, SHADOW, LIGHTS, false, PHONG, ( MINW <= 4 )>( P, lds, st, cnt ) ) {
 #ifdef PBR_GUARD_PATH
 				if( ++guardSteps > guardMax ) {
 					atomicAdd( &P.guard[1], 1u );
@@ -2110,7 +2137,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 		// ---- leaf phase ---------------------------------------------------------------------
 		if( mode == MODE_LEAF ) {
 			PH_STAT( sLeafIt, sLeafAct )
-			testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
+			testLeaf<false, ( MINW <= 4 )>( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
 			mode = alive( w.cur ) ? MODE_NODE : MODE_SHADE;
 		}
 
@@ -2121,7 +2148,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 
 			if( mode == MODE_SHADE && ( nShade >= P.phShade || nNode == 0 ) ) {
 				PH_STAT( sShadeIt, sShadeAct )
-				if( shadeStep<BRDF, SHADOW, LIGHTS, true>( P, lds, st, cnt, w.hit ) ) {
+				if( shadeStep<BRDF, SHADOW, LIGHTS, true, false, ( MINW <= 4 )>( P, lds, st, cnt, w.hit ) ) {
 					finishPixel<true>( P, st );
 
 					if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
