@@ -646,11 +646,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	}
 
 	if( ctx->frameBufFrames < chunkCap ) {
+		// sized once for renders of up to 256 frames (or the cap): a longer render after a short one must not pay
+		// for a multi-GB reallocation (288 GB of HBM: 8.5 GB at 1080p is not the constraint)
+		const size_t frames = std::max<size_t>( chunkCap, std::min<size_t>( 256, std::max<size_t>( 1, kFrameBufBytes / frameBytes ) ) );
 		(void) hipFree( ctx->dFrameBuf );
 		ctx->dFrameBuf = nullptr;
 		ctx->frameBufFrames = 0;
-		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dFrameBuf, frameBytes * chunkCap ) );
-		ctx->frameBufFrames = chunkCap;
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dFrameBuf, frameBytes * frames ) );
+		ctx->frameBufFrames = frames;
 	}
 
 	P.frameBuf = ctx->dFrameBuf;
