@@ -2,10 +2,12 @@
 // It exposes the host half of the path — config, scene load / generation, BVH build,
 // buffer packing, camera, PathTracer driver — with plain pointers, so the harness can hand the
 // SAME flat arrays to the HIP core (libpbrhip.so) and to the CPU oracle.
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "Cfg.h"
 #include "bvh_builder.h"
@@ -349,6 +351,60 @@ int pbrh_cl_adaptor_render( void* scene, uint32_t frames, float seedStep, float*
 		gError = e.what();
 		return -1;
 	}
+}
+
+
+// ---- image files (the writer the reference never had — it links DevIL without using it) ----
+// PPM (P6) from RGBA8 as pbr_read_display( top_row_first = 1 ) returns it; PFM (PF, little endian, bottom row first —
+// the format's own convention and pbr_read_output's) from the linear float image.  Return 0 / -1.
+int pbrh_write_ppm( const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height ) {
+	FILE* f = ( path != nullptr && rgba8 != nullptr ) ? std::fopen( path, "wb" ) : nullptr;
+
+	if( f == nullptr ) {
+		gError = std::string( "cannot write " ) + ( path ? path : "(null)" );
+		return -1;
+	}
+
+	std::fprintf( f, "P6\n%u %u\n255\n", width, height );
+	std::vector<uint8_t> row( (size_t) width * 3 );
+
+	for( uint32_t y = 0; y < height; y++ ) {
+		for( uint32_t x = 0; x < width; x++ ) {
+			const uint8_t* px = rgba8 + ( (size_t) y * width + x ) * 4;
+			row[(size_t) x * 3 + 0] = px[0];
+			row[(size_t) x * 3 + 1] = px[1];
+			row[(size_t) x * 3 + 2] = px[2];
+		}
+
+		std::fwrite( row.data(), 1, row.size(), f );
+	}
+
+	return ( std::fclose( f ) == 0 ) ? 0 : -1;
+}
+
+int pbrh_write_pfm( const char* path, const float* rgba, uint32_t width, uint32_t height ) {
+	FILE* f = ( path != nullptr && rgba != nullptr ) ? std::fopen( path, "wb" ) : nullptr;
+
+	if( f == nullptr ) {
+		gError = std::string( "cannot write " ) + ( path ? path : "(null)" );
+		return -1;
+	}
+
+	std::fprintf( f, "PF\n%u %u\n-1.0\n", width, height );
+	std::vector<float> row( (size_t) width * 3 );
+
+	for( uint32_t y = 0; y < height; y++ ) {
+		for( uint32_t x = 0; x < width; x++ ) {
+			const float* px = rgba + ( (size_t) y * width + x ) * 4;
+			row[(size_t) x * 3 + 0] = px[0];
+			row[(size_t) x * 3 + 1] = px[1];
+			row[(size_t) x * 3 + 2] = px[2];
+		}
+
+		std::fwrite( row.data(), sizeof( float ), row.size(), f );
+	}
+
+	return ( std::fclose( f ) == 0 ) ? 0 : -1;
 }
 
 }  // extern "C"

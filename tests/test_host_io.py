@@ -186,3 +186,22 @@ def test_reference_assets_load(cfg_defaults, name, faces, objects):
     assert sc.info["faces"] == faces and sc.info["objects"] == objects
     arr = sc.arrays()
     assert arr["facesV"][:, :3].max() < sc.info["vertices"]
+
+
+def test_image_writers_round_trip(cfg_defaults, tmp_path):
+    """pbrh_write_ppm / pbrh_write_pfm: the display image and the linear image as files."""
+    pbr = cfg_defaults
+    rng = np.random.default_rng(2)
+    rgba8 = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    pbr.write_ppm(tmp_path / "a.ppm", rgba8)
+    raw = (tmp_path / "a.ppm").read_bytes()
+    assert raw.startswith(b"P6\n7 5\n255\n")
+    assert np.array_equal(np.frombuffer(raw[len(b"P6\n7 5\n255\n"):], np.uint8).reshape(5, 7, 3), rgba8[..., :3])
+    lin = rng.normal(size=(4, 6, 4)).astype(np.float32)
+    pbr.write_pfm(tmp_path / "b.pfm", lin)
+    raw = (tmp_path / "b.pfm").read_bytes()
+    head = b"PF\n6 4\n-1.0\n"
+    assert raw.startswith(head)
+    assert np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(4, 6, 3), lin[..., :3])
+    with pytest.raises(pbr.PbrError):
+        pbr.write_ppm(tmp_path / "no" / "dir.ppm", rgba8)
