@@ -4,6 +4,7 @@ on whole images, plus size-independent properties at BASELINE.json's full resolu
 Every test here needs a real MI355X."""
 import ctypes
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -560,6 +561,34 @@ def test_phong_tessellation_bit_exact(pbr, oracle, device, tmp_path, brdf):
             device.render(0, pbr.frame_seeds(0, 1), pbr.pixel_dimension(w, h), sc.camera())
         finally:
             del os.environ["PBR_SCHEDULE"]
+
+
+def test_guard_build_with_the_cxx_node_phase_gives_the_same_bits(pbr, device, tmp_path):
+    """libpbrhip_guard.so (-DPBR_GUARD) bounds every device loop and compiles traverse()'s node phase from C++ instead
+    of the hand-scheduled block: same images, no guard trips.  Run in a child process (the library is chosen at import)."""
+    sc = make_scene(pbr, "sponza", 4, 9000, **{"render.max_depth": 3})
+    w, h = 64, 40
+    device.upload_scene(sc.desc)
+    device.configure(sc.config(w, h))
+    device.render(0, pbr.frame_seeds(0, 3), pbr.pixel_dimension(w, h), sc.camera())
+    want = device.read_output()
+    script = tmp_path / "guarded.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import pbr_loader\n"
+        "pbr = pbr_loader.load()\n"
+        "pbr.cfg_reset(); pbr.cfg_set(**{'render.max_depth': 3})\n"
+        "sc = pbr.HostScene.generate('sponza', 4, 9000)\n"
+        "dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(sc.config(%d, %d))\n"
+        "dev.render(0, pbr.frame_seeds(0, 3), pbr.pixel_dimension(%d, %d), sc.camera())\n"
+        "assert dev.guard_trips() == [0, 0, 0], dev.guard_trips()\n"
+        "np.save(%r, dev.read_output())\n" % (ROOT, w, h, w, h, str(tmp_path / "guarded.npy")))
+    env = dict(os.environ, PBR_GUARD="1")
+    done = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    got = np.load(tmp_path / "guarded.npy")
+    assert same_values(got, want), describe_mismatch(got, want)
 
 
 def test_display_step_is_the_clamped_linear_image(pbr, device):
