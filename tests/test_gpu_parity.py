@@ -563,6 +563,48 @@ def test_phong_tessellation_bit_exact(pbr, oracle, device, tmp_path, brdf):
             del os.environ["PBR_SCHEDULE"]
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_bit_exact(pbr, oracle, device, monkeypatch, seed):
+    """Seeded differential sweep over the configuration space: scene kind / size, image shape, depths, samples,
+    BRDF, anti-aliasing, lights + shadow rays, schedule, register budget, LDS share, frames per launch pair."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["cornell", "sponza", "dragon", "hairball"][rng.integers(4)]
+    tris = 0 if kind == "cornell" else int(rng.integers(300, 6000))
+    brdf = int(rng.integers(2))
+    cfg_keys = {
+        "render.max_depth": int(rng.integers(1, 6)), "render.max_added_depth": int(rng.integers(0, 4)),
+        "render.samples": int(rng.integers(1, 4)), "render.brdf": brdf,
+        "render.antialiasing": float(rng.choice([0.0, 0.7, 1.5])),
+    }
+    schedule = ["refill", "phased", "tile", "batched", "wavefront", None][rng.integers(6)]
+    if schedule is not None:
+        monkeypatch.setenv("PBR_SCHEDULE", schedule)
+    if rng.integers(2):
+        monkeypatch.setenv("PBR_VARIANT", ["lean", "wide"][rng.integers(2)])
+    if rng.integers(3) == 0:
+        monkeypatch.setenv("PBR_LDS_SLOTS", str(int(rng.integers(0, 200))))
+    if rng.integers(2):
+        monkeypatch.setenv("PBR_CHUNK_FRAMES", str(int(rng.integers(1, 4))))
+    w, h = 8 * int(rng.integers(1, 12)), 8 * int(rng.integers(1, 9))
+    frames = int(rng.integers(1, 6))
+    first = int(rng.integers(0, 3))
+    sc = make_scene(pbr, kind, int(rng.integers(1, 100)), tris, **cfg_keys)
+    cfg, desc, keep = sc.config(w, h), sc.desc, None
+    if kind == "cornell" and rng.integers(2):
+        lights = np.zeros((2, 12), np.float32)
+        lights[0] = [0.1, 1.6, 0.2, 0, 4.0, 3.5, 3.0, 0, 2, 0.12, 0, 0]
+        lights[1] = [-0.5, 0.4, 0.6, 0, 1, 1, 1, 0, 1, 0, 0, 0]
+        desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
+        desc.lights, desc.num_lights = lights.ctypes.data, 2
+        keep = lights
+        cfg.shadow_rays = int(rng.integers(2))
+    what = "%s tris=%d %dx%d frames=%d first=%d %s schedule=%s" % (kind, tris, w, h, frames, first, cfg_keys, schedule)
+    got, want, ref = both_render(pbr, oracle, device, sc, w, h, frames, first=first, cfg=cfg, desc=desc)
+    assert same_values(got, want), what + ": " + describe_mismatch(got, want)
+    assert same_values(device.read_debug(), ref.debug), what
+    assert device.counters() == ref.counter_dict(), what
+
+
 def test_guard_build_with_the_cxx_node_phase_gives_the_same_bits(pbr, device, tmp_path):
     """libpbrhip_guard.so (-DPBR_GUARD) bounds every device loop and compiles traverse()'s node phase from C++ instead
     of the hand-scheduled block: same images, no guard trips.  Run in a child process (the library is chosen at import)."""
