@@ -54,6 +54,9 @@ def build_hip(force=False, guard=False):
         return target
     cmd = [
         _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+        # hipcc's SLP vectoriser packs adjacent scalar f32 operations into v_pk_* instructions, which issue at
+        # half rate on gfx950 and need v_mov shuffles + hazard s_nops around them: same bits, 3-9 % slower kernels
+        "-fno-slp-vectorize",
         "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC, *(["-DPBR_GUARD=1"] if guard else []),
         "-o", target, os.path.join(CSRC, "pbr_hip.hip"),
     ]
