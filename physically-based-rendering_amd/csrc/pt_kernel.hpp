@@ -1,18 +1,21 @@
-// The path-tracing megakernel for gfx950.
+// The path-tracing kernels for gfx950.
 //
 // Replaces source/opencl/pathtracing.cl + pt_*.cl (one OpenCL work-item per pixel, one launch
 // per frame, accumulation through the host).  Here:
-//   * a wave64 owns one 8x8-pixel tile at a time, taken from a device-wide work counter
-//     (persistent waves: the grid is sized to the chip, not to the image);
-//   * each lane walks its pixel through ALL requested frames; a lane whose path ends starts its
-//     next path immediately (lane-local regeneration), so a wave iteration = one traversal +
-//     one shading step for 64 live paths regardless of how long individual paths are;
-//   * the running mean (pt_rgb.cl:9-21) stays in registers across frames; the framebuffer is
-//     tile-major (64 px x RGBA32F = 1 KiB per tile), so a wave reads / writes its tile with one
-//     fully coalesced 16 B-per-lane access;
-//   * BVH nodes stay 32 B (one node = two adjacent dwordx4 loads, links pre-converted to int);
-//     triangles are pre-gathered per face as {a, b-a, c-a, material} = 48 B, removing the
-//     facesV -> vertices indirection of pt_intersect.cl:146-149.
+//   * persistent waves (the grid is sized to the chip, not to the image) draw units of work — one
+//     frame of one pixel — from an XCD-banded queue (nextSlot); a lane whose path ends starts its next
+//     path, and a lane whose unit ends takes the next unit, in the same wave iteration;
+//   * a multi-frame render is ONE launch over all (pixel, frame) units; each writes {finalColor, focus}
+//     to a frame buffer and foldFrames applies the running mean (pt_rgb.cl:9-21) in frame order.  (The
+//     tile schedule, REFILL = false, keeps the older form: a wave walks a tile through all frames with
+//     the mean in registers.)  The framebuffer is tile-major (64 px x RGBA32F = 1 KiB per tile);
+//   * the BVH is a node stream of 32-B records with explicit successors, the most-visited records first
+//     and staged in LDS (decodeNode); the walk alternates a hand-scheduled node phase with a leaf phase
+//     for the lanes parked on hit leaves (traverse, nodePhaseAsm);
+//   * triangles are pre-gathered per face as {a, b-a, c-a, material} = 48 B, removing the
+//     facesV -> vertices indirection of pt_intersect.cl:146-149;
+//   * two ways to keep lanes busy: pathTracing (lock step per bounce) and pathTracingPhased (a lane
+//     state machine); the host times both on the scene and keeps the faster (pbr_hip.hip, launch()).
 // Per-pixel results are bit-identical to the per-frame reference schedule: a pixel's value
 // depends only on (seed_k, scene, its own previous value), pathtracing.cl:28,255,332.
 #pragma once
@@ -1717,31 +1720,26 @@ PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, u
 	return PT_NO_WORK;
 }
 
-// Work distribution.  EVERY lane draws pixel slots from one device-wide counter with a plain
-// per-lane atomicAdd( counter, 1 ); hipcc folds the adds of the lanes that are active at that
-// point into one wave-level add (v_mbcnt + s_bcnt1 + a single global_atomic_add) and hands
-// each lane base + its rank — the ballot / prefix-sum refill, done by the compiler.  Slots are
-// tile-major, so lanes that fetch together work on neighbouring pixels and their framebuffer
-// accesses coalesce; correctness does not depend on it (slot -> pixel is a bijection).
+// Work distribution: nextSlot() above.  EVERY lane draws its units with a plain per-lane atomicAdd( head, 1 );
+// hipcc folds the adds of the lanes that are active at that point into one wave-level add (v_mbcnt +
+// s_bcnt1 + a single global_atomic_add) and hands each lane base + its rank — the ballot / prefix-sum
+// refill, done by the compiler.  Slots are tile-major, so lanes that fetch together work on neighbouring
+// pixels and their framebuffer accesses coalesce; correctness does not depend on it.
 //
-//   REFILL = true   one merged per-lane loop: a lane whose pixel is finished (all frames) takes
-//                   the next slot at once while its neighbours keep tracing — no lane waits for
-//                   the slowest pixel of a tile.  For launches of many frames.
-//   REFILL = false  nested loops: the lanes of a wave reconverge after each pixel, i.e. a wave
-//                   walks whole 8x8 tiles like an OpenCL work-group of the reference does
-//                   (one atomic per tile).  For single-frame launches, where a per-path refill
-//                   would cost one atomic per path.
+//   REFILL = true   frame-parallel: the unit is one frame of one pixel; a lane whose unit is finished takes the
+//                   next one at once while its neighbours keep tracing.  The default for every launch.
+//   REFILL = false  the tile schedule (PBR_SCHEDULE=tile): the lanes of a wave reconverge after each pixel, i.e.
+//                   a wave walks whole 8x8 tiles through all frames like an OpenCL work-group of the reference.
 //
 // (A lane-0 atomic + readfirstlane + wave-uniform `break` formulation of this loop was
 // miscompiled by ROCm 7.2 hipcc into an endless re-run of tile 0 on gfx950 — DESIGN.md,
 // "Toolchain notes" — hence the deliberately per-lane control flow.)
 // Block = 1024 threads (16 waves): one or two blocks own a CU's 160 KB of LDS for the staged tree
 // top.  MINW = waves per SIMD the register allocation must admit (__launch_bounds__):
-//   4  "lean"  <= 128 VGPRs, 1 block / CU — no spills; best when the scene fits the caches and
-//              the kernel is bound by its own arithmetic (Cornell-class);
-//   8  "wide"  <= 64 VGPRs, 2 blocks / CU — the traversal loop stays spill-free (it needs ~45
-//              registers), the shading code spills to scratch; twice the waves to hide the latency
-//              of dependent node fetches, +45-70 % on the 260k - 2M triangle scenes.
+//   4  "lean"  <= 128 VGPRs, 1 block / CU — no spills; best when the kernel is bound by its own
+//              arithmetic (Cornell-class) and for the lane state machine on the largest scenes;
+//   8  "wide"  <= 64 VGPRs, 2 blocks / CU — the walk stays spill-free, the shading code spills to
+//              scratch; twice the waves to hide the latency of dependent node fetches.
 #ifndef PBR_BLOCK
 #define PBR_BLOCK 1024
 #endif
