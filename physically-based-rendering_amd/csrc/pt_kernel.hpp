@@ -1115,6 +1115,7 @@ PT_DEV f3 newRaySchlick( f3 dir, f3 normal, const Material& mtl, float& seed ) {
 // ---------------------------------------------------------------------------------------
 
 // brdfShirleyAshikhmin, pt_brdf.cl:228-268
+template<bool CALLS = false>
 PT_DEV void brdfSA(
 	const Material& mtl, f3 outDir, f3 inDir, f3 normal,
 	float* brdfSpec, float* brdfDiff, float* dotHK1, float* pdf
@@ -1137,7 +1138,7 @@ PT_DEV void brdfSA(
 	float ps_e = nu * dotHU * dotHU + nv * dotHV * dotHV;
 	ps_e = ( dotHN == 1.0f ) ? 0.0f : ps_e / ( 1.0f - dotHN * dotHN );
 	const float ps0 = (float) ( (double) ( sqrt1( ( nu + 1.0f ) * ( nv + 1.0f ) ) * 0.125f ) * M_1_PI_D );
-	const float ps1_num = pow1( dotHN, ps_e );
+	const float ps1_num = powSelect<CALLS>( dotHN, ps_e );
 	const float ps1 = ps1_num / ( hk1 * fmax1( dotNK1, dotNK2 ) );
 
 	float pd = mtl.Rd * 0.38750768752f;
@@ -1152,6 +1153,7 @@ PT_DEV void brdfSA(
 }
 
 // newRayShirleyAshikhmin, pt_brdf.cl:278-330
+template<bool CALLS = false>
 PT_DEV f3 newRaySA( f3 dir, f3 rayNormal, const Material& mtl, float& seed ) {
 	const float nu = mtl.p2, nv = mtl.p3;
 	float a = rnd( seed );
@@ -1184,7 +1186,7 @@ PT_DEV f3 newRaySA( f3 dir, f3 rayNormal, const Material& mtl, float& seed ) {
 	float sinphi, cosphi;
 	sincos( phi, &sinphi, &cosphi );
 	const float theta_e = 1.0f / ( nu * cosphi * cosphi + nv * sinphi * sinphi + 1.0f );
-	const float theta = acos1( pow1( 1.0f - b, theta_e ) );
+	const float theta = acos1( powSelect<CALLS>( 1.0f - b, theta_e ) );
 
 	const f3 normal = ( mtl.d < 1.0f || dot( rayNormal, -dir ) >= 0.0f ) ? rayNormal : -rayNormal;
 
@@ -1225,7 +1227,7 @@ PT_DEV f3 refract( f3 dir, f3 normal, const Material& mtl, float& seed ) {
 }
 
 // getNewRay, pt_brdf.cl:344-378 (direction only; the origin is fma( t, dir, origin ))
-template<int BRDF>
+template<int BRDF, bool CALLS = false>
 PT_DEV f3 newRayDir( f3 dir, f3 normal, const Material& mtl, float& seed, bool& addDepth ) {
 	// && short-circuits: the random number is drawn only when d < 1
 	bool doTransRefr = false;
@@ -1240,11 +1242,11 @@ PT_DEV f3 newRayDir( f3 dir, f3 normal, const Material& mtl, float& seed, bool& 
 		return refract( dir, normal, mtl, seed );
 	}
 
-	return ( BRDF == 0 ) ? newRaySchlick( dir, normal, mtl, seed ) : newRaySA( dir, normal, mtl, seed );
+	return ( BRDF == 0 ) ? newRaySchlick( dir, normal, mtl, seed ) : newRaySA<CALLS>( dir, normal, mtl, seed );
 }
 
 // The factor updateColor multiplies `color` by (pathtracing.cl:98-124 Schlick, :127-177 S-A).
-template<int BRDF>
+template<int BRDF, bool CALLS = false>
 PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal ) {
 	const float d = mtl.d;
 
@@ -1260,7 +1262,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal ) {
 	}
 
 	float spec, diff, dotHK1, pdf;
-	brdfSA( mtl, outDir, inDir, normal, &spec, &diff, &dotHK1, &pdf );
+	brdfSA<CALLS>( mtl, outDir, inDir, normal, &spec, &diff, &dotHK1, &pdf );
 	spec = spec / pdf;
 	diff = diff / pdf;
 
@@ -1277,7 +1279,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal ) {
 
 // The shadow-ray contribution to finalColor (pathtracing.cl:102-115 Schlick, :133-154 S-A).
 // Returns false when |pdf| <= 1e-5 (no contribution, secondaryPaths unchanged).
-template<int BRDF>
+template<int BRDF, bool CALLS = false>
 PT_DEV bool shadowContribution(
 	const Material& mtl, f3 outDir, f3 lightDir, f3 normal, f3 color, f3 lightRgb, f3* add
 ) {
@@ -1301,7 +1303,7 @@ PT_DEV bool shadowContribution(
 	}
 
 	float spec, diff, dotHK1, pdf;
-	brdfSA( mtl, outDir, lightDir, normal, &spec, &diff, &dotHK1, &pdf );
+	brdfSA<CALLS>( mtl, outDir, lightDir, normal, &spec, &diff, &dotHK1, &pdf );
 
 	if( !( __builtin_fabsf( pdf ) > 0.00001f ) ) {
 		return false;
@@ -1437,7 +1439,8 @@ PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
 // shade the hit, and — when the path / frame ends — fold it into the running mean and start the
 // next path.  Returns true when the pixel has had all P.nFrames frames; otherwise st.ray is the
 // next ray to trace.
-template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false>
+// CALLS: pow as a function call instead of inline (pt_math.hpp, pow1Call) — every kernel but the lean lock-step one
+template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false, bool CALLS = !EAGER>
 PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt, const Hit hit ) {
 	// references keep the shading code below in the reference's vocabulary
 	Ray& ray = st.ray;
@@ -1525,7 +1528,7 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 				}
 
 				// getNewRay, pt_brdf.cl:344-378 — uses the UNflipped normal
-				const f3 newDir = newRayDir<BRDF>( ray.dir, normal, mtl, seed, addDepth );
+				const f3 newDir = newRayDir<BRDF, CALLS>( ray.dir, normal, mtl, seed, addDepth );
 
 				// pathtracing.cl:298-300
 				if( dot( normal, -ray.dir ) <= 0.0f ) {
@@ -1537,14 +1540,14 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 					if( lit ) {
 						f3 add;
 
-						if( shadowContribution<BRDF>( mtl, ray.dir, lightDir, normal, color, lightRgb, &add ) ) {
+						if( shadowContribution<BRDF, CALLS>( mtl, ray.dir, lightDir, normal, color, lightRgb, &add ) ) {
 							finalColor = finalColor + add;
 							secondaryPaths += 1;
 						}
 					}
 				}
 
-				color = color * throughput<BRDF>( mtl, ray.dir, newDir, normal );
+				color = color * throughput<BRDF, CALLS>( mtl, ray.dir, newDir, normal );
 
 				depthAdded += ( addDepth && depthAdded < P.maxAddedDepth ) ? 1 : 0;
 
@@ -2146,7 +2149,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 
 			if( mode == MODE_SHADE && ( nShade >= P.phShade || nNode == 0 ) ) {
 				PH_STAT( sShadeIt, sShadeAct )
-				if( shadeStep<BRDF, SHADOW, LIGHTS, true, false, ( MINW <= 4 )>( P, lds, st, cnt, w.hit ) ) {
+				if( shadeStep<BRDF, SHADOW, LIGHTS, true, false, ( MINW <= 4 ), true>( P, lds, st, cnt, w.hit ) ) {
 					finishPixel<true>( P, st );
 
 					if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
