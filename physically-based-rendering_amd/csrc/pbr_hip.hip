@@ -57,13 +57,13 @@ struct pbr_ctx {
 	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
 	// frames that are rendered anyway, then the fastest one is kept
 	int tunedPlan = -1;
-	double tuneMs[4] = { 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
-	uint32_t tuneFrames[4] = { 0, 0, 0, 0 };
+	double tuneMs[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
+	uint32_t tuneFrames[5] = { 0, 0, 0, 0, 0 };
 	int refineCount = 0;                            // refinement: the plans within 10 % of the fastest (at least two) again, on longer chunks
-	int refinePlan[4] = { -1, -1, -1, -1 };
+	int refinePlan[5] = { -1, -1, -1, -1, -1 };
 	uint32_t refineChunks = 0;                      // chunks rendered so far in the refinement
-	double refineMs[4] = { 0.0, 0.0, 0.0, 0.0 };
-	uint32_t refineFrames[4] = { 0, 0, 0, 0 };
+	double refineMs[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+	uint32_t refineFrames[5] = { 0, 0, 0, 0, 0 };
 	char lastPlan[48] = "";        // name of the plan that rendered the largest chunk of the last render
 	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
 	uint32_t lastTraceLaunches = 0; // ... and how many there were (frame-parallel renders are chunked)
@@ -230,6 +230,14 @@ KernelFn pickKernelPhasedMode( uint32_t brdf, bool shadow, bool lights ) {
 
 KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) {
 	return wide ? pickKernelPhasedMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelPhasedMode<PBR_LEAN_MINW>( brdf, shadow, lights );
+}
+
+// the "mid" budget: <= 80 VGPRs, launched as two 768-thread blocks per CU = 6 waves / SIMD
+const int kMidMinWaves = 6;
+const int kMidBlockThreads = 768;
+
+KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
+	return pickKernelPhasedMode<kMidMinWaves>( brdf, shadow, lights );
 }
 
 // Register budget when a schedule is forced (PBR_SCHEDULE) without PBR_VARIANT: scenes whose tree does
@@ -471,13 +479,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// split between the blocks the register budget admits.
 	struct Plan {
 		KernelFn kernel;
-		int blocks, numHot, park, shade, parkEighths;
+		int blocks, blockThreads, numHot, park, shade, parkEighths;
 		size_t ldsBytes;
 		const char* name;
 	};
 
-	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan ) -> int {
-		const int blockThreads = PBR_BLOCK;
+	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK ) -> int {
 		const int wavesPerBlock = blockThreads / 64;
 		int blocksPerCU = 0;
 		HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, blockThreads, 0 ) );
@@ -502,6 +509,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		const int needed = ( ctx->numLocalTiles + wavesPerBlock - 1 ) / wavesPerBlock;
 		blocks = ( blocks > needed ) ? needed : blocks;
 		plan->kernel = kernel;
+		plan->blockThreads = blockThreads;
 		plan->blocks = ( blocks < 1 ) ? 1 : blocks;
 		plan->numHot = (int) slots;
 		plan->ldsBytes = slots * 32;
@@ -528,7 +536,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
 		P.parkEighths = plan.parkEighths;
-		hipLaunchKernelGGL( plan.kernel, dim3( (unsigned) plan.blocks ), dim3( (unsigned) PBR_BLOCK ), plan.ldsBytes, ctx->stream, P );
+		hipLaunchKernelGGL( plan.kernel, dim3( (unsigned) plan.blocks ), dim3( (unsigned) plan.blockThreads ), plan.ldsBytes, ctx->stream, P );
 		HIP_TRY( ctx, hipGetLastError() );
 		return PBR_OK;
 	};
@@ -575,14 +583,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// longer renders run as several launch pairs.
 	//
 	// Which kernel: the lock-step walk ("refill") or the lane state machine ("phased"), each with the
-	// lean (4 waves / SIMD, no spills) or the wide (8 waves / SIMD) register budget.  Which one wins
+	// lean (4 waves / SIMD, no spills) or the wide (8 waves / SIMD) register budget, the state machine also at 6.  Which one wins
 	// depends on the scene (1080p: Cornell refill-lean 3470 vs phased-lean 2760 Msamples/s, dragon-class
 	// phased-lean 1380 vs refill-wide 1000), and all of them give the same bits — so the first frames
 	// of a scene + configuration, which have to be rendered anyway, are rendered in turn by each
 	// candidate (kTuneFrames each) and timed; short launches favour the plans with fewer, larger blocks,
-	// so the plans within 10 % of the fastest (at least two) are timed again on 2 x kRefineChunk frames each, in the
-	// order A B C C B A, before the fastest is kept.
-	const int kPlans = 4;
+	// so the two or three fastest (the third only if within 10 % of the first) are timed again on 2 x kRefineChunk frames
+	// each, in the order A B C C B A, before the fastest is kept.
+	const int kPlans = 5;
 	const uint32_t kTuneFrames = 2;
 	const uint32_t kRefineChunk = 8;     // refinement: two chunks of this many frames per plan
 	Plan plans[kPlans];
@@ -592,6 +600,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernel( brdf, shadow, lights, true, true ), "refill-wide", 0, 0, &plans[1] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 48, &plans[3] );
+		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhasedMid( brdf, shadow, lights ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads );
 
 		if( status != PBR_OK ) {
 			return status;
@@ -745,12 +754,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			if( ctx->tuneFrames[kPlans - 1] >= kTuneFrames ) {
 				// screening done: every plan within 10 % of the fastest — at least the two fastest — goes on to the refinement
 				auto perFrame = [&]( int k ) { return ctx->tuneMs[k] / ctx->tuneFrames[k]; };
-				int order[kPlans] = { 0, 1, 2, 3 };
+				int order[kPlans] = { 0, 1, 2, 3, 4 };
 				std::sort( order, order + kPlans, [&]( int x, int y ) { return perFrame( x ) < perFrame( y ); } );
 				ctx->refineCount = 0;
 
 				for( int k = 0; k < kPlans; k++ ) {
-					if( k < 2 || perFrame( order[k] ) <= 1.10 * perFrame( order[0] ) ) {
+					if( k < 2 || ( k < 3 && perFrame( order[k] ) <= 1.10 * perFrame( order[0] ) ) ) {
 						ctx->refinePlan[ctx->refineCount++] = order[k];
 					}
 				}
