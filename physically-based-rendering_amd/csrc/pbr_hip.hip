@@ -57,13 +57,14 @@ struct pbr_ctx {
 	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
 	// frames that are rendered anyway, then the fastest one is kept
 	int tunedPlan = -1;
-	double tuneMs[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
-	uint32_t tuneFrames[5] = { 0, 0, 0, 0, 0 };
+	uint32_t tuneRenderFrames = 0;                  // the longest render (frames per call) this context has been asked for
+	double tuneMs[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
+	uint32_t tuneFrames[6] = { 0, 0, 0, 0, 0, 0 };
 	int refineCount = 0;                            // refinement: the plans within 10 % of the fastest (at least two) again, on longer chunks
-	int refinePlan[5] = { -1, -1, -1, -1, -1 };
+	int refinePlan[6] = { -1, -1, -1, -1, -1, -1 };
 	uint32_t refineChunks = 0;                      // chunks rendered so far in the refinement
-	double refineMs[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
-	uint32_t refineFrames[5] = { 0, 0, 0, 0, 0 };
+	double refineMs[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+	uint32_t refineFrames[6] = { 0, 0, 0, 0, 0, 0 };
 	char lastPlan[48] = "";        // name of the plan that rendered the largest chunk of the last render
 	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
 	uint32_t lastTraceLaunches = 0; // ... and how many there were (frame-parallel renders are chunked)
@@ -240,9 +241,15 @@ KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
 	return pickKernelPhasedMode<kMidMinWaves>( brdf, shadow, lights );
 }
 
+KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights );
+
 // Register budget when a schedule is forced (PBR_SCHEDULE) without PBR_VARIANT: scenes whose tree does
 // not fit the staged LDS prefix get "wide" (pt_kernel.hpp), small scenes "lean".  Unforced renders are auto-tuned.
 const uint32_t kWideMinNodes = 2048;
+
+KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights ) {
+	return pickKernelMode<true, kMidMinWaves>( brdf, shadow, lights );
+}
 
 // PHONGTESS == 1: the refill schedule in the wide budget only (the long cubic solve spills either way)
 KernelFn pickKernelPhong( uint32_t brdf, bool shadow, bool lights ) {
@@ -590,7 +597,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// candidate (kTuneFrames each) and timed; short launches favour the plans with fewer, larger blocks,
 	// so the two or three fastest (the third only if within 10 % of the first) are timed again on 2 x kRefineChunk frames
 	// each, in the order A B C C B A, before the fastest is kept.
-	const int kPlans = 5;
+	const int kPlans = 6;
 	const uint32_t kTuneFrames = 2;
 	const uint32_t kRefineChunk = 8;     // refinement: two chunks of this many frames per plan
 	Plan plans[kPlans];
@@ -601,6 +608,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 48, &plans[3] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhasedMid( brdf, shadow, lights ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads );
+		status = ( status != PBR_OK ) ? status : makePlan( pickKernelMid( brdf, shadow, lights ), "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
 
 		if( status != PBR_OK ) {
 			return status;
@@ -665,6 +673,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		ctx->frameBufFrames = frames;
 	}
 
+	ctx->tuneRenderFrames = std::max( ctx->tuneRenderFrames, nFrames );
 	P.frameBuf = ctx->dFrameBuf;
 	P.frameStride = (unsigned) pixelSlots;
 	const unsigned foldBlocks = (unsigned) ( ( pixelSlots + 255 ) / 256 );
@@ -754,7 +763,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			if( ctx->tuneFrames[kPlans - 1] >= kTuneFrames ) {
 				// screening done: every plan within 10 % of the fastest — at least the two fastest — goes on to the refinement
 				auto perFrame = [&]( int k ) { return ctx->tuneMs[k] / ctx->tuneFrames[k]; };
-				int order[kPlans] = { 0, 1, 2, 3, 4 };
+				int order[kPlans] = { 0, 1, 2, 3, 4, 5 };
 				std::sort( order, order + kPlans, [&]( int x, int y ) { return perFrame( x ) < perFrame( y ); } );
 				ctx->refineCount = 0;
 
@@ -772,11 +781,25 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			ctx->refineChunks++;
 
 			if( ctx->refineChunks >= 2u * (uint32_t) ctx->refineCount ) {
-				int best = 0;
+				// A launch costs a + b x frames (a: ramp-up and drain, 0.3 - 0.6 ms; b: the per-frame rate), and the plans
+				// differ in both: from the screening launch (kTuneFrames frames) and the refinement launches (kRefineChunk
+				// frames) of each finalist, estimate a and b and compare the cost of a render as long as this caller's.
+				const double n = (double) std::max<uint32_t>( ctx->tuneRenderFrames, 1u );
+				int best = -1;
+				double bestCost = 0.0;
 
-				for( int k = 1; k < ctx->refineCount; k++ ) {
-					if( ctx->refineMs[k] / ctx->refineFrames[k] < ctx->refineMs[best] / ctx->refineFrames[best] ) {
+				for( int k = 0; k < ctx->refineCount; k++ ) {
+					const int plan = ctx->refinePlan[k];
+					const double tShort = ctx->tuneMs[plan] * (double) kTuneFrames / ctx->tuneFrames[plan];
+					const double tLong = ctx->refineMs[k] * (double) kRefineChunk / ctx->refineFrames[k];
+					double b = ( tLong - tShort ) / (double) ( kRefineChunk - kTuneFrames );
+					b = std::max( b, 0.0 );
+					const double a = std::max( tLong - b * (double) kRefineChunk, 0.0 );
+					const double cost = ( a + b * n ) / n;
+
+					if( best < 0 || cost < bestCost ) {
 						best = k;
+						bestCost = cost;
 					}
 				}
 
