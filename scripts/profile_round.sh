@@ -9,7 +9,7 @@ for s in cornell sponza dragon hairball; do
   steps=64; [ $s = cornell ] && steps=256
   timeout 300 python3 bench.py --scene $s --steps $steps > $out/bench_$s.json 2> $out/bench_$s.err
   # the profiled runs use the schedule the tuner settled on in the plain run (PBR_PLAN: no tuning launches under the profiler)
-  plan=$(python3 -c "import json,sys; n=json.loads(open('$out/bench_$s.json').read().strip().splitlines()[-1]).get('schedule','refill-lean'); print(['refill-lean','refill-wide','phased-lean','phased-wide'].index(n))")
+  plan=$(python3 -c "import json,sys; n=json.loads(open('$out/bench_$s.json').read().strip().splitlines()[-1]).get('schedule','refill-lean'); print(['refill-lean','refill-wide','phased-lean','phased-wide','phased-mid','refill-mid'].index(n))")
   export PBR_PLAN=$plan
   cd /tmp
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats_$s -- python3 $R/bench.py --scene $s --steps $steps --cpu-seconds 0 > $R/$out/stats_$s.json 2> /dev/null
