@@ -7,9 +7,9 @@ One "step" = one frame = one pass of the hot path over every pixel (SAMPLES = 1 
 the reference's default).  The K timed steps run as ONE pbr_render call = one path-tracing launch
 over all (pixel, frame) units + one foldFrames launch that applies the running mean in frame order
 (several such pairs only if K frames x 16 B x pixels exceed 16 GiB), after W untimed warm-up
-frames — during which the library also times its four schedules on this scene and keeps the
-fastest (2 frames each, then those within 10 % of the fastest again on 16 frames each: W >= 72, the default, settles
-it before the timed region; with a smaller W the rest of the tuning runs inside the timed frames).  Scene arrays and the
+frames — during which the library also times its six schedules on this scene and keeps the
+fastest (2 frames each, then the best two or three again on 32 frames each: W >= 112, the default, settles it
+before the timed region; with a smaller W the difference is rendered as untimed set-up before the warm-up).  Scene arrays and the
 accumulated image are resident in HBM before the timed region starts.  Default workload =
 BASELINE.json configs[1]: Cornell box, 1920x1080, 256 spp, depth 8, 1 GPU.
 
@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-TUNE_FRAMES = 72        # 6 plans x 2 screening frames + up to 3 finalists x 2 x 8 refinement frames = 60, rounded up
+TUNE_FRAMES = 112       # 6 plans x 2 screening frames + up to 3 finalists x 2 x ( 4 + 12 ) refinement frames = 108, rounded up
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4 copy ~6290
 
 WORKLOADS = {
@@ -98,7 +98,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=72)
+    ap.add_argument("--warmup", type=int, default=112)
     ap.add_argument("--scene", default="cornell", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -177,7 +177,7 @@ def main():
 
     # set-up, untimed and outside the W warm-up steps: the schedule tuner needs TUNE_FRAMES frames of this scene +
     # configuration once (the counterpart of the reference's per-scene clBuildProgram).  With the default
-    # W = 72 the warm-up itself covers it; a caller who asks for a shorter warm-up gets the difference here, and the
+    # W = 112 the warm-up itself covers it; a caller who asks for a shorter warm-up gets the difference here, and the
     # warm-up then starts the accumulation again at frame 0.
     setup_frames = max(0, TUNE_FRAMES - args.warmup)
     if setup_frames > 0:

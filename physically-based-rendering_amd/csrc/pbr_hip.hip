@@ -35,6 +35,7 @@ struct pbr_ctx {
 	float4* dTris = nullptr;
 	float4* dTriPN = nullptr;      // exact vertices + vertex normals per face (Phong tessellation); null if the normal indices are unusable
 	float4* dMats = nullptr;
+	float4* dFaceN = nullptr;      // per-face unit normal + material, prepareFaceNormals
 	float4* dLights = nullptr;
 	uint32_t numHotAvail = 0;      // records at the head of the node stream that are ranked for LDS staging
 	int firstRef = 0;              // record of node 1
@@ -63,8 +64,7 @@ struct pbr_ctx {
 	int refineCount = 0;                            // refinement: the plans within 10 % of the fastest (at least two) again, on longer chunks
 	int refinePlan[6] = { -1, -1, -1, -1, -1, -1 };
 	uint32_t refineChunks = 0;                      // chunks rendered so far in the refinement
-	double refineMs[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
-	uint32_t refineFrames[6] = { 0, 0, 0, 0, 0, 0 };
+	double refineFit[6][5] = {};                    // per finalist, over its refinement launches: sums of 1, n, n^2, ms, n * ms (n = frames of the launch)
 	char lastPlan[48] = "";        // name of the plan that rendered the largest chunk of the last render
 	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
 	uint32_t lastTraceLaunches = 0; // ... and how many there were (frame-parallel renders are chunked)
@@ -111,6 +111,8 @@ void freeScene( pbr_ctx* ctx ) {
 	(void) hipFree( ctx->dTris );
 	(void) hipFree( ctx->dTriPN );
 	ctx->dTriPN = nullptr;
+	(void) hipFree( ctx->dFaceN );
+	ctx->dFaceN = nullptr;
 	(void) hipFree( ctx->dMats );
 	(void) hipFree( ctx->dLights );
 	ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dLights = nullptr;
@@ -412,6 +414,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	P.firstRef = ctx->firstRef;
 	P.tris = ctx->dTris;
 	P.triPN = ctx->dTriPN;
+	P.faceN = ctx->dFaceN;
 	P.phongAlpha = ctx->cfg.phong_tessellation;
 	P.mats = ctx->dMats;
 	P.lights = ctx->dLights;
@@ -595,11 +598,15 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// phased-lean 1380 vs refill-wide 1000), and all of them give the same bits — so the first frames
 	// of a scene + configuration, which have to be rendered anyway, are rendered in turn by each
 	// candidate (kTuneFrames each) and timed; short launches favour the plans with fewer, larger blocks,
-	// so the two or three fastest (the third only if within 10 % of the first) are timed again on 2 x kRefineChunk frames
-	// each, in the order A B C C B A, before the fastest is kept.
+	// so the two or three fastest (the third only if within 10 % of the first) are timed again on short and long chunks,
+	// in the palindromic order A B C (short) C B A (long) A B C (long) C B A (short): two lengths separate a launch's
+	// fixed cost from its per-frame cost, and every plan's short launches and its long launches are centred on the same
+	// moment, so the drift of the clocks — the GPU ramps up from idle during exactly these launches, which biased a
+	// one-sided order by 5 % in the per-frame cost — cancels in both.
 	const int kPlans = 6;
 	const uint32_t kTuneFrames = 2;
-	const uint32_t kRefineChunk = 8;     // refinement: two chunks of this many frames per plan
+	const uint32_t kRefineShort = 4, kRefineLong = 12;     // refinement: two chunks of each length per plan
+	const uint32_t kRefinePasses = 4;
 	Plan plans[kPlans];
 	{
 		const uint32_t brdf = ctx->cfg.brdf;
@@ -716,7 +723,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			n = std::min<uint32_t>( n, kTuneFrames - ctx->tuneFrames[choice] );
 		}
 		if( refining >= 0 ) {
-			n = std::min<uint32_t>( n, kRefineChunk );
+			const uint32_t pass = ctx->refineChunks / (uint32_t) ctx->refineCount;
+			const bool longPass = ( pass == 1u || pass == 2u );
+			n = std::min<uint32_t>( n, longPass ? kRefineLong : kRefineShort );
 		}
 
 		P.nFrames = (int) n;
@@ -776,26 +785,42 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		}
 
 		if( refining >= 0 ) {
-			ctx->refineMs[refining] += (double) ms;
-			ctx->refineFrames[refining] += n;
+			double* fit = ctx->refineFit[refining];
+			fit[0] += 1.0;
+			fit[1] += (double) n;
+			fit[2] += (double) n * (double) n;
+			fit[3] += (double) ms;
+			fit[4] += (double) n * (double) ms;
 			ctx->refineChunks++;
 
-			if( ctx->refineChunks >= 2u * (uint32_t) ctx->refineCount ) {
-				// A launch costs a + b x frames (a: ramp-up and drain, 0.3 - 0.6 ms; b: the per-frame rate), and the plans
-				// differ in both: from the screening launch (kTuneFrames frames) and the refinement launches (kRefineChunk
-				// frames) of each finalist, estimate a and b and compare the cost of a render as long as this caller's.
-				const double n = (double) std::max<uint32_t>( ctx->tuneRenderFrames, 1u );
+			if( ctx->refineChunks >= kRefinePasses * (uint32_t) ctx->refineCount ) {
+				// A launch costs a + b x frames (a: ramp-up and drain, 0.3 - 0.6 ms; b: the per-frame rate) and the plans
+				// differ in both: least squares over each finalist's refinement launches, then the cost of a render as
+				// long as this caller's.  (Launches of one length only — a caller rendering frame by frame — give a = 0.)
+				const double frames = (double) std::max<uint32_t>( ctx->tuneRenderFrames, 1u );
 				int best = -1;
 				double bestCost = 0.0;
 
 				for( int k = 0; k < ctx->refineCount; k++ ) {
-					const int plan = ctx->refinePlan[k];
-					const double tShort = ctx->tuneMs[plan] * (double) kTuneFrames / ctx->tuneFrames[plan];
-					const double tLong = ctx->refineMs[k] * (double) kRefineChunk / ctx->refineFrames[k];
-					double b = ( tLong - tShort ) / (double) ( kRefineChunk - kTuneFrames );
-					b = std::max( b, 0.0 );
-					const double a = std::max( tLong - b * (double) kRefineChunk, 0.0 );
-					const double cost = ( a + b * n ) / n;
+					const double* f = ctx->refineFit[k];
+					const double det = f[0] * f[2] - f[1] * f[1];
+					double a = 0.0, b = f[3] / f[1];
+
+					if( det > 1e-9 * f[2] * f[0] ) {
+						const double bFit = ( f[0] * f[4] - f[1] * f[3] ) / det;
+						const double aFit = ( f[3] - bFit * f[1] ) / f[0];
+
+						if( aFit >= 0.0 && bFit >= 0.0 ) {
+							a = aFit;
+							b = bFit;
+						}
+					}
+
+					const double cost = ( a + b * frames ) / frames;
+
+					if( std::getenv( "PBR_TUNE_LOG" ) != nullptr ) {
+						std::fprintf( stderr, "[pbr tune] fit %-12s a %.3f ms  b %.3f ms/frame  -> %.4f ms/frame at %u frames\n", plans[ctx->refinePlan[k]].name, a, b, cost, (unsigned) frames );
+					}
 
 					if( best < 0 || cost < bestCost ) {
 						best = k;
@@ -1157,6 +1182,22 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	HIP_TRY( ctx, hipMemcpy( ctx->dMats, mats.data(), sizeof( float4 ) * mats.size(), hipMemcpyHostToDevice ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dLights, lights.data(), sizeof( float4 ) * lights.size(), hipMemcpyHostToDevice ) );
 
+	// the face normals the shading would recompute on every hit, evaluated once by the shading's own device function
+	{
+		const char* off = std::getenv( "PBR_FACE_NORMALS" );   // experiments: 0 = recompute per hit
+
+		if( s->num_faces > 0 && !( off != nullptr && std::atoi( off ) == 0 ) ) {
+			HIP_TRY( ctx, hipMalloc( (void**) &ctx->dFaceN, sizeof( float4 ) * s->num_faces ) );
+			DevParams P;
+			std::memset( &P, 0, sizeof( P ) );
+			P.tris = ctx->dTris;
+			hipLaunchKernelGGL( ptk::prepareFaceNormals, dim3( ( s->num_faces + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, P, ctx->dFaceN, (int) s->num_faces );
+			HIP_TRY( ctx, hipGetLastError() );
+		}
+
+		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	}
+
 	ctx->numHotAvail = numHot;
 	ctx->firstRef = recordOf[1];
 	ctx->numNodes = s->num_nodes;
@@ -1169,8 +1210,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
 	ctx->refineCount = 0;
 	ctx->refineChunks = 0;
-	std::memset( ctx->refineMs, 0, sizeof( ctx->refineMs ) );
-	std::memset( ctx->refineFrames, 0, sizeof( ctx->refineFrames ) );
+	std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
 	ctx->hasScene = true;
 
 	return PBR_OK;
@@ -1225,8 +1265,7 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
 	ctx->refineCount = 0;
 	ctx->refineChunks = 0;
-	std::memset( ctx->refineMs, 0, sizeof( ctx->refineMs ) );
-	std::memset( ctx->refineFrames, 0, sizeof( ctx->refineFrames ) );
+	std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
 	ctx->configured = true;
 
 	return PBR_OK;
@@ -1468,6 +1507,7 @@ DevParams sceneParams( pbr_ctx* ctx ) {
 	P.parkEighths = 4;
 	P.nodes = ctx->dNodes;
 	P.tris = ctx->dTris;
+	P.faceN = ctx->dFaceN;
 	P.mats = ctx->dMats;
 	P.lights = ctx->dLights;
 	P.guard = ctx->dGuard;

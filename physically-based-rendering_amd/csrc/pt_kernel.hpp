@@ -77,6 +77,11 @@ struct DevParams {
 	float explicitWeight;
 	float pxDim, antiAliasing;
 	float sky[3];
+	// last, so that kernels which do not use it do not load it: per face {unit normal of the flat triangle,
+	// material(int bits)} — what faceNormal() computes from the record in `tris` on every hit, evaluated once by
+	// prepareFaceNormals with the same code.  The lock-step kernels read it (Cornell +1.3 %); in the lane state
+	// machine the extra pointer costs more in registers than the 40 instructions per hit are worth (measured -2 %).
+	const float4* faceN;
 };
 
 struct Ray {
@@ -110,13 +115,34 @@ PT_DEV float fresnel( float u, float c ) {
 }
 
 // jitter, pt_utils.cl:306-318
-PT_DEV f3 jitter( f3 nl, float phi, float sina, float cosa ) {
-	const f3 u = normalize( cross( yzx( nl ), nl ) );
-	const f3 v = normalize( cross( nl, u ) );
+// The tangent frame of a normal as jitter (pt_utils.cl:264-279) and brdfShirleyAshikhmin (pt_brdf.cl:233-234) build it
+// — the same two expressions in both, so a bounce that samples a direction around a normal and then evaluates the
+// BRDF for the same normal (bit for bit: the check is on the bits) needs it once.
+struct TangentFrame {
+	f3 n, u, v;
+	bool valid;
+};
+
+PT_DEV void tangentFrame( f3 n, f3* u, f3* v ) {
+	*u = normalize( cross( yzx( n ), n ) );
+	*v = normalize( cross( n, *u ) );
+}
+
+PT_DEV bool sameBits( f3 a, f3 b ) {
+	return __float_as_int( a.x ) == __float_as_int( b.x ) && __float_as_int( a.y ) == __float_as_int( b.y ) && __float_as_int( a.z ) == __float_as_int( b.z );
+}
+
+PT_DEV f3 jitterUV( f3 nl, f3 u, f3 v, float phi, float sina, float cosa ) {
 	float sp, cp;
 	sincos( phi, &sp, &cp );
 	const f3 w = normalize( u * cp + v * sp );
 	return normalize( w * sina + nl * cosa );
+}
+
+PT_DEV f3 jitter( f3 nl, float phi, float sina, float cosa ) {
+	f3 u, v;
+	tangentFrame( nl, &u, &v );
+	return jitterUV( nl, u, v, phi, sina, cosa );
 }
 
 PT_DEV Material loadMaterial( const DevParams& P, int index ) {
@@ -937,7 +963,14 @@ PT_DEV void stageHotNodes( const DevParams& P, float4* lds ) {
 }
 
 // Geometric normal of a face: fast_normalize( cross( edge1, edge2 ) ), pt_intersect.cl:122
+template<bool STORED = false>
 PT_DEV f3 faceNormal( const DevParams& P, int face, int* material ) {
+	if( STORED && P.faceN != nullptr ) {
+		const float4 r = P.faceN[face];
+		*material = __float_as_int( r.w );
+		return mk3( r.x, r.y, r.z );
+	}
+
 	const float4 r0 = P.tris[face * 3 + 0];
 	const float4 r1 = P.tris[face * 3 + 1];
 	const float4 r2 = P.tris[face * 3 + 2];
@@ -1118,11 +1151,19 @@ PT_DEV f3 newRaySchlick( f3 dir, f3 normal, const Material& mtl, float& seed ) {
 template<bool CALLS = false>
 PT_DEV void brdfSA(
 	const Material& mtl, f3 outDir, f3 inDir, f3 normal,
-	float* brdfSpec, float* brdfDiff, float* dotHK1, float* pdf
+	float* brdfSpec, float* brdfDiff, float* dotHK1, float* pdf, const TangentFrame* frame = nullptr
 ) {
 	const float nu = mtl.p2, nv = mtl.p3;
-	const f3 un = normalize( cross( yzx( normal ), normal ) );
-	const f3 vn = normalize( cross( normal, un ) );
+	f3 un, vn;
+
+	if( frame != nullptr && frame->valid && sameBits( frame->n, normal ) ) {
+		un = frame->u;
+		vn = frame->v;
+	}
+	else {
+		tangentFrame( normal, &un, &vn );
+	}
+
 	const f3 k1 = inDir;
 	const f3 k2 = -outDir;
 	const f3 h = normalize( k1 + k2 );
@@ -1154,7 +1195,7 @@ PT_DEV void brdfSA(
 
 // newRayShirleyAshikhmin, pt_brdf.cl:278-330
 template<bool CALLS = false>
-PT_DEV f3 newRaySA( f3 dir, f3 rayNormal, const Material& mtl, float& seed ) {
+PT_DEV f3 newRaySA( f3 dir, f3 rayNormal, const Material& mtl, float& seed, TangentFrame* frame = nullptr ) {
 	const float nu = mtl.p2, nv = mtl.p3;
 	float a = rnd( seed );
 	const float b = rnd( seed );
@@ -1192,9 +1233,19 @@ PT_DEV f3 newRaySA( f3 dir, f3 rayNormal, const Material& mtl, float& seed ) {
 
 	float st, ct;
 	sincos( theta, &st, &ct );
-	const f3 h = jitter( normal, phi_full, st, ct );
+	f3 u, v;
+	tangentFrame( normal, &u, &v );
+
+	if( frame != nullptr ) {
+		frame->n = normal;
+		frame->u = u;
+		frame->v = v;
+		frame->valid = true;
+	}
+
+	const f3 h = jitterUV( normal, u, v, phi_full, st, ct );
 	const f3 spec = reflect( dir, h );
-	const f3 diff = jitter( normal, PI_X2 * rnd( seed ), sqrt1( b ), sqrt1( 1.0f - b ) );
+	const f3 diff = jitterUV( normal, u, v, PI_X2 * rnd( seed ), sqrt1( b ), sqrt1( 1.0f - b ) );
 
 	return ( dot( spec, normal ) <= 0.0f ) ? diff : spec;
 }
@@ -1228,7 +1279,7 @@ PT_DEV f3 refract( f3 dir, f3 normal, const Material& mtl, float& seed ) {
 
 // getNewRay, pt_brdf.cl:344-378 (direction only; the origin is fma( t, dir, origin ))
 template<int BRDF, bool CALLS = false>
-PT_DEV f3 newRayDir( f3 dir, f3 normal, const Material& mtl, float& seed, bool& addDepth ) {
+PT_DEV f3 newRayDir( f3 dir, f3 normal, const Material& mtl, float& seed, bool& addDepth, TangentFrame* frame = nullptr ) {
 	// && short-circuits: the random number is drawn only when d < 1
 	bool doTransRefr = false;
 
@@ -1242,12 +1293,12 @@ PT_DEV f3 newRayDir( f3 dir, f3 normal, const Material& mtl, float& seed, bool& 
 		return refract( dir, normal, mtl, seed );
 	}
 
-	return ( BRDF == 0 ) ? newRaySchlick( dir, normal, mtl, seed ) : newRaySA<CALLS>( dir, normal, mtl, seed );
+	return ( BRDF == 0 ) ? newRaySchlick( dir, normal, mtl, seed ) : newRaySA<CALLS>( dir, normal, mtl, seed, frame );
 }
 
 // The factor updateColor multiplies `color` by (pathtracing.cl:98-124 Schlick, :127-177 S-A).
 template<int BRDF, bool CALLS = false>
-PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal ) {
+PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const TangentFrame* frame = nullptr ) {
 	const float d = mtl.d;
 
 	if( BRDF == 0 ) {
@@ -1262,7 +1313,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal ) {
 	}
 
 	float spec, diff, dotHK1, pdf;
-	brdfSA<CALLS>( mtl, outDir, inDir, normal, &spec, &diff, &dotHK1, &pdf );
+	brdfSA<CALLS>( mtl, outDir, inDir, normal, &spec, &diff, &dotHK1, &pdf, frame );
 	spec = spec / pdf;
 	diff = diff / pdf;
 
@@ -1281,7 +1332,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal ) {
 // Returns false when |pdf| <= 1e-5 (no contribution, secondaryPaths unchanged).
 template<int BRDF, bool CALLS = false>
 PT_DEV bool shadowContribution(
-	const Material& mtl, f3 outDir, f3 lightDir, f3 normal, f3 color, f3 lightRgb, f3* add
+	const Material& mtl, f3 outDir, f3 lightDir, f3 normal, f3 color, f3 lightRgb, f3* add, const TangentFrame* frame = nullptr
 ) {
 	const float d = mtl.d;
 
@@ -1303,7 +1354,7 @@ PT_DEV bool shadowContribution(
 	}
 
 	float spec, diff, dotHK1, pdf;
-	brdfSA<CALLS>( mtl, outDir, lightDir, normal, &spec, &diff, &dotHK1, &pdf );
+	brdfSA<CALLS>( mtl, outDir, lightDir, normal, &spec, &diff, &dotHK1, &pdf, frame );
 
 	if( !( __builtin_fabsf( pdf ) > 0.00001f ) ) {
 		return false;
@@ -1440,7 +1491,7 @@ PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
 // next path.  Returns true when the pixel has had all P.nFrames frames; otherwise st.ray is the
 // next ray to trace.
 // CALLS: pow as a function call instead of inline (pt_math.hpp, pow1Call) — every kernel but the lean lock-step one
-template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false, bool CALLS = !EAGER>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false, bool CALLS = !EAGER, bool FACEN = false>
 PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt, const Hit hit ) {
 	// references keep the shading code below in the reference's vocabulary
 	Ray& ray = st.ray;
@@ -1472,7 +1523,7 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 		}
 		else {
 			int mtlIndex;
-			f3 normal = faceNormal( P, hit.face, &mtlIndex );
+			f3 normal = faceNormal<FACEN>( P, hit.face, &mtlIndex );
 
 			if( PHONG ) {
 				normal = hit.normal;   // ray.normal as intersectFace stored it (pt_bvh.cl:18): the Phong normal on curved faces
@@ -1528,7 +1579,9 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 				}
 
 				// getNewRay, pt_brdf.cl:344-378 — uses the UNflipped normal
-				const f3 newDir = newRayDir<BRDF, CALLS>( ray.dir, normal, mtl, seed, addDepth );
+				TangentFrame frame;
+				frame.valid = false;
+				const f3 newDir = newRayDir<BRDF, CALLS>( ray.dir, normal, mtl, seed, addDepth, &frame );
 
 				// pathtracing.cl:298-300
 				if( dot( normal, -ray.dir ) <= 0.0f ) {
@@ -1540,14 +1593,14 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 					if( lit ) {
 						f3 add;
 
-						if( shadowContribution<BRDF, CALLS>( mtl, ray.dir, lightDir, normal, color, lightRgb, &add ) ) {
+						if( shadowContribution<BRDF, CALLS>( mtl, ray.dir, lightDir, normal, color, lightRgb, &add, &frame ) ) {
 							finalColor = finalColor + add;
 							secondaryPaths += 1;
 						}
 					}
 				}
 
-				color = color * throughput<BRDF, CALLS>( mtl, ray.dir, newDir, normal );
+				color = color * throughput<BRDF, CALLS>( mtl, ray.dir, newDir, normal, &frame );
 
 				depthAdded += ( addDepth && depthAdded < P.maxAddedDepth ) ? 1 : 0;
 
@@ -1645,7 +1698,7 @@ PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, La
 	hit.face = 0;
 	hit.normal = mk3( 0.0f, 0.0f, 0.0f );
 	traverse<false, LIGHTS, true, PHONG, EAGER>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
-	return shadeStep<BRDF, SHADOW, LIGHTS, FP, PHONG, EAGER>( P, lds, st, cnt, hit );
+	return shadeStep<BRDF, SHADOW, LIGHTS, FP, PHONG, EAGER, !EAGER, true>( P, lds, st, cnt, hit );
 }
 
 // ---- the pixel-slot queue ----------------------------------------------------------------
@@ -2212,6 +2265,22 @@ __global__ __launch_bounds__( 256 ) void foldFrames( const DevParams P, const fl
 	}
 
 	dst[slot] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// Scene preparation (pbr_upload_scene): per-face and per-material values the shading would otherwise
+// recompute on every hit — evaluated here by the same device functions, so the bits are the same
+// ---------------------------------------------------------------------------------------
+__global__ void prepareFaceNormals( DevParams P, float4* faceN, int numFaces ) {
+	const int face = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
+
+	if( face >= numFaces ) {
+		return;
+	}
+
+	int material;
+	const f3 n = faceNormal<false>( P, face, &material );
+	faceN[face] = make_float4( n.x, n.y, n.z, __int_as_float( material ) );
 }
 
 // ---------------------------------------------------------------------------------------

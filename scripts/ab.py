@@ -18,7 +18,7 @@ for job in jobs:
     sc = pbr.HostScene.generate(kind, seed, tris)
     cfg, cam, px = sc.config(W, H), sc.camera(), pbr.pixel_dimension(W, H)
     dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(cfg)
-    dev.render(0, pbr.frame_seeds(0, 72), px, cam)                     # warm-up (and schedule auto-tuning: 4 x 2 + up to 4 x 16 frames)
+    dev.render(0, pbr.frame_seeds(0, 112), px, cam)                     # warm-up (and schedule auto-tuning: 6 x 2 + up to 3 x 32 frames)
     times = []
     for rep in range(2):
         dev.reset_accum()

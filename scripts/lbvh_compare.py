@@ -22,7 +22,7 @@ for name in (sys.argv[1:] or ["sponza", "dragon", "hairball"]):
             desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
             desc.bvh, desc.num_nodes, desc.facesV, desc.facesN = nodes.ctypes.data, nodes.shape[0], fv.ctypes.data, fn.ctypes.data
         dev.upload_scene(desc); dev.configure(cfg)
-        dev.render(0, pbr.frame_seeds(0, 72), px, cam)
+        dev.render(0, pbr.frame_seeds(0, 112), px, cam)
         dev.reset_accum(); c0 = dev.counters()
         dev.render(0, pbr.frame_seeds(0, FRAMES), px, cam)
         c1 = dev.counters(); ms = dev.last_kernel_ms()
