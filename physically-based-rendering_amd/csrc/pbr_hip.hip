@@ -59,6 +59,7 @@ struct pbr_ctx {
 	// frames that are rendered anyway, then the fastest one is kept
 	int tunedPlan = -1;
 	uint32_t tuneRenderFrames = 0;                  // the longest render (frames per call) this context has been asked for
+	uint32_t tunedAtFrames = 0;                     // the render length tunedPlan was chosen for
 	double tuneMs[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
 	uint32_t tuneFrames[6] = { 0, 0, 0, 0, 0, 0 };
 	int refineCount = 0;                            // refinement: the plans within 10 % of the fastest (at least two) again, on longer chunks
@@ -681,6 +682,66 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	}
 
 	ctx->tuneRenderFrames = std::max( ctx->tuneRenderFrames, nFrames );
+
+	// A launch costs a + b x frames (a: ramp-up and drain, 0.3 - 0.6 ms; b: the per-frame rate) and the plans differ in
+	// both: least squares over each finalist's refinement launches, then the cost of a render of `frames` frames.
+	// Launches of one length only (a caller rendering frame by frame) cannot separate the two: a = 0, `separable` false.
+	bool separable = true;
+	auto decide = [&]( uint32_t renderFrames ) -> int {
+		const double frames = (double) std::max<uint32_t>( renderFrames, 1u );
+		int best = -1;
+		double bestCost = 0.0;
+		separable = true;
+
+		for( int k = 0; k < ctx->refineCount; k++ ) {
+			const double* f = ctx->refineFit[k];
+			const double det = f[0] * f[2] - f[1] * f[1];
+			double a = 0.0, b = f[3] / f[1];
+
+			if( det > 1e-9 * f[2] * f[0] ) {
+				const double bFit = ( f[0] * f[4] - f[1] * f[3] ) / det;
+				const double aFit = ( f[3] - bFit * f[1] ) / f[0];
+
+				if( aFit >= 0.0 && bFit >= 0.0 ) {
+					a = aFit;
+					b = bFit;
+				}
+			}
+			else {
+				separable = false;
+			}
+
+			const double cost = ( a + b * frames ) / frames;
+
+			if( std::getenv( "PBR_TUNE_LOG" ) != nullptr ) {
+				std::fprintf( stderr, "[pbr tune] fit %-12s a %.3f ms  b %.3f ms/frame  -> %.4f ms/frame at %u frames\n", plans[ctx->refinePlan[k]].name, a, b, cost, (unsigned) frames );
+			}
+
+			if( best < 0 || cost < bestCost ) {
+				best = k;
+				bestCost = cost;
+			}
+		}
+
+		return ctx->refinePlan[best];
+	};
+
+	if( ctx->tunedPlan >= 0 && ctx->refineCount > 0 && nFrames > 2u * ctx->tunedAtFrames ) {
+		// tuned for shorter renders than this one (a viewer's frame-by-frame calls, then a batch): the fixed cost
+		// weighs less now.  With fits from two launch lengths that is a new evaluation; with one length only, the
+		// finalists are timed again on this render's frames.
+		const int again = decide( nFrames );
+
+		if( separable ) {
+			ctx->tunedPlan = again;
+			ctx->tunedAtFrames = nFrames;
+		}
+		else if( nFrames >= 4u * kRefineLong ) {
+			ctx->tunedPlan = -1;
+			ctx->refineChunks = 0;
+			std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
+		}
+	}
 	P.frameBuf = ctx->dFrameBuf;
 	P.frameStride = (unsigned) pixelSlots;
 	const unsigned foldBlocks = (unsigned) ( ( pixelSlots + 255 ) / 256 );
@@ -794,41 +855,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			ctx->refineChunks++;
 
 			if( ctx->refineChunks >= kRefinePasses * (uint32_t) ctx->refineCount ) {
-				// A launch costs a + b x frames (a: ramp-up and drain, 0.3 - 0.6 ms; b: the per-frame rate) and the plans
-				// differ in both: least squares over each finalist's refinement launches, then the cost of a render as
-				// long as this caller's.  (Launches of one length only — a caller rendering frame by frame — give a = 0.)
-				const double frames = (double) std::max<uint32_t>( ctx->tuneRenderFrames, 1u );
-				int best = -1;
-				double bestCost = 0.0;
-
-				for( int k = 0; k < ctx->refineCount; k++ ) {
-					const double* f = ctx->refineFit[k];
-					const double det = f[0] * f[2] - f[1] * f[1];
-					double a = 0.0, b = f[3] / f[1];
-
-					if( det > 1e-9 * f[2] * f[0] ) {
-						const double bFit = ( f[0] * f[4] - f[1] * f[3] ) / det;
-						const double aFit = ( f[3] - bFit * f[1] ) / f[0];
-
-						if( aFit >= 0.0 && bFit >= 0.0 ) {
-							a = aFit;
-							b = bFit;
-						}
-					}
-
-					const double cost = ( a + b * frames ) / frames;
-
-					if( std::getenv( "PBR_TUNE_LOG" ) != nullptr ) {
-						std::fprintf( stderr, "[pbr tune] fit %-12s a %.3f ms  b %.3f ms/frame  -> %.4f ms/frame at %u frames\n", plans[ctx->refinePlan[k]].name, a, b, cost, (unsigned) frames );
-					}
-
-					if( best < 0 || cost < bestCost ) {
-						best = k;
-						bestCost = cost;
-					}
-				}
-
-				ctx->tunedPlan = ctx->refinePlan[best];
+				ctx->tunedPlan = decide( ctx->tuneRenderFrames );
+				ctx->tunedAtFrames = ctx->tuneRenderFrames;
 			}
 		}
 
@@ -1206,6 +1234,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	ctx->numLights = s->num_lights;
 	ctx->sceneBrdf = s->brdf;
 	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
+	ctx->tuneRenderFrames = ctx->tunedAtFrames = 0;
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
 	ctx->refineCount = 0;
@@ -1261,6 +1290,7 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * kCounterSlots ) );
 	HIP_TRY( ctx, hipDeviceSynchronize() );   // the memsets ran on the null stream; launches use ctx->stream
 	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
+	ctx->tuneRenderFrames = ctx->tunedAtFrames = 0;
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
 	ctx->refineCount = 0;

@@ -184,6 +184,31 @@ def test_larger_scenes_bit_exact(pbr, oracle, device, monkeypatch, kind, triangl
     assert device.counters() == ref.counter_dict()
 
 
+def test_schedule_tuner_through_a_viewer_then_a_batch(pbr, oracle, device):
+    """No schedule forced: launch() screens its six plans, times the finalists and keeps one (pbr_hip.hip) — on
+    frame-by-frame calls first, as the reference's viewer renders (PathTracer.cpp:60-68), which cannot separate a
+    launch's fixed cost from its per-frame cost; the first long render then times the finalists again.  Whatever
+    it picks, the accumulated image is the oracle's."""
+    sc = make_scene(pbr, **{"render.max_depth": 4})
+    w, h = 40, 32
+    cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    ref = oracle.Renderer(sc.desc, cfg, threads=8)
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    first = 0
+    for n in [1] * 30 + [60, 40]:
+        seeds = pbr.frame_seeds(first, n)
+        want = ref.render(first, seeds, px, cam)
+        device.render(first, seeds, px, cam)
+        first += n
+        if n == 1 and first == 30:
+            assert device.last_plan()[1] >= 0, "30 single-frame launches settle the tuner"
+    assert device.last_plan()[1] >= 0
+    got = device.read_output()
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert device.counters() == ref.counter_dict()
+
+
 @pytest.mark.parametrize("chunk", ["1", "2", "3"])
 @pytest.mark.parametrize("schedule", ["refill", "phased"])
 def test_frame_parallel_chunks_fold_in_frame_order(pbr, oracle, device, monkeypatch, schedule, chunk):
