@@ -33,7 +33,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-TUNE_FRAMES = 112       # 6 plans x 2 screening frames + up to 3 finalists x 2 x ( 4 + 12 ) refinement frames = 108, rounded up
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4 copy ~6290
 
 WORKLOADS = {
@@ -175,11 +174,11 @@ def main():
         torch.cuda.synchronize()
         dev.import_tiles(gather_out.data_ptr())
 
-    # set-up, untimed and outside the W warm-up steps: the schedule tuner needs TUNE_FRAMES frames of this scene +
+    # set-up, untimed and outside the W warm-up steps: the schedule tuner needs dev.tune_budget() frames of this scene +
     # configuration once (the counterpart of the reference's per-scene clBuildProgram).  With the default
     # W = 112 the warm-up itself covers it; a caller who asks for a shorter warm-up gets the difference here, and the
     # warm-up then starts the accumulation again at frame 0.
-    setup_frames = max(0, TUNE_FRAMES - args.warmup)
+    setup_frames = max(0, dev.tune_budget() - args.warmup)     # 108 frames at 1080p on one GPU, N x as many on a rank of N
     if setup_frames > 0:
         dev.render(0, pbr.frame_seeds(0, setup_frames), px, cam)
 

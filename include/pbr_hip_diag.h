@@ -46,6 +46,11 @@ int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t r
  * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
 int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
 
+/* How many frames of the configured size the schedule tuner wants to see before it settles (its launch lengths are
+ * fixed in 1080p-frame equivalents, so a rank of an N-GPU run needs N times as many): a benchmark renders that many
+ * before it starts its clock. */
+int pbr_diag_tune_budget( pbr_ctx* ctx, uint32_t* frames );
+
 /* The path-tracing launches of the last render: their summed duration (HIP events around each one)
  * and their number.  A multi-frame render is one launch unless its per-frame result buffer would
  * exceed 16 GiB; pbr_last_kernel_ms covers the whole render, foldFrames launches included. */

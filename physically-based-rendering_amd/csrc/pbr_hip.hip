@@ -62,6 +62,7 @@ struct pbr_ctx {
 	uint32_t tunedAtFrames = 0;                     // the render length tunedPlan was chosen for
 	double tuneMs[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
 	uint32_t tuneFrames[6] = { 0, 0, 0, 0, 0, 0 };
+	uint32_t tuneLaunches[6] = { 0, 0, 0, 0, 0, 0 };
 	int refineCount = 0;                            // refinement: the plans within 10 % of the fastest (at least two) again, on longer chunks
 	int refinePlan[6] = { -1, -1, -1, -1, -1, -1 };
 	uint32_t refineChunks = 0;                      // chunks rendered so far in the refinement
@@ -374,6 +375,13 @@ int launchWavefront( pbr_ctx* ctx, DevParams P, bool shadow, bool lights ) {
 	return PBR_OK;
 }
 
+// The schedule tuner's chunk lengths are in 1080p-frame equivalents (launch()): how many of this context's frames make one.
+uint32_t tuneScaleOf( size_t localPixels ) {
+	const size_t reference = (size_t) 1920 * 1080;
+	const size_t scale = ( reference + localPixels / 2 ) / std::max<size_t>( localPixels, 1 );
+	return (uint32_t) std::min<size_t>( std::max<size_t>( scale, 1 ), 64 );
+}
+
 int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* seeds,
             bool explicitWeight, float weight, float pxDim, const pbr_camera* cam ) {
 	if( !ctx->hasScene || !ctx->configured ) {
@@ -496,7 +504,6 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	};
 
 	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK ) -> int {
-		const int wavesPerBlock = blockThreads / 64;
 		int blocksPerCU = 0;
 		HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, blockThreads, 0 ) );
 		blocksPerCU = ( blocksPerCU < 1 ) ? 1 : blocksPerCU;
@@ -516,12 +523,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 		HIP_TRY( ctx, hipFuncSetAttribute( (const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ( slots * 32 ) ) );
 
-		int blocks = ctx->numCUs * blocksPerCU;
-		const int needed = ( ctx->numLocalTiles + wavesPerBlock - 1 ) / wavesPerBlock;
-		blocks = ( blocks > needed ) ? needed : blocks;
 		plan->kernel = kernel;
 		plan->blockThreads = blockThreads;
-		plan->blocks = ( blocks < 1 ) ? 1 : blocks;
+		plan->blocks = ctx->numCUs * blocksPerCU;   // all that are resident at once; run() launches fewer when there is less work
 		plan->numHot = (int) slots;
 		plan->ldsBytes = slots * 32;
 		plan->park = park;
@@ -542,12 +546,18 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		return PBR_OK;
 	};
 
-	auto run = [&]( const Plan& plan ) -> int {
+	// waveUnits: how many wave-sized pieces of work the launch has — tiles for the tile schedule, tiles x frames for
+	// the frame-parallel ones (a rank of an 8-GPU run has 4050 tiles at 1080p: fewer than the 6144 - 8192 resident
+	// waves, but 256 frames of them)
+	auto run = [&]( const Plan& plan, size_t waveUnits ) -> int {
+		const size_t wavesPerBlock = (size_t) plan.blockThreads / 64;
+		const size_t needed = std::max<size_t>( 1, ( waveUnits + wavesPerBlock - 1 ) / wavesPerBlock );
+		const unsigned blocks = (unsigned) std::min<size_t>( (size_t) plan.blocks, needed );
 		P.numHot = plan.numHot;
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
 		P.parkEighths = plan.parkEighths;
-		hipLaunchKernelGGL( plan.kernel, dim3( (unsigned) plan.blocks ), dim3( (unsigned) plan.blockThreads ), plan.ldsBytes, ctx->stream, P );
+		hipLaunchKernelGGL( plan.kernel, dim3( blocks ), dim3( (unsigned) plan.blockThreads ), plan.ldsBytes, ctx->stream, P );
 		HIP_TRY( ctx, hipGetLastError() );
 		return PBR_OK;
 	};
@@ -569,7 +579,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 		HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
 
-		const int ran = run( plan );
+		const int ran = run( plan, (size_t) ctx->numLocalTiles );
 
 		if( ran != PBR_OK ) {
 			return ran;
@@ -605,8 +615,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// moment, so the drift of the clocks — the GPU ramps up from idle during exactly these launches, which biased a
 	// one-sided order by 5 % in the per-frame cost — cancels in both.
 	const int kPlans = 6;
-	const uint32_t kTuneFrames = 2;
-	const uint32_t kRefineShort = 4, kRefineLong = 12;     // refinement: two chunks of each length per plan
+	// Lengths in 1080p-frame equivalents: a rank of an 8-GPU run (or a small image) has 1/8 of the pixels per frame, and
+	// launches of a few hundred microseconds say little about a long render (measured at 1/8 of the tiles: the tuner
+	// kept a plan 26 % slower than the best).  So the chunk lengths grow as the frame shrinks.
+	const uint32_t tuneScale = tuneScaleOf( (size_t) ctx->numLocalTiles * 64 );
+	const uint32_t kTuneFrames = 2 * tuneScale;     // screening, per plan (or two launches, whichever comes first)
+	const uint32_t kRefineShort = 4 * tuneScale, kRefineLong = 12 * tuneScale;     // refinement: two chunks of each length per plan
 	const uint32_t kRefinePasses = 4;
 	Plan plans[kPlans];
 	{
@@ -622,6 +636,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			return status;
 		}
 	}
+
+	auto screened = [&]( int plan ) { return ctx->tuneFrames[plan] >= kTuneFrames || ctx->tuneLaunches[plan] >= 2u; };
 
 	int forcedPlan = -1;
 	Plan batchedPlan;
@@ -771,7 +787,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 				tuning = true;
 				choice = 0;
 
-				while( choice < kPlans - 1 && ctx->tuneFrames[choice] >= kTuneFrames ) {
+				while( choice < kPlans - 1 && screened( choice ) ) {
 					choice++;
 				}
 			}
@@ -799,7 +815,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 		HIP_TRY( ctx, hipEventRecord( ctx->evTraceStart, ctx->stream ) );
 
-		const int ran = run( plan );
+		const int ran = run( plan, (size_t) ctx->numLocalTiles * n );
 
 		if( ran != PBR_OK ) {
 			return ran;
@@ -829,8 +845,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		if( tuning ) {
 			ctx->tuneMs[choice] += (double) ms;
 			ctx->tuneFrames[choice] += n;
+			ctx->tuneLaunches[choice]++;
 
-			if( ctx->tuneFrames[kPlans - 1] >= kTuneFrames ) {
+			if( screened( kPlans - 1 ) ) {
 				// screening done: every plan within 10 % of the fastest — at least the two fastest — goes on to the refinement
 				auto perFrame = [&]( int k ) { return ctx->tuneMs[k] / ctx->tuneFrames[k]; };
 				int order[kPlans] = { 0, 1, 2, 3, 4, 5 };
@@ -1237,6 +1254,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	ctx->tuneRenderFrames = ctx->tunedAtFrames = 0;
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
+	std::memset( ctx->tuneLaunches, 0, sizeof( ctx->tuneLaunches ) );
 	ctx->refineCount = 0;
 	ctx->refineChunks = 0;
 	std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
@@ -1293,6 +1311,7 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	ctx->tuneRenderFrames = ctx->tunedAtFrames = 0;
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
+	std::memset( ctx->tuneLaunches, 0, sizeof( ctx->tuneLaunches ) );
 	ctx->refineCount = 0;
 	ctx->refineChunks = 0;
 	std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
@@ -1872,6 +1891,19 @@ int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t r
 	float ms = 0.0f;
 	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
 	*ms_out = (double) ms * 1.0;
+	return PBR_OK;
+}
+
+int pbr_diag_tune_budget( pbr_ctx* ctx, uint32_t* frames ) {
+	if( ctx == nullptr || frames == nullptr ) {
+		return PBR_EINVAL;
+	}
+	if( !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "tune budget before pbr_configure" );
+	}
+
+	// screening: 6 plans x 2; refinement: up to 3 finalists x 2 x ( 4 + 12 ); all in 1080p-frame equivalents
+	*frames = ( 6u * 2u + 3u * 2u * ( 4u + 12u ) ) * tuneScaleOf( (size_t) ctx->numLocalTiles * 64 );
 	return PBR_OK;
 }
 
