@@ -27,7 +27,12 @@ for sc, r in d.items():
     kr.sort(key=lambda x: int(x["Start_Timestamp"]))
     last = kr[-1]; dur = (int(last["End_Timestamp"]) - int(last["Start_Timestamp"])) / 1e6
     u = r["bench_under_rocprof"]
-    r["timed_launch_agreement"] = {"rocprof_timed_launch_ms": dur, "bench_launch_ms_same_run": u["roofline"]["launch_ms"], "kernel": last["Kernel_Name"][:60]}
+    ks = [x for x in r.get("kernel_stats", []) if "pathTracing" in x["Name"]]
+    avg = float(ks[0]["AverageNs"]) / 1e6 if ks else float("nan")
+    calls = int(ks[0]["Calls"]) if ks else 0
+    r["timed_launch_agreement"] = {"rocprof_timed_launch_ms": dur, "bench_launch_ms_same_run": u["roofline"]["launch_ms"], "kernel": last["Kernel_Name"][:60],
+                                   "rocprof_stats_average_ms": avg, "rocprof_stats_calls": calls}
+    print("         kernel_stats.csv: %d calls, average %.3f ms" % (calls, avg))
     p = r["pmc_timed_launch"]
     ns = [v for k, v in p.items() if k.startswith("duration_ns(SQ")][0]; cyc = ns * 2.4
     print("%-8s %7.1f %-12s launch %.3f ms  ach %.0f frac %.2f  traffic %.0f+%.0f  cpu %.2f (%.0fx)  VALU %.0f%% SALU %.0f%% lanes %.2f wait %.2f L2 %.3f  rocprof %.3f vs %.3f (%s)  read %.1f GB = %.2f TB/s" % (
