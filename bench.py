@@ -179,6 +179,8 @@ def main():
     # W = 112 the warm-up itself covers it; a caller who asks for a shorter warm-up gets the difference here, and the
     # warm-up then starts the accumulation again at frame 0.
     setup_frames = max(0, dev.tune_budget() - args.warmup)     # 108 frames at 1080p on one GPU, N x as many on a rank of N
+    if any(os.environ.get(k) for k in ("PBR_PLAN", "PBR_SCHEDULE", "PBR_VARIANT")):
+        setup_frames = 0                                       # a forced schedule: nothing to tune (profiling passes)
     if setup_frames > 0:
         dev.render(0, pbr.frame_seeds(0, setup_frames), px, cam)
 

@@ -1061,9 +1061,17 @@ PT_DEV float schG( float v, float r ) {
 }
 
 // brdfSchlick, pt_brdf.cl:125-150 with D / B2 (:71-112) inlined
-PT_DEV float brdfSchlick( const Material& mtl, f3 outDir, f3 inDir, f3 normal, float* u, float* pdf ) {
+PT_DEV float brdfSchlick( const Material& mtl, f3 outDir, f3 inDir, f3 normal, float* u, float* pdf, const TangentFrame* frame = nullptr ) {
 	const f3 vOutV = -outDir;
-	const f3 un = normalize( cross( yzx( normal ), normal ) );
+	f3 un;
+
+	if( frame != nullptr && frame->valid && sameBits( frame->n, normal ) ) {
+		un = frame->u;
+	}
+	else {
+		un = normalize( cross( yzx( normal ), normal ) );
+	}
+
 	const f3 h = normalize( vOutV + inDir );
 	const float t = dot( h, normal );
 	const float vIn = dot( inDir, normal );
@@ -1096,7 +1104,7 @@ PT_DEV float brdfSchlick( const Material& mtl, f3 outDir, f3 inDir, f3 normal, f
 }
 
 // newRaySchlick, pt_brdf.cl:160-208
-PT_DEV f3 newRaySchlick( f3 dir, f3 normal, const Material& mtl, float& seed ) {
+PT_DEV f3 newRaySchlick( f3 dir, f3 normal, const Material& mtl, float& seed, TangentFrame* frame = nullptr ) {
 	const float rough = mtl.p3;
 	const float iso = mtl.p2;
 
@@ -1132,11 +1140,21 @@ PT_DEV f3 newRaySchlick( f3 dir, f3 normal, const Material& mtl, float& seed ) {
 
 	float sa, ca;
 	sincos( alpha, &sa, &ca );
-	const f3 H = jitter( normal, phi, sa, ca );
+	f3 fu, fv;
+	tangentFrame( normal, &fu, &fv );
+
+	if( frame != nullptr ) {
+		frame->n = normal;
+		frame->u = fu;
+		frame->v = fv;
+		frame->valid = true;
+	}
+
+	const f3 H = jitterUV( normal, fu, fv, phi, sa, ca );
 	f3 out = reflect( dir, H );
 
 	if( dot( out, normal ) <= 0.0f ) {
-		out = jitter( normal, PI_X2 * rnd( seed ), sqrt1( a ), sqrt1( 1.0f - a ) );
+		out = jitterUV( normal, fu, fv, PI_X2 * rnd( seed ), sqrt1( a ), sqrt1( 1.0f - a ) );
 	}
 
 	return out;
@@ -1293,7 +1311,7 @@ PT_DEV f3 newRayDir( f3 dir, f3 normal, const Material& mtl, float& seed, bool& 
 		return refract( dir, normal, mtl, seed );
 	}
 
-	return ( BRDF == 0 ) ? newRaySchlick( dir, normal, mtl, seed ) : newRaySA<CALLS>( dir, normal, mtl, seed, frame );
+	return ( BRDF == 0 ) ? newRaySchlick( dir, normal, mtl, seed, frame ) : newRaySA<CALLS>( dir, normal, mtl, seed, frame );
 }
 
 // The factor updateColor multiplies `color` by (pathtracing.cl:98-124 Schlick, :127-177 S-A).
@@ -1303,7 +1321,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const
 
 	if( BRDF == 0 ) {
 		float u, pdf;
-		float brdf = brdfSchlick( mtl, outDir, inDir, normal, &u, &pdf );
+		float brdf = brdfSchlick( mtl, outDir, inDir, normal, &u, &pdf, frame );
 		brdf *= fmax1( dot( normal, inDir ), 0.0f );
 		brdf = brdf / pdf;
 
@@ -1338,7 +1356,7 @@ PT_DEV bool shadowContribution(
 
 	if( BRDF == 0 ) {
 		float u, pdf;
-		float brdf = brdfSchlick( mtl, outDir, lightDir, normal, &u, &pdf );
+		float brdf = brdfSchlick( mtl, outDir, lightDir, normal, &u, &pdf, frame );
 
 		if( !( __builtin_fabsf( pdf ) > 0.00001f ) ) {
 			return false;

@@ -10,6 +10,10 @@ how = ("rocprofv3 --pmc, separate passes of `python bench.py --scene S --steps K
        "writes = WRITE_SIZE KB; Infinity-Cache hits are included; the timed path-tracing launch only")
 for sc, r in d.items():
     b = r["bench"]; cfg = b["config"]
+    # the stats pass may have been redone (scripts/profile_stats_only.sh): read it from its files, not from the summary
+    r["bench_under_rocprof"] = json.loads(open("%s/stats_%s.json" % (src, sc)).read().strip().splitlines()[-1])
+    rows = list(csv.DictReader(open(glob.glob("%s/stats_%s/*/*_kernel_stats.csv" % (src, sc))[0])))
+    r["kernel_stats"] = [x for x in rows if "ptk::" in x["Name"]]
     os.makedirs(dst + "/" + sc, exist_ok=True)
     json.dump(b, open(dst + "/" + sc + "/bench_line.json", "w"), indent=1)
     json.dump(r["bench_under_rocprof"], open(dst + "/" + sc + "/bench_line_under_rocprof.json", "w"), indent=1)
