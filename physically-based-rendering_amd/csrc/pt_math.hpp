@@ -144,6 +144,16 @@ PT_DEV float atan1( float xx ) {
 // ---- pow: exp2( y * log2( x ) ) in binary64 ----------------------------------------------
 PT_DEV double fmad( double a, double b, double c ) { return __builtin_fma( a, b, c ); }
 
+// fma( a, b, c ) with the constant c in a scalar register pair.  A binary64 literal cannot be an operand, and left to
+// itself the compiler puts each polynomial coefficient into a VGPR pair with two v_mov_b32 next to every v_fma_f64: a
+// third of pow's vector instructions.  As an SGPR operand the constant costs two s_mov_b32 on the scalar unit, which
+// these kernels leave half idle, and nothing on the vector unit that bounds them.  Same operation, same result.
+PT_DEV double fmaConst( double a, double b, double c ) {
+	double r;
+	asm( "v_fma_f64 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( b ), "s"( c ) );
+	return r;
+}
+
 PT_DEV double log2_d( double a ) {
 	const unsigned long long bits = (unsigned long long) __double_as_longlong( a );
 	int e = (int) ( ( bits >> 52 ) & 0x7ffULL ) - 1023;
@@ -157,13 +167,13 @@ PT_DEV double log2_d( double a ) {
 	const double s = ( m - 1.0 ) / ( m + 1.0 );
 	const double s2 = s * s;
 	double p = 0x1.e1e1e1e1e1e1ep-5;
-	p = fmad( p, s2, 0x1.1111111111111p-4 );
-	p = fmad( p, s2, 0x1.3b13b13b13b14p-4 );
-	p = fmad( p, s2, 0x1.745d1745d1746p-4 );
-	p = fmad( p, s2, 0x1.c71c71c71c71cp-4 );
-	p = fmad( p, s2, 0x1.2492492492492p-3 );
-	p = fmad( p, s2, 0x1.999999999999ap-3 );
-	p = fmad( p, s2, 0x1.5555555555555p-2 );
+	p = fmaConst( p, s2, 0x1.1111111111111p-4 );
+	p = fmaConst( p, s2, 0x1.3b13b13b13b14p-4 );
+	p = fmaConst( p, s2, 0x1.745d1745d1746p-4 );
+	p = fmaConst( p, s2, 0x1.c71c71c71c71cp-4 );
+	p = fmaConst( p, s2, 0x1.2492492492492p-3 );
+	p = fmaConst( p, s2, 0x1.999999999999ap-3 );
+	p = fmaConst( p, s2, 0x1.5555555555555p-2 );
 	p = fmad( p, s2, 1.0 );
 	const double ln_m = 2.0 * s * p;
 
@@ -174,16 +184,16 @@ PT_DEV double exp2_d( double t ) {
 	const double n = __builtin_rint( t );
 	const double g = ( t - n ) * 0x1.62e42fefa39efp-1;
 	double p = 0x1.6124613a86d09p-33;
-	p = fmad( p, g, 0x1.1eed8eff8d898p-29 );
-	p = fmad( p, g, 0x1.ae64567f544e4p-26 );
-	p = fmad( p, g, 0x1.27e4fb7789f5cp-22 );
-	p = fmad( p, g, 0x1.71de3a556c734p-19 );
-	p = fmad( p, g, 0x1.a01a01a01a01ap-16 );
-	p = fmad( p, g, 0x1.a01a01a01a01ap-13 );
-	p = fmad( p, g, 0x1.6c16c16c16c17p-10 );
-	p = fmad( p, g, 0x1.1111111111111p-7 );
-	p = fmad( p, g, 0x1.5555555555555p-5 );
-	p = fmad( p, g, 0x1.5555555555555p-3 );
+	p = fmaConst( p, g, 0x1.1eed8eff8d898p-29 );
+	p = fmaConst( p, g, 0x1.ae64567f544e4p-26 );
+	p = fmaConst( p, g, 0x1.27e4fb7789f5cp-22 );
+	p = fmaConst( p, g, 0x1.71de3a556c734p-19 );
+	p = fmaConst( p, g, 0x1.a01a01a01a01ap-16 );
+	p = fmaConst( p, g, 0x1.a01a01a01a01ap-13 );
+	p = fmaConst( p, g, 0x1.6c16c16c16c17p-10 );
+	p = fmaConst( p, g, 0x1.1111111111111p-7 );
+	p = fmaConst( p, g, 0x1.5555555555555p-5 );
+	p = fmaConst( p, g, 0x1.5555555555555p-3 );
 	p = fmad( p, g, 0.5 );
 	p = fmad( p, g, 1.0 );
 	p = fmad( p, g, 1.0 );
