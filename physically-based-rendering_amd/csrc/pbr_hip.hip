@@ -603,10 +603,10 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// foldFrames applies setColors in frame order.  The buffer (16 B per pixel and frame) is capped,
 	// longer renders run as several launch pairs.
 	//
-	// Which kernel: the lock-step walk ("refill") or the lane state machine ("phased"), each with the
-	// lean (4 waves / SIMD, no spills) or the wide (8 waves / SIMD) register budget, the state machine also at 6.  Which one wins
-	// depends on the scene (1080p: Cornell refill-lean 3470 vs phased-lean 2760 Msamples/s, dragon-class
-	// phased-lean 1380 vs refill-wide 1000), and all of them give the same bits — so the first frames
+	// Which kernel: the lock-step walk ("refill") or the lane state machine ("phased"), each with the lean
+	// (4 waves / SIMD, no spills), the mid (6) or the wide (8 waves / SIMD) register budget.  Which one wins
+	// depends on the scene (1080p: Cornell refill-mid 4250 vs phased-mid 3650 Msamples/s, dragon-class
+	// phased-mid 1900 vs refill-wide 1000), and all of them give the same bits — so the first frames
 	// of a scene + configuration, which have to be rendered anyway, are rendered in turn by each
 	// candidate (kTuneFrames each) and timed; short launches favour the plans with fewer, larger blocks,
 	// so the two or three fastest (the third only if within 10 % of the first) are timed again on short and long chunks,
@@ -660,7 +660,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		}
 	}
 
-	if( const char* plan = std::getenv( "PBR_PLAN" ) ) {   // experiments: 0..3 = the candidates above, no tuning
+	if( const char* plan = std::getenv( "PBR_PLAN" ) ) {   // experiments: 0..5 = the candidates above, no tuning
 		forcedPlan = std::max( 0, std::min( kPlans - 1, std::atoi( plan ) ) );
 	}
 
@@ -771,7 +771,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		int choice = forcedPlan;
 		bool tuning = false;
 
-		int refining = -1;   // index into refinePlan while the two fastest are compared
+		int refining = -1;   // index into refinePlan while the finalists are compared
 
 		if( choice < 0 ) {
 			choice = ctx->tunedPlan;
