@@ -184,6 +184,24 @@ def test_larger_scenes_bit_exact(pbr, oracle, device, monkeypatch, kind, triangl
     assert device.counters() == ref.counter_dict()
 
 
+@pytest.mark.parametrize("plan,name", [(0, "refill-lean"), (1, "refill-wide"), (2, "phased-lean"), (3, "phased-wide"), (4, "phased-mid"), (5, "refill-mid")])
+@pytest.mark.parametrize("kind,triangles,cfg", [
+    ("cornell", 0, {"render.max_depth": 5, "render.max_added_depth": 2}),
+    ("dragon", 12000, {"render.max_depth": 3, "render.brdf": 0}),
+    ("hairball", 9000, {"render.max_depth": 3, "render.samples": 2}),
+])
+def test_every_tuner_candidate_bit_exact(pbr, oracle, device, monkeypatch, plan, name, kind, triangles, cfg):
+    """The six plans launch() chooses from (PBR_PLAN pins one): 4, 6 and 8 waves per SIMD of the lock-step kernel and of
+    the lane state machine, 768- and 1024-thread blocks — each against the oracle, images, debug image and counters."""
+    monkeypatch.setenv("PBR_PLAN", str(plan))
+    sc = make_scene(pbr, kind, 7, triangles, **cfg)
+    got, want, ref = both_render(pbr, oracle, device, sc, 88, 56, 6)
+    assert device.last_plan()[0] == name
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert same_values(device.read_debug(), ref.debug)
+    assert device.counters() == ref.counter_dict()
+
+
 def test_schedule_tuner_through_a_viewer_then_a_batch(pbr, oracle, device):
     """No schedule forced: launch() screens its six plans, times the finalists and keeps one (pbr_hip.hip) — on
     frame-by-frame calls first, as the reference's viewer renders (PathTracer.cpp:60-68), which cannot separate a
