@@ -14,7 +14,7 @@ accumulated image are resident in HBM before the timed region starts.  Default w
 BASELINE.json configs[1]: Cornell box, 1920x1080, 256 spp, depth 8, 1 GPU.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): 8x8-pixel tiles are dealt
-round-robin to the ranks (tile t -> rank t % N), the scene is replicated, no collective on the
+round-robin to the ranks (along a row-rotated order, tiles.py: a rank never gets whole tile columns), the scene is replicated, no collective on the
 data path; the timed region ends with one RCCL all-gather of the compact tile buffers
 (W*H*16/N bytes per rank) and the scatter into the full frame.  The total work is fixed, so
 this is strong scaling.
@@ -237,7 +237,7 @@ def main():
                 "scene": args.scene, "triangles": scene.info["faces"], "bvh_nodes": scene.info["flat_nodes"],
                 "width": w, "height": h, "spp": args.steps * int(cfg.samples), "max_depth": depth,
                 "max_added_depth": int(cfg.max_added_depth), "brdf": int(cfg.brdf),
-                "seeds": "seed_k = 0.0333 * (k + 1)", "tiles": "8x8 px, tile t -> rank t %% %d" % world,
+                "seeds": "seed_k = 0.0333 * (k + 1)", "tiles": "8x8 px, dealt round-robin to %d rank(s) along rows rotated by 5 * row columns" % world,
                 "host_bvh_build_s": round(t_build, 3),
             },
             "setup_frames": setup_frames, "kernel_ms": kernel_ms, "schedule": plan, "schedule_tuned": tuned >= 0, "trace_launches": trace_launches,

@@ -85,10 +85,13 @@ typedef struct {
 	uint32_t max_added_depth;     /* MAX_ADDED_DEPTH */
 	uint32_t samples;             /* SAMPLES (paths per pixel per frame) */
 	float anti_aliasing;          /* ANTI_ALIASING */
-	float phong_tessellation;     /* PHONGTESS_ALPHA; > 0 is rejected (not built, off in the reference's config) */
+	float phong_tessellation;     /* PHONGTESS_ALPHA; > 0 = PHONGTESS on (pt_phongtess.cl; needs facesN / normals in the scene), 0 = flat triangles */
 	float sky_light[4];           /* SKY_LIGHT */
 	/* Tile sharding (not in the reference, which is single-device): this context renders the
-	 * 8x8-pixel tiles t with t % tile_world == tile_rank.  1 / 0 = everything. */
+	 * 8x8-pixel tiles whose position p in the dealing order has p % tile_world == tile_rank, where tile (tx, ty) has
+	 * p = ty * tilesX + ( tx + 5 * ty ) % tilesX (row-major with row ty rotated by 5 * ty columns: plain row-major
+	 * order would hand a rank whole tile columns whenever tilesX is a multiple of tile_world, and columns do not cost
+	 * the same).  Local tile j of a rank is the tile at p = j * tile_world + tile_rank.  1 / 0 = everything, p = tile. */
 	uint32_t tile_world, tile_rank;
 } pbr_config;
 
@@ -173,8 +176,8 @@ double pbr_last_kernel_ms( const pbr_ctx* ctx );
 
 /* Bytes of this rank's compact tile buffer: ceil( tiles / tile_world ) * 1024. */
 uint64_t pbr_tile_bytes( const pbr_ctx* ctx );
-/* Copy this rank's tiles of imageOut (local tile j = global tile j * tile_world + tile_rank,
- * 64 pixels x RGBA32F each) to d_dst on this context's stream and wait. */
+/* Copy this rank's tiles of imageOut (local tile j = the tile at dealing position j * tile_world + tile_rank,
+ * see pbr_config; 64 pixels x RGBA32F each) to d_dst on this context's stream and wait. */
 int pbr_export_tiles( pbr_ctx* ctx, void* d_dst );
 /* d_all = tile_world consecutive rank buffers (all-gather layout).  Scatters every tile into
  * this context's full-frame buffer; the context's own sharding is unchanged. */

@@ -40,6 +40,7 @@ struct pbr_ctx {
 	uint32_t numHotAvail = 0;      // records at the head of the node stream that are ranked for LDS staging
 	int firstRef = 0;              // record of node 1
 	uint32_t numNodes = 0, numFaces = 0, numMaterials = 0, numLights = 0;
+	uint32_t tilesXMagic = 0;      // see pbr_configure
 	uint32_t sceneBrdf = 1;
 
 	// configuration + images
@@ -454,6 +455,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	P.width = (int) ctx->cfg.width;
 	P.height = (int) ctx->cfg.height;
 	P.tilesX = ctx->tilesX;
+	P.tilesXMagic = ctx->tilesXMagic;
 	P.numLocalTiles = ctx->numLocalTiles;
 	// the local tiles as a grid for the banded queue: its true shape when unsharded, about that when sharded
 	P.queueWidth = std::max( 1, ( ctx->tilesX + (int) ctx->cfg.tile_world - 1 ) / (int) ctx->cfg.tile_world );
@@ -1296,6 +1298,21 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	// tiles t = j * world + rank, j = 0 .. : count those below numTiles
 	ctx->numLocalTiles = ( ctx->numTiles - (int) cfg->tile_rank + (int) cfg->tile_world - 1 ) / (int) cfg->tile_world;
 
+	// beginPixel divides tile positions (and PT_DEAL_SHIFT x tile rows) by tilesX once per unit of work: as a
+	// multiplication where that is exact for every value that can occur — checked here, value by value
+	{
+		const uint64_t d = (uint64_t) ctx->tilesX;
+		const uint64_t magic = ( 1ull << 32 ) / d + 1ull;
+		const uint64_t largest = std::max<uint64_t>( (uint64_t) ctx->numTiles + cfg->tile_world, (uint64_t) PT_DEAL_SHIFT * ( (uint64_t) ctx->numTiles / d + 1 ) );
+		bool exact = ( magic < ( 1ull << 32 ) );
+
+		for( uint64_t x = 0; exact && x <= largest; x++ ) {
+			exact = ( ( x * magic ) >> 32 ) == x / d;
+		}
+
+		ctx->tilesXMagic = exact ? (uint32_t) magic : 0u;
+	}
+
 	// Every context can hold the full image (import_tiles scatters all ranks' tiles into imgOut).
 	const size_t fullBytes = sizeof( float4 ) * 64 * (size_t) ctx->numTiles;
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dImgIn, fullBytes ) );
@@ -1411,10 +1428,11 @@ int pbr_get_focus_depth( pbr_ctx* ctx, int x, int y, float* t, int* owned ) {
 	const int fy = std::max( 0, std::min( (int) ctx->cfg.height - 1, y ) );
 	const int tile = ( fy >> 3 ) * ctx->tilesX + ( fx >> 3 );
 	*t = 0.0f;
-	*owned = ( tile % (int) ctx->cfg.tile_world == (int) ctx->cfg.tile_rank ) ? 1 : 0;
+	const int position = ptk::dealPositionOfTile( tile, ctx->tilesX, (int) ctx->cfg.tile_world );
+	*owned = ( position % (int) ctx->cfg.tile_world == (int) ctx->cfg.tile_rank ) ? 1 : 0;
 
 	if( *owned ) {
-		const size_t slot = (size_t) ( tile / (int) ctx->cfg.tile_world ) * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) );
+		const size_t slot = (size_t) ( position / (int) ctx->cfg.tile_world ) * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) );
 		float4 pixel;
 		HIP_TRY( ctx, hipSetDevice( ctx->device ) );
 		HIP_TRY( ctx, hipMemcpyAsync( &pixel, ctx->dImgIn + slot, sizeof( pixel ), hipMemcpyDeviceToHost, ctx->stream ) );
@@ -1526,7 +1544,7 @@ int pbr_import_tiles( pbr_ctx* ctx, const void* d_all ) {
 	const int perRank = ( ctx->numTiles + (int) ctx->cfg.tile_world - 1 ) / (int) ctx->cfg.tile_world;
 	const size_t n = (size_t) ctx->numTiles * 64;
 	hipLaunchKernelGGL( ptk::scatterGathered, dim3( (unsigned) ( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, ctx->stream,
-		(const float4*) d_all, ctx->dFull, ctx->numTiles, perRank, (int) ctx->cfg.tile_world );
+		(const float4*) d_all, ctx->dFull, ctx->numTiles, perRank, (int) ctx->cfg.tile_world, ctx->tilesX );
 	HIP_TRY( ctx, hipGetLastError() );
 	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
 	return PBR_OK;

@@ -65,6 +65,7 @@ struct DevParams {
 	float lenseFocal, lenseAperture;
 
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
+	unsigned tilesXMagic;   // floor( x / tilesX ) == umulhi( x, tilesXMagic ) for every x the kernels divide (checked by the host); 0: divide
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
 	float phongAlpha;            // PHONGTESS_ALPHA (kernels built with PHONG = true only)
 	int parkEighths;             // traverse(): a node phase ends once this many eighths of the lanes that entered it have left it
@@ -83,6 +84,37 @@ struct DevParams {
 	// machine the extra pointer costs more in registers than the 40 instructions per hit are worth (measured -2 %).
 	const float4* faceN;
 };
+
+// ---- which rank owns which tile (multi-GPU sharding) -----------------------------------------
+// Tiles are dealt round-robin along a DEALING ORDER: row-major, but row ty rotated by PT_DEAL_SHIFT * ty columns.
+// position p of tile (tx, ty) = ty * tilesX + ( tx + PT_DEAL_SHIFT * ty ) % tilesX;  owner = p % world, local index =
+// p / world.  Dealing along the plain row-major order gives every rank whole tile COLUMNS whenever tilesX is a multiple
+// of world (1080p: 240 columns, 8 ranks), and columns do not cost the same: measured 2.6 % (Cornell) and 2.3 %
+// (Dragon-class) more work on the heaviest of 8 ranks than on the average one; along the rotated order 0.04 % / 0.2 %
+// (scripts/tile_balance.py).  With world = 1 there is nothing to deal and the order is the plain one.
+#define PT_DEAL_SHIFT 5
+
+__host__ __device__ inline int dealPositionOfTile( int tileGlobal, int tilesX, int world ) {
+	if( world <= 1 ) {
+		return tileGlobal;
+	}
+
+	const int ty = tileGlobal / tilesX;
+	const int tx = tileGlobal - ty * tilesX;
+	return ty * tilesX + ( tx + PT_DEAL_SHIFT * ty ) % tilesX;
+}
+
+__host__ __device__ inline int tileAtDealPosition( int position, int tilesX, int world ) {
+	if( world <= 1 ) {
+		return position;
+	}
+
+	const int ty = position / tilesX;
+	const int shifted = position - ty * tilesX;
+	const int back = ( PT_DEAL_SHIFT * ty ) % tilesX;
+	const int tx = ( shifted >= back ) ? shifted - back : shifted - back + tilesX;
+	return ty * tilesX + tx;
+}
 
 struct Ray {
 	f3 origin, dir;
@@ -1447,11 +1479,22 @@ PT_DEV void flushCounters( const DevParams& P, LaneCounters& c ) {
 // P.frameBuf and the running mean is folded afterwards, in frame order, by foldFrames.
 template<bool FP = false>
 PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneCounters& cnt, unsigned frame = 0u ) {
-	const int tileGlobal = (int) ( slot >> 6 ) * P.tileWorld + P.tileRank;
+	// tileAtDealPosition with the divisions by tilesX as multiplications (once per unit: a 32-bit division is ~20 instructions)
+	const unsigned tilesX = (unsigned) P.tilesX;
+	const unsigned position = ( slot >> 6 ) * (unsigned) P.tileWorld + (unsigned) P.tileRank;
+	const unsigned ty = ( P.tilesXMagic != 0u ) ? __umulhi( position, P.tilesXMagic ) : position / tilesX;
+	unsigned tx = position - ty * tilesX;
+
+	if( P.tileWorld > 1 ) {
+		const unsigned turn = (unsigned) PT_DEAL_SHIFT * ty;
+		const unsigned back = turn - ( ( P.tilesXMagic != 0u ) ? __umulhi( turn, P.tilesXMagic ) : turn / tilesX ) * tilesX;
+		tx = ( tx >= back ) ? tx - back : tx - back + tilesX;
+	}
+
 	const int inTile = (int) ( slot & 63u );
 	st.slot = slot;
-	st.px = ( tileGlobal % P.tilesX ) * 8 + ( inTile & 7 );
-	st.py = ( tileGlobal / P.tilesX ) * 8 + ( inTile >> 3 );
+	st.px = (int) tx * 8 + ( inTile & 7 );
+	st.py = (int) ty * 8 + ( inTile >> 3 );
 
 	st.acc = mk3( 0.0f, 0.0f, 0.0f );
 	st.accW = 0.0f;
@@ -2317,8 +2360,10 @@ __global__ void untile( const float4* tiles, float4* rows, int width, int height
 	const int tileGlobal = ( y >> 3 ) * tilesX + ( x >> 3 );
 	float4 v = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
 
-	if( tileGlobal % tileWorld == tileRank ) {
-		const int tileLocal = tileGlobal / tileWorld;
+	const int position = dealPositionOfTile( tileGlobal, tilesX, tileWorld );
+
+	if( position % tileWorld == tileRank ) {
+		const int tileLocal = position / tileWorld;
 		v = tiles[(size_t) tileLocal * 64 + (size_t) ( ( y & 7 ) * 8 + ( x & 7 ) )];
 	}
 
@@ -2339,8 +2384,10 @@ __global__ void displayRGBA8( const float4* tiles, uchar4* rows, int width, int 
 	const int tileGlobal = ( y >> 3 ) * tilesX + ( x >> 3 );
 	float4 v = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
 
-	if( tileGlobal % tileWorld == tileRank ) {
-		const int tileLocal = tileGlobal / tileWorld;
+	const int position = dealPositionOfTile( tileGlobal, tilesX, tileWorld );
+
+	if( position % tileWorld == tileRank ) {
+		const int tileLocal = position / tileWorld;
 		v = tiles[(size_t) tileLocal * 64 + (size_t) ( ( y & 7 ) * 8 + ( x & 7 ) )];
 	}
 
@@ -2366,14 +2413,14 @@ __global__ void retile( const float4* rows, float4* tiles, int width, int numLoc
 
 	const int tileLocal = (int) ( i >> 6 );
 	const int lane = (int) ( i & 63 );
-	const int tileGlobal = tileLocal * tileWorld + tileRank;
+	const int tileGlobal = tileAtDealPosition( tileLocal * tileWorld + tileRank, tilesX, tileWorld );
 	const int x = ( tileGlobal % tilesX ) * 8 + ( lane & 7 );
 	const int y = ( tileGlobal / tilesX ) * 8 + ( lane >> 3 );
 	tiles[i] = rows[(size_t) y * (size_t) width + (size_t) x];
 }
 
 // all-gather layout (tileWorld rank buffers of `perRank` tiles each) -> this context's full tile-major image
-__global__ void scatterGathered( const float4* all, float4* tiles, int numTiles, int perRank, int tileWorld ) {
+__global__ void scatterGathered( const float4* all, float4* tiles, int numTiles, int perRank, int tileWorld, int tilesX ) {
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 
 	if( i >= (size_t) numTiles * 64 ) {
@@ -2382,8 +2429,9 @@ __global__ void scatterGathered( const float4* all, float4* tiles, int numTiles,
 
 	const int tileGlobal = (int) ( i >> 6 );
 	const int lane = (int) ( i & 63 );
-	const int rank = tileGlobal % tileWorld;
-	const int local = tileGlobal / tileWorld;
+	const int position = dealPositionOfTile( tileGlobal, tilesX, tileWorld );
+	const int rank = position % tileWorld;
+	const int local = position / tileWorld;
 	tiles[i] = all[( (size_t) rank * perRank + local ) * 64 + lane];
 }
 
