@@ -376,6 +376,20 @@ int launchWavefront( pbr_ctx* ctx, DevParams P, bool shadow, bool lights ) {
 	return PBR_OK;
 }
 
+// {magic, shifts} with which ptk::divInvariant divides any 32-bit n by d exactly (d = 0 is never divided by: as 1)
+void invariantDivisor( unsigned d, unsigned out[2] ) {
+	d = ( d == 0u ) ? 1u : d;
+	unsigned l = 0;
+
+	while( ( 1ull << l ) < (unsigned long long) d ) {
+		l++;
+	}
+
+	const unsigned long long magic = ( ( 1ull << 32 ) * ( ( 1ull << l ) - d ) ) / d + 1ull;
+	out[0] = (unsigned) magic;
+	out[1] = ( l < 1u ? l : 1u ) | ( ( l > 0u ? l - 1u : 0u ) << 8 );
+}
+
 // The schedule tuner's chunk lengths are in 1080p-frame equivalents (launch()): how many of this context's frames make one.
 uint32_t tuneScaleOf( size_t localPixels ) {
 	const size_t reference = (size_t) 1920 * 1080;
@@ -460,6 +474,13 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// the local tiles as a grid for the banded queue: its true shape when unsharded, about that when sharded
 	P.queueWidth = std::max( 1, ( ctx->tilesX + (int) ctx->cfg.tile_world - 1 ) / (int) ctx->cfg.tile_world );
 	P.queueRows = ( ctx->numLocalTiles + P.queueWidth - 1 ) / P.queueWidth;
+
+	for( int band = 0; band < PT_BANDS; band++ ) {   // the two divisors of nextSlot, per band (same arithmetic as there)
+		const unsigned row0 = ( (unsigned) band * (unsigned) P.queueRows ) / PT_BANDS;
+		const unsigned rows = ( (unsigned) ( band + 1 ) * (unsigned) P.queueRows ) / PT_BANDS - row0;
+		invariantDivisor( rows * (unsigned) P.queueWidth * 64u, &P.bandDiv[band * 4 + 0] );
+		invariantDivisor( rows, &P.bandDiv[band * 4 + 2] );
+	}
 	P.tileWorld = (int) ctx->cfg.tile_world;
 	P.tileRank = (int) ctx->cfg.tile_rank;
 	P.numNodes = (int) ctx->numNodes;

@@ -41,6 +41,10 @@ using namespace ptm;
 #define M_PI_2_D 0x1.921fb54442d18p+0
 #define M_1_PI_D 0x1.45f306dc9c883p-2
 
+#ifndef PT_BANDS
+#define PT_BANDS 8
+#endif
+
 struct DevParams {
 	const float4* nodes;    // the node stream: 2 x float4 per record {min.xy, max.xy}, {min.z, max.z, w0, w1}, see decodeNode;
 	                        // the most-visited nodes first (every block copies records [0, numHot) to LDS)
@@ -65,6 +69,7 @@ struct DevParams {
 	float lenseFocal, lenseAperture;
 
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
+	unsigned bandDiv[PT_BANDS * 4];   // per queue band: {magic, shifts} to divide by its slot count, {magic, shifts} by its rows (nextSlot, divInvariant)
 	unsigned tilesXMagic;   // floor( x / tilesX ) == umulhi( x, tilesXMagic ) for every x the kernels divide (checked by the host); 0: divide
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
 	float phongAlpha;            // PHONGTESS_ALPHA (kernels built with PHONG = true only)
@@ -1772,9 +1777,6 @@ PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, La
 // instead of all of them.  Inside a band, tiles are dealt column by column, so the ~1024 tiles
 // that the waves of one XCD hold at a time form a compact block, not a 1920-pixel-wide strip.
 // Placement is for speed only: every slot is handed out exactly once whichever wave asks.
-#ifndef PT_BANDS
-#define PT_BANDS 8
-#endif
 #define PT_BAND_STRIDE 32   // words between queue heads: one 128-B line each
 #define PT_NO_WORK 0xFFFFFFFFu
 
@@ -1796,6 +1798,14 @@ PT_DEV WorkCursor beginWork() {
 // launches (frames > 1 units per pixel), which frame of it — or PT_NO_WORK.  Per-lane control flow on
 // purpose ("Toolchain notes"); the band index is made wave-uniform before the atomic so
 // that hipcc still folds the adds of the active lanes into one wave-level add.
+// n / d for a divisor that is fixed per launch, without dividing (Granlund & Montgomery 1994, the round-up variant:
+// exact for every 32-bit n): the host derives {magic, shifts} from d (pbr_hip.hip, invariantDivisor).  A 32-bit
+// division by a run-time value is ~20 instructions, and nextSlot runs whenever any lane of a wave takes a new unit.
+PT_DEV unsigned divInvariant( unsigned n, unsigned magic, unsigned shifts ) {
+	const unsigned t = __umulhi( magic, n );
+	return ( t + ( ( n - t ) >> ( shifts & 255u ) ) ) >> ( shifts >> 8 );
+}
+
 PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, unsigned& frame ) {
 	const unsigned width = (unsigned) P.queueWidth;
 	const unsigned rowsTotal = (unsigned) P.queueRows;
@@ -1818,13 +1828,13 @@ PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, u
 			continue;
 		}
 
-		frame = ( frames > 1u ) ? q / bandSlots : 0u;
+		frame = ( frames > 1u ) ? divInvariant( q, P.bandDiv[band * 4 + 0], P.bandDiv[band * 4 + 1] ) : 0u;
 		const unsigned qf = q - frame * bandSlots;
 		const unsigned tq = qf >> 6;
 #ifdef PBR_QUEUE_ROWMAJOR   // lab only: tiles of a band in row-major order
 		const unsigned tile = row0 * width + tq;
 #else
-		const unsigned col = tq / rows;
+		const unsigned col = divInvariant( tq, P.bandDiv[band * 4 + 2], P.bandDiv[band * 4 + 3] );
 		const unsigned row = tq - col * rows;
 		const unsigned tile = ( row0 + row ) * width + col;
 #endif
