@@ -1453,7 +1453,6 @@ struct PixelState {
 	int px, py;
 	f3 acc;                  // running mean over the frames done so far (imageIn -> imageOut)
 	float accW;
-	float tFocus, tObject;   // depth of field inputs (previous frame), -1 = off
 	// frame
 	int frame, sample;
 	f3 finalColor;
@@ -1482,6 +1481,22 @@ PT_DEV void flushCounters( const DevParams& P, LaneCounters& c ) {
 // Take up pixel `slot`: load the accumulated value and start the first path of frame `frame`.
 // FP (frame-parallel): the unit of work is ONE frame of the pixel; its {finalColor, focus} go to
 // P.frameBuf and the running mean is folded afterwards, in frame order, by foldFrames.
+// getPreviousFocus, pathtracing.cl:58-65 (single-frame launches only; CLAMP_TO_EDGE): the previous frame's first-hit
+// distance at the focus pixel and at this pixel, -1 = depth of field off.  imageIn does not change during a launch, so
+// the two values are re-read where a camera ray starts instead of living in two registers for the whole path.
+PT_DEV void focusInputs( const DevParams& P, unsigned slot, float* tFocus, float* tObject ) {
+	*tFocus = -1.0f;
+	*tObject = -1.0f;
+
+	if( P.focusX >= 0 && P.focusY >= 0 ) {
+		const int fx = ( P.focusX > P.width - 1 ) ? P.width - 1 : P.focusX;
+		const int fy = ( P.focusY > P.height - 1 ) ? P.height - 1 : P.focusY;
+		const int ft = ( fy >> 3 ) * P.tilesX + ( fx >> 3 );
+		*tObject = P.imgIn[slot].w;
+		*tFocus = P.focusGiven ? P.focusDepth : P.imgIn[(size_t) ft * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) )].w;
+	}
+}
+
 template<bool FP = false>
 PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneCounters& cnt, unsigned frame = 0u ) {
 	// tileAtDealPosition with the divisions by tilesX as multiplications (once per unit: a 32-bit division is ~20 instructions)
@@ -1510,18 +1525,6 @@ PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneC
 		st.accW = prev.w;
 	}
 
-	// getPreviousFocus, pathtracing.cl:58-65 (single-frame launches only; CLAMP_TO_EDGE)
-	st.tFocus = -1.0f;
-	st.tObject = -1.0f;
-
-	if( P.focusX >= 0 && P.focusY >= 0 ) {
-		const int fx = ( P.focusX > P.width - 1 ) ? P.width - 1 : P.focusX;
-		const int fy = ( P.focusY > P.height - 1 ) ? P.height - 1 : P.focusY;
-		const int ft = ( fy >> 3 ) * P.tilesX + ( fx >> 3 );
-		st.tObject = FP ? P.imgIn[slot].w : st.accW;
-		st.tFocus = P.focusGiven ? P.focusDepth : P.imgIn[(size_t) ft * 64 + (size_t) ( ( fy & 7 ) * 8 + ( fx & 7 ) )].w;
-	}
-
 	st.frame = (int) frame;
 	st.sample = 0;
 	st.finalColor = mk3( 0.0f, 0.0f, 0.0f );
@@ -1534,7 +1537,9 @@ PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneC
 	st.color = mk3( 1.0f, 1.0f, 1.0f );
 	st.depth = 0;
 	st.depthAdded = 0;
-	st.ray = initRay( P, st.px, st.py, st.seed, st.tFocus, st.tObject );
+	float tFocus, tObject;
+	focusInputs( P, slot, &tFocus, &tObject );
+	st.ray = initRay( P, st.px, st.py, st.seed, tFocus, tObject );
 	cnt.paths++;
 }
 
@@ -1750,7 +1755,9 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 	color = mk3( 1.0f, 1.0f, 1.0f );
 	depth = 0;
 	depthAdded = 0;
-	ray = initRay( P, st.px, st.py, seed, st.tFocus, st.tObject );
+	float tFocus, tObject;
+	focusInputs( P, st.slot, &tFocus, &tObject );
+	ray = initRay( P, st.px, st.py, seed, tFocus, tObject );
 	cnt.paths++;
 
 	return false;

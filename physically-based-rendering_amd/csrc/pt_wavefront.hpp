@@ -68,8 +68,6 @@ PT_DEV void loadState( const DevParams& P, const WfParams& W, unsigned s, PixelS
 	st.slot = s;
 	st.px = ( tileGlobal % P.tilesX ) * 8 + ( inTile & 7 );
 	st.py = ( tileGlobal / P.tilesX ) * 8 + ( inTile >> 3 );
-	st.tFocus = -1.0f;    // fused launches run without depth of field (pbr_render)
-	st.tObject = -1.0f;
 
 	st.ray.origin = mk3( c0.x, c0.y, c0.z );
 	st.seed = c0.w;
