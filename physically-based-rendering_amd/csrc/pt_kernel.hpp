@@ -1450,7 +1450,6 @@ PT_DEV unsigned waveSum( unsigned v ) {
 // Everything a lane carries for the pixel it is working on.
 struct PixelState {
 	unsigned slot;           // tile-major pixel slot: tile = slot >> 6, position in tile = slot & 63
-	int px, py;
 	f3 acc;                  // running mean over the frames done so far (imageIn -> imageOut)
 	float accW;
 	// frame
@@ -1481,6 +1480,26 @@ PT_DEV void flushCounters( const DevParams& P, LaneCounters& c ) {
 // Take up pixel `slot`: load the accumulated value and start the first path of frame `frame`.
 // FP (frame-parallel): the unit of work is ONE frame of the pixel; its {finalColor, focus} go to
 // P.frameBuf and the running mean is folded afterwards, in frame order, by foldFrames.
+// Image coordinates of a pixel slot of this rank: tileAtDealPosition with the divisions by tilesX as multiplications
+// (a 32-bit division is ~20 instructions).  Recomputed where a camera ray starts — once per path — rather than
+// kept in two registers for the whole path.
+PT_DEV void pixelOfSlot( const DevParams& P, unsigned slot, int* px, int* py ) {
+	const unsigned tilesX = (unsigned) P.tilesX;
+	const unsigned position = ( slot >> 6 ) * (unsigned) P.tileWorld + (unsigned) P.tileRank;
+	const unsigned ty = ( P.tilesXMagic != 0u ) ? __umulhi( position, P.tilesXMagic ) : position / tilesX;
+	unsigned tx = position - ty * tilesX;
+
+	if( P.tileWorld > 1 ) {
+		const unsigned turn = (unsigned) PT_DEAL_SHIFT * ty;
+		const unsigned back = turn - ( ( P.tilesXMagic != 0u ) ? __umulhi( turn, P.tilesXMagic ) : turn / tilesX ) * tilesX;
+		tx = ( tx >= back ) ? tx - back : tx - back + tilesX;
+	}
+
+	const int inTile = (int) ( slot & 63u );
+	*px = (int) tx * 8 + ( inTile & 7 );
+	*py = (int) ty * 8 + ( inTile >> 3 );
+}
+
 // getPreviousFocus, pathtracing.cl:58-65 (single-frame launches only; CLAMP_TO_EDGE): the previous frame's first-hit
 // distance at the focus pixel and at this pixel, -1 = depth of field off.  imageIn does not change during a launch, so
 // the two values are re-read where a camera ray starts instead of living in two registers for the whole path.
@@ -1499,22 +1518,7 @@ PT_DEV void focusInputs( const DevParams& P, unsigned slot, float* tFocus, float
 
 template<bool FP = false>
 PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneCounters& cnt, unsigned frame = 0u ) {
-	// tileAtDealPosition with the divisions by tilesX as multiplications (once per unit: a 32-bit division is ~20 instructions)
-	const unsigned tilesX = (unsigned) P.tilesX;
-	const unsigned position = ( slot >> 6 ) * (unsigned) P.tileWorld + (unsigned) P.tileRank;
-	const unsigned ty = ( P.tilesXMagic != 0u ) ? __umulhi( position, P.tilesXMagic ) : position / tilesX;
-	unsigned tx = position - ty * tilesX;
-
-	if( P.tileWorld > 1 ) {
-		const unsigned turn = (unsigned) PT_DEAL_SHIFT * ty;
-		const unsigned back = turn - ( ( P.tilesXMagic != 0u ) ? __umulhi( turn, P.tilesXMagic ) : turn / tilesX ) * tilesX;
-		tx = ( tx >= back ) ? tx - back : tx - back + tilesX;
-	}
-
-	const int inTile = (int) ( slot & 63u );
 	st.slot = slot;
-	st.px = (int) tx * 8 + ( inTile & 7 );
-	st.py = (int) ty * 8 + ( inTile >> 3 );
 
 	st.acc = mk3( 0.0f, 0.0f, 0.0f );
 	st.accW = 0.0f;
@@ -1539,7 +1543,9 @@ PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneC
 	st.depthAdded = 0;
 	float tFocus, tObject;
 	focusInputs( P, slot, &tFocus, &tObject );
-	st.ray = initRay( P, st.px, st.py, st.seed, tFocus, tObject );
+	int px, py;
+	pixelOfSlot( P, slot, &px, &py );
+	st.ray = initRay( P, px, py, st.seed, tFocus, tObject );
 	cnt.paths++;
 }
 
@@ -1757,7 +1763,9 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 	depthAdded = 0;
 	float tFocus, tObject;
 	focusInputs( P, st.slot, &tFocus, &tObject );
-	ray = initRay( P, st.px, st.py, seed, tFocus, tObject );
+	int px, py;
+	pixelOfSlot( P, st.slot, &px, &py );
+	ray = initRay( P, px, py, seed, tFocus, tObject );
 	cnt.paths++;
 
 	return false;

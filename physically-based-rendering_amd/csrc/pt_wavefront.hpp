@@ -63,11 +63,7 @@ PT_DEV void loadState( const DevParams& P, const WfParams& W, unsigned s, PixelS
 	const float4 c0 = p[0 * n], c1 = p[1 * n], c2 = p[2 * n], c3 = p[3 * n];
 	const float4 c4 = p[4 * n], c5 = p[5 * n], c6 = p[6 * n], c7 = p[7 * n];
 
-	const int tileGlobal = tileAtDealPosition( (int) ( s >> 6 ) * P.tileWorld + P.tileRank, P.tilesX, P.tileWorld );
-	const int inTile = (int) ( s & 63u );
 	st.slot = s;
-	st.px = ( tileGlobal % P.tilesX ) * 8 + ( inTile & 7 );
-	st.py = ( tileGlobal / P.tilesX ) * 8 + ( inTile >> 3 );
 
 	st.ray.origin = mk3( c0.x, c0.y, c0.z );
 	st.seed = c0.w;
