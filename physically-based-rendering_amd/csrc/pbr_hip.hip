@@ -475,12 +475,13 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	P.queueWidth = std::max( 1, ( ctx->tilesX + (int) ctx->cfg.tile_world - 1 ) / (int) ctx->cfg.tile_world );
 	P.queueRows = ( ctx->numLocalTiles + P.queueWidth - 1 ) / P.queueWidth;
 
-	for( int band = 0; band < PT_BANDS; band++ ) {   // the two divisors of nextSlot, per band (same arithmetic as there)
+	for( int band = 0; band < PT_BANDS; band++ ) {   // nextSlot divides by a band's rows (same arithmetic as there) ...
 		const unsigned row0 = ( (unsigned) band * (unsigned) P.queueRows ) / PT_BANDS;
 		const unsigned rows = ( (unsigned) ( band + 1 ) * (unsigned) P.queueRows ) / PT_BANDS - row0;
-		invariantDivisor( rows * (unsigned) P.queueWidth * 64u, &P.bandDiv[band * 4 + 0] );
-		invariantDivisor( rows, &P.bandDiv[band * 4 + 2] );
+		invariantDivisor( rows, &P.bandDiv[band * 2] );
 	}
+
+	invariantDivisor( 1u, P.framesDiv );   // ... and by the frames of the launch (set per chunk below)
 	P.tileWorld = (int) ctx->cfg.tile_world;
 	P.tileRank = (int) ctx->cfg.tile_rank;
 	P.numNodes = (int) ctx->numNodes;
@@ -829,6 +830,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		}
 
 		P.nFrames = (int) n;
+		invariantDivisor( n, P.framesDiv );
 		P.firstCount = (int) ( firstCount + done );
 		P.seeds = ctx->dSeeds + done;
 
