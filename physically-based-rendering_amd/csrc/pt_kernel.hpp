@@ -56,8 +56,8 @@ struct DevParams {
 	float4* imgOut;
 	float4* imgDbg;
 	const float* seeds;     // one per frame
-	float4* frameBuf;       // frame-parallel launches: {finalColor, focus} of frame k, pixel slot s at [k * frameStride + s]
-	unsigned frameStride;   // = numLocalTiles * 64
+	float4* frameBuf;       // frame-parallel launches: {finalColor, focus} of frame k, pixel slot s at frameBufIndex( s, k )
+	unsigned frameStride;   // = numLocalTiles * 64: the pixel slots of this launch
 	unsigned long long* counters;  // nodes, tris, hits, paths
 	unsigned int* workCounter;  // PT_BANDS heads, one per band of the pixel-slot queue, PT_BAND_STRIDE words apart (nextSlot)
 	unsigned int* guard;    // [0] tile-loop, [1] path-loop, [2] traversal trips (PBR_GUARD builds only)
@@ -1501,6 +1501,14 @@ PT_DEV void pixelOfSlot( const DevParams& P, unsigned slot, int* px, int* py ) {
 	*py = (int) ty * 8 + ( inTile >> 3 );
 }
 
+// Where {finalColor, focus} of frame k (of this launch) of a pixel slot lives in the frame buffer: rows of 8 slots
+// (8 x 16 B = one 128-byte line), the rows of the nFrames frames of such a group one after the other.  The 64 lanes
+// of a wave finish frames of one pixel (nextSlot), so their stores fall into one 8-KiB stretch (frame-major planes:
+// 64 pages 33 MB apart, Cornell -1.5 %), and foldFrames, one thread per slot, still reads whole lines.
+PT_DEV size_t frameBufIndex( const DevParams& P, unsigned slot, unsigned k ) {
+	return ( (size_t) ( slot >> 3 ) * (size_t) P.nFrames + (size_t) k ) * 8u + (size_t) ( slot & 7u );
+}
+
 // getPreviousFocus, pathtracing.cl:58-65 (single-frame launches only; CLAMP_TO_EDGE): the previous frame's first-hit
 // distance at the focus pixel and at this pixel, -1 = depth of field off.  imageIn does not change during a launch, so
 // the two values are re-read where a camera ray starts instead of living in two registers for the whole path.
@@ -1726,7 +1734,7 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 
 		if( FP ) {
 			// the unit ends here; foldFrames applies the running mean in frame order
-			P.frameBuf[(size_t) st.frame * P.frameStride + st.slot] = make_float4( finalColor.x, finalColor.y, finalColor.z, st.focus );
+			P.frameBuf[frameBufIndex( P, st.slot, (unsigned) st.frame )] = make_float4( finalColor.x, finalColor.y, finalColor.z, st.focus );
 			cnt.nodes += st.dbgNodes;
 			cnt.tris += st.dbgTris;
 			st.frame++;
@@ -2348,7 +2356,7 @@ __global__ __launch_bounds__( 256 ) void foldFrames( const DevParams P, const fl
 	float4 acc = src[slot];
 
 	for( int k = 0; k < P.nFrames; k++ ) {
-		const float4 fc = P.frameBuf[(size_t) k * P.frameStride + slot];
+		const float4 fc = P.frameBuf[frameBufIndex( P, slot, (unsigned) k )];
 		const unsigned n = (unsigned) ( P.firstCount + k );
 		const float w = P.useExplicitWeight ? P.explicitWeight : ( (float) n / (float) ( n + 1u ) );
 		acc.x = fc.x + ( acc.x - fc.x ) * w;
