@@ -78,3 +78,21 @@ def test_tile_layout_round_trip(pbr, world):
     assert (masks == 1).all()                       # every pixel has exactly one owner
     ids = np.concatenate([t.local_tile_ids(w, h, world, r) for r in range(world)])
     assert sorted(ids.tolist()) == list(range(45))
+
+
+@pytest.mark.parametrize("w,h,world", [(1920, 1080, 8), (1920, 1080, 4), (3840, 2160, 8), (72, 40, 3)])
+def test_dealing_order_spreads_every_rank_over_columns_and_rows(pbr, w, h, world):
+    """tiles.py / pt_kernel.hpp dealPositionOfTile: with plain row-major dealing a rank owns whole tile columns whenever
+    tiles_x is a multiple of world (240 columns, 8 ranks at 1080p) — measured 2.6 % more work on the heaviest rank.
+    Along the row-rotated order every rank has (almost) the same number of tiles in every column and in every row."""
+    t = pbr.tiles
+    tiles_x, tiles_y, total, per_rank = t.tile_counts(w, h, world)
+    seen = np.zeros(total, int)
+    for rank in range(world):
+        ids = t.local_tile_ids(w, h, world, rank)
+        seen[ids] += 1
+        cols = np.bincount(ids % tiles_x, minlength=tiles_x)
+        rows = np.bincount(ids // tiles_x, minlength=tiles_y)
+        assert cols.max() - cols.min() <= 2, (rank, cols.min(), cols.max())
+        assert rows.max() - rows.min() <= 2, (rank, rows.min(), rows.max())
+    assert (seen == 1).all()
