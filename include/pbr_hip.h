@@ -23,6 +23,7 @@
 #ifndef PBR_HIP_H
 #define PBR_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -109,6 +110,12 @@ const char* pbr_last_error( const pbr_ctx* ctx );
  * follow (links, face, vertex and material indices — the reference reads out of bounds for
  * material -1, ObjParser.cpp:140,192) and re-lays the arrays out for CDNA4. */
 int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* scene );
+/* The checks of pbr_upload_scene alone, without a context or a device (a host-side loader can vet a foreign BVH
+ * before it goes anywhere near a GPU): array sizes, every node's face / link words — miss links must be integers in
+ * [-1, N) that point FORWARD (the stackless walk of pt_bvh.cl:96-117 keeps no visited set; a backward link would make
+ * it circle forever) — leaf pairs k, k + 1, the last node a leaf, vertex and material indices of every face.
+ * Returns PBR_OK or PBR_EINVAL with the reason in message[capacity]. */
+int pbr_validate_scene( const pbr_scene_desc* scene, char* message, size_t capacity );
 
 /* CL::loadProgram + createKernel + initKernelArgs (PathTracer.cpp:225-229, :88-125) and
  * initOpenCLBuffers_Textures (:525-533): selects the kernel variant, allocates the three

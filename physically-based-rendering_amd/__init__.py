@@ -60,8 +60,7 @@ class Counters(ctypes.Structure):
 
 
 def _load(path, builder):
-    if not os.path.exists(path):
-        builder()
+    builder()      # a no-op unless the library is missing or older than its sources (build.py _stale)
     try:
         return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     except OSError:
@@ -90,6 +89,7 @@ hip.pbr_last_error.argtypes = [_vp]
 hip.pbr_last_error.restype = ctypes.c_char_p
 hip.pbr_upload_scene.argtypes = [_vp, ctypes.POINTER(SceneDesc)]
 hip.pbr_configure.argtypes = [_vp, ctypes.POINTER(Config)]
+hip.pbr_validate_scene.argtypes = [ctypes.POINTER(SceneDesc), ctypes.c_char_p, ctypes.c_size_t]
 hip.pbr_write_input.argtypes = [_vp, _fp]
 hip.pbr_reset_accum.argtypes = [_vp]
 hip.pbr_render_frame.argtypes = [_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.POINTER(Camera)]
@@ -186,6 +186,13 @@ def cfg_get(key):
     buf = ctypes.create_string_buffer(256)
     host.pbrh_cfg_get(key.encode(), buf, 256)
     return buf.value.decode()
+
+
+def validate_scene(desc):
+    """pbr_validate_scene: the upload's checks without a device.  Returns "" or the reason the scene is rejected."""
+    buf = ctypes.create_string_buffer(512)
+    status = hip.pbr_validate_scene(ctypes.byref(desc), buf, 512)
+    return "" if status == PBR_OK else (buf.value.decode() or "invalid scene")
 
 
 def pixel_dimension(width, height, fov=45.0):

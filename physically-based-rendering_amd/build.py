@@ -31,11 +31,31 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _stale(target, sources):
+def _digest(sources, flags=""):
+    """Content hash of the sources (and the build flags): mtimes do not survive the copy to the GPU box."""
+    import hashlib
+    h = hashlib.sha256(flags.encode())
+    for path in sorted(sources):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target, sources, flags=""):
+    """Missing, or built from other sources than the ones that are here now (the digest is kept next to the library)."""
     if not os.path.exists(target):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+    try:
+        with open(target + ".srchash") as f:
+            return f.read().strip() != _digest(sources, flags)
+    except OSError:
+        return True
+
+
+def _stamp(target, sources, flags=""):
+    with open(target + ".srchash", "w") as f:
+        f.write(_digest(sources, flags) + "\n")
 
 
 def _run(cmd):
@@ -47,7 +67,7 @@ def _run(cmd):
 
 
 def build_hip(force=False, guard=False):
-    sources = [os.path.join(CSRC, f) for f in ("pbr_hip.hip", "pt_kernel.hpp", "pt_math.hpp", "pt_wavefront.hpp")]
+    sources = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
     sources += [os.path.join(INCLUDE, f) for f in ("pbr_hip.h", "pbr_hip_diag.h")]
     target = HIP_GUARD_LIB if guard else HIP_LIB
     if not force and not _stale(target, sources):
@@ -61,13 +81,14 @@ def build_hip(force=False, guard=False):
         "-o", target, os.path.join(CSRC, "pbr_hip.hip"),
     ]
     _run(cmd)
+    _stamp(target, sources)
     return target
 
 
 def build_host(force=False):
     sources = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".cpp", ".h"))] + [os.path.join(INCLUDE, "pbr_hip.h")]
     build_hip()
-    if not force and not _stale(HOST_LIB, sources + [HIP_LIB]):
+    if not force and not _stale(HOST_LIB, sources):
         return HOST_LIB
     cmd = [
         "g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra",
@@ -76,6 +97,7 @@ def build_host(force=False):
         "-o", HOST_LIB, "-L", CSRC, "-lpbrhip", "-Wl,-rpath,$ORIGIN/../csrc",
     ]
     _run(cmd)
+    _stamp(HOST_LIB, sources)
     return HOST_LIB
 
 

@@ -1007,10 +1007,13 @@ const char* pbr_last_error( const pbr_ctx* ctx ) {
 	return ( ctx != nullptr ) ? ctx->error.c_str() : "null context";
 }
 
-int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
-	if( ctx == nullptr || ctx->stream == nullptr ) {
-		return fail( ctx, PBR_ESTATE, "context is not usable" );
-	}
+}  // extern "C"
+
+namespace {
+
+// Everything pbr_upload_scene checks before it touches the device: every index the kernels will follow.
+// face0s / links (optional): per node, first face or -1 (container) and second face / miss link.
+int checkScene( pbr_ctx* ctx, const pbr_scene_desc* s, std::vector<int>* face0sOut, std::vector<int>* linksOut ) {
 	if( s == nullptr || s->bvh == nullptr || s->facesV == nullptr || s->vertices == nullptr || s->materials == nullptr ) {
 		return fail( ctx, PBR_EINVAL, "scene: null array" );
 	}
@@ -1039,6 +1042,13 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 				return fail( ctx, PBR_EINVAL, "node %u: miss link %g is not an index", i, (double) n.bbMax.w );
 			}
 
+			// ... and FORWARD: the stackless walk has no visited set, so a ray that keeps missing a box whose link
+			// points at or before it would circle forever (the reference's flattening only emits links behind the
+			// subtree, PathTracer.cpp:300-330; -1 and 0 end the walk)
+			if( i > 0 && n.bbMax.w > 0.0f && n.bbMax.w <= (float) i ) {
+				return fail( ctx, PBR_EINVAL, "node %u: miss link %g must point forward (or be -1 / 0 = end of the walk)", i, (double) n.bbMax.w );
+			}
+
 			face0s[i] = -1;
 			links[i] = (int) n.bbMax.w;
 		}
@@ -1053,6 +1063,61 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 		}
 		else {
 			return fail( ctx, PBR_EINVAL, "node %u: bbMin.w = %g is neither -1 nor a face index", i, (double) n.bbMin.w );
+		}
+	}
+
+	if( face0s[s->num_nodes - 1] < 0 ) {
+		return fail( ctx, PBR_EINVAL, "node %u: the last node is a container (its children would lie outside the array)", s->num_nodes - 1 );
+	}
+
+	// ---- faces ----
+	for( uint32_t f = 0; f < s->num_faces; f++ ) {
+		const pbr_uint4& fv = s->facesV[f];
+
+		if( fv.x >= s->num_vertices || fv.y >= s->num_vertices || fv.z >= s->num_vertices ) {
+			return fail( ctx, PBR_EINVAL, "face %u: vertex index out of range", f );
+		}
+		if( fv.w >= s->num_materials ) {
+			return fail( ctx, PBR_EINVAL, "face %u: material index %u out of range (faces without usemtl carry -1)", f, fv.w );
+		}
+	}
+
+	if( face0sOut != nullptr ) {
+		face0sOut->swap( face0s );
+	}
+	if( linksOut != nullptr ) {
+		linksOut->swap( links );
+	}
+
+	return PBR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pbr_validate_scene( const pbr_scene_desc* s, char* message, size_t capacity ) {
+	pbr_ctx scratch;   // no device behind it: only its error string is used
+	const int status = checkScene( &scratch, s, nullptr, nullptr );
+
+	if( message != nullptr && capacity > 0 ) {
+		std::snprintf( message, capacity, "%s", scratch.error.c_str() );
+	}
+
+	return status;
+}
+
+int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
+	if( ctx == nullptr || ctx->stream == nullptr ) {
+		return fail( ctx, PBR_ESTATE, "context is not usable" );
+	}
+
+	std::vector<int> face0s, links;
+	{
+		const int checked = checkScene( ctx, s, &face0s, &links );
+
+		if( checked != PBR_OK ) {
+			return checked;
 		}
 	}
 
@@ -1133,10 +1198,6 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 		int w0, w1;
 
 		if( face0s[i] < 0 ) {
-			if( i + 1 >= N ) {
-				return fail( ctx, PBR_EINVAL, "node %u: the last node is a container (its children would lie outside the array)", i );
-			}
-
 			w0 = refOf( (long long) i + 1 );
 			w1 = refOf( links[i] );
 		}
@@ -1155,13 +1216,6 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 
 	for( uint32_t f = 0; f < s->num_faces; f++ ) {
 		const pbr_uint4& fv = s->facesV[f];
-
-		if( fv.x >= s->num_vertices || fv.y >= s->num_vertices || fv.z >= s->num_vertices ) {
-			return fail( ctx, PBR_EINVAL, "face %u: vertex index out of range", f );
-		}
-		if( fv.w >= s->num_materials ) {
-			return fail( ctx, PBR_EINVAL, "face %u: material index %u out of range (faces without usemtl carry -1)", f, fv.w );
-		}
 
 		const pbr_float4& a = s->vertices[fv.x];
 		const pbr_float4& b = s->vertices[fv.y];

@@ -283,6 +283,7 @@ void CL::execute( cl_kernel kernel ) {
 	need( ARG_CAMERA, &camera, sizeof( camera ) );
 
 	this->check( pbr_render_frame( mCtx, seed, weight, pxDim, &camera ), "pbr_render_frame" );
+	mOutputIsFresh = false;   // a new imageOut: nothing the caller holds matches it until the next readImageOutput
 }
 
 
@@ -328,6 +329,7 @@ void CL::readImageOutput( cl_mem image, size_t width, size_t height, cl_float* o
 	this->check( pbr_read_output( mCtx, outputTarget ), "pbr_read_output" );
 	mLastReadTarget = outputTarget;
 	mLastRead.assign( outputTarget, outputTarget + width * height * 4 );
+	mOutputIsFresh = true;   // imageOut on the device is what the caller now holds: feeding it back is one swap
 }
 
 
@@ -345,11 +347,17 @@ cl_mem CL::updateImageReadOnly( cl_mem image, size_t width, size_t height, cl_fl
 
 	// The reference feeds last frame's output back as this frame's input (PathTracer.cpp:61-67).
 	// When that is exactly what `data` holds, the image is already on the device.
-	if( !mSceneDirty && data == mLastReadTarget && mLastRead.size() == count &&
+	// Once: the swap turns imageOut into imageIn, so a second feed of the same buffer without a frame in between
+	// (reset the sample count, then re-feed) must not swap back — it uploads like the reference does.
+	if( !mSceneDirty && mOutputIsFresh && data == mLastReadTarget && mLastRead.size() == count &&
 	    std::memcmp( data, mLastRead.data(), count * sizeof( float ) ) == 0 ) {
 		this->check( pbr_accumulate( mCtx ), "pbr_accumulate" );
+		mOutputIsFresh = false;
+		mInputDirty = false;
 		return image;
 	}
+
+	mOutputIsFresh = false;
 
 	blob->bytes.assign( (const unsigned char*) data, (const unsigned char*) data + count * sizeof( float ) );
 	mInputDirty = true;

@@ -88,5 +88,6 @@ class CL {
 		bool mProgramLoaded, mSceneDirty, mInputDirty;
 		const cl_float* mLastReadTarget;    // where readImageOutput( imageOut ) last copied to
 		std::vector<float> mLastRead;       // and what
+		bool mOutputIsFresh = false;        // set by readImageOutput( imageOut ), cleared by the swap it allows and by execute()
 
 };

@@ -1,6 +1,11 @@
 #!/bin/bash
 # usage: scripts/pmc_one.sh <outdir> "<counters>" <kernel-substring> -- <command...>   one rocprofv3 --pmc pass
-out=$1; ctrs=$2; kern=$3; shift 4
+out=$1; ctrs=$2; kern=$3
+# The command after `--` must be the PROGRAM ITSELF (see scripts/pmc.sh): no env / bash -c / taskset / #!/usr/bin/env hop.
+if [ "$4" != "--" ] || [ $# -lt 5 ]; then echo "usage: $0 <outdir> \"<counters>\" <kernel-substring> -- python3 <script> [args]" >&2; exit 2; fi
+case "$(basename "$5")" in env|bash|sh|taskset|numactl|timeout|nice) echo "$0: '$5' re-execs: put the program itself after --" >&2; exit 2;; esac
+if [ -f "$5" ] && head -c 64 "$5" | grep -q '^#!.*env'; then echo "$0: '$5' is a #!/usr/bin/env script: run it as python3 $5" >&2; exit 2; fi
+shift 4
 export TMPDIR=/tmp
 mkdir -p $out
 timeout 200 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/run -- "$@" > $out/run.log 2>&1 || echo "failed/timeout: $ctrs"

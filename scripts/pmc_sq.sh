@@ -1,6 +1,13 @@
 #!/bin/bash
-# usage: scripts/pmc_sq.sh <outdir> <kernel-substring> -- <command...>   SQ-only counter passes (2 runs)
-out=$1; kern=$2; shift 3
+# usage: scripts/pmc_sq.sh <outdir> <kernel-substring> -- python3 <script> [args]   SQ-only counter passes (2 runs)
+out=$1; kern=$2
+# The command after `--` must be the PROGRAM ITSELF (python3 <script> ... or a binary): with --pmc the profiler's preload
+# initialises the GPU before the program starts, so env / bash -c / taskset / numactl / a "#!/usr/bin/env" script would be
+# an exec from a GPU-initialised process, which this pool refuses.  Set variables by exporting them before this script.
+if [ "$3" != "--" ] || [ $# -lt 4 ]; then echo "usage: $0 <outdir> <kernel-substring> -- python3 <script> [args]" >&2; exit 2; fi
+case "$(basename "$4")" in env|bash|sh|taskset|numactl|timeout|nice) echo "$0: '$4' re-execs: put the program itself after --" >&2; exit 2;; esac
+if [ -f "$4" ] && head -c 64 "$4" | grep -q '^#!.*env'; then echo "$0: '$4' is a #!/usr/bin/env script: run it as python3 $4" >&2; exit 2; fi
+shift 3
 export TMPDIR=/tmp
 mkdir -p $out
 sets=(

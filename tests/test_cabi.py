@@ -64,3 +64,48 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hpp", ".hip")):
                 text = open(os.path.join(base, f), errors="ignore").read().lower()
                 assert "pt_oracle" not in text and "liboracle" not in text and "import oracle" not in text, f
+
+
+def test_scene_validation_without_a_device(pbr):
+    """pbr_validate_scene = the checks of pbr_upload_scene, context-free.  A miss link that points backward (or at the
+    node itself) would make the stackless walk circle forever on the device: rejected before anything is uploaded."""
+    import numpy as np
+    pbr.cfg_reset()
+    sc = pbr.HostScene.generate("sponza", 3, 3000)
+    assert pbr.validate_scene(sc.desc) == ""
+    arr = sc.arrays()
+    inner = np.nonzero((arr["bvh"][:, 3] == -1.0) & (arr["bvh"][:, 7] > 0))[0]
+    assert len(inner) > 10
+
+    def with_bvh(nodes):
+        d = pbr.SceneDesc.from_buffer_copy(sc.desc)
+        d.bvh = nodes.ctypes.data
+        return d
+
+    i = int(inner[5])
+    for bad_link in (i, i - 1, 1):                                       # itself, the node before, node 1
+        nodes = arr["bvh"].copy()
+        nodes[i, 7] = bad_link
+        assert "must point forward" in pbr.validate_scene(with_bvh(nodes)), bad_link
+    for fine in (-1.0, 0.0, float(i + 1)):                               # end of the walk, or forward
+        nodes = arr["bvh"].copy()
+        nodes[i, 7] = fine
+        assert pbr.validate_scene(with_bvh(nodes)) == ""
+    nodes = arr["bvh"].copy()
+    nodes[i, 7] = 2.5
+    assert "not an index" in pbr.validate_scene(with_bvh(nodes))
+    nodes = arr["bvh"].copy()
+    nodes[-1, 3], nodes[-1, 7] = -1.0, -1.0
+    assert "last node is a container" in pbr.validate_scene(with_bvh(nodes))
+    faces = arr["facesV"].copy()
+    faces[7, 3] = 0xFFFFFFFF
+    d = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    d.facesV = faces.ctypes.data
+    assert "material index" in pbr.validate_scene(d)
+    faces = arr["facesV"].copy()
+    faces[7, 1] = sc.desc.num_vertices
+    d.facesV = faces.ctypes.data
+    assert "vertex index" in pbr.validate_scene(d)
+    d = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    d.num_nodes = 1
+    assert "root is never tested" in pbr.validate_scene(d)

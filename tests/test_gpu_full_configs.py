@@ -1,0 +1,165 @@
+"""BASELINE.json's three large configurations at THEIR OWN SIZE on the GPU (the stage and whole-image tests of
+test_gpu_parity.py use <= 20 000-triangle stand-ins the oracle can render in seconds):
+
+  configs[2]  Dragon-class, ~870 k triangles, 1920 x 1080
+  configs[3]  Sponza-class, ~260 k triangles, 1920 x 1080
+  configs[4]  hairball, 2 M triangles, 3840 x 2160
+
+i.e. million-node streams with the full LDS prefix and cold DFS tails, 8.3 M-pixel queues, renders that cross the
+16 GiB frame-buffer cap.  Per configuration: (a) a 16-row band of the image and of the debug image (per-pixel node /
+face-test counters, pathtracing.cl:73-78) against the oracle, for every one of the six schedules; (b) size-independent
+properties: run-to-run identical, 1 + 2 == 3 frames, paths == W * H * frames, the debug image sums to the launch's
+counters; (c) 8-way tile shards re-assemble the unsharded frame; (d) a render long enough for two launch pairs equals
+the same frames rendered in one-frame launches.  Walk: pt_bvh.cl:82-123; kernel: pathtracing.cl:207-334."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import same_values, describe_mismatch
+
+pytestmark = pytest.mark.gpu
+
+# name: (generator kind, seed, triangle budget, width, height, max_depth) — bench.py's WORKLOADS at BASELINE.json's sizes
+FULL = {
+    "dragon": ("dragon", 1, 870000, 1920, 1080, 3),
+    "sponza": ("sponza", 2, 260000, 1920, 1080, 3),
+    "hairball": ("hairball", 3, 2000000, 3840, 2160, 3),
+}
+PLANS = ["refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid"]
+
+_scenes = {}
+
+
+def full_scene(pbr, name):
+    """The scene (host BVH build: seconds at 2 M triangles) once per session."""
+    kind, seed, tris, w, h, depth = FULL[name]
+    pbr.cfg_reset()
+    pbr.cfg_set(**{"render.max_depth": depth})
+    if name not in _scenes:
+        _scenes[name] = pbr.HostScene.generate(kind, seed, tris)
+    sc = _scenes[name]
+    return sc, sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h), w, h
+
+
+@pytest.fixture()
+def device(pbr, gpu_device):
+    dev = pbr.Device(gpu_device)
+    yield dev
+    dev.close()
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_row_band_against_the_oracle_in_every_schedule(pbr, oracle, device, monkeypatch, name):
+    sc, cfg, cam, px, w, h = full_scene(pbr, name)
+    assert sc.info["faces"] > 0.95 * FULL[name][2]
+    frames = 3
+    seeds = pbr.frame_seeds(0, frames)
+    rows = (h // 2 - 8, h // 2 + 8)
+    ref = oracle.Renderer(sc.desc, cfg, threads=os.cpu_count() or 8)
+    for k, seed in enumerate(seeds):
+        out = ref.render_frame(float(seed), float(np.float32(k) / np.float32(k + 1)), px, cam, rows=rows)
+        ref.image[rows[0]:rows[1]] = out[rows[0]:rows[1]]
+    band = slice(rows[0], rows[1])
+    assert np.isfinite(ref.image[band][..., 3]).any(), "the band sees geometry"
+
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    first = None
+    for plan, plan_name in enumerate(PLANS):
+        monkeypatch.setenv("PBR_PLAN", str(plan))
+        device.reset_accum()
+        device.render(0, seeds, px, cam)
+        assert device.last_plan()[0] == plan_name
+        got, dbg = device.read_output(), device.read_debug()
+        assert same_values(got[band], ref.image[band]), plan_name + ": " + describe_mismatch(got[band], ref.image[band])
+        assert same_values(dbg[band], ref.debug[band]), plan_name + " debug: " + describe_mismatch(dbg[band], ref.debug[band])
+        assert device.counters()["paths"] == w * h * frames
+        if first is None:
+            first = (got, dbg, device.counters())
+        else:
+            assert same_values(got, first[0]) and same_values(dbg, first[1]), plan_name
+            assert device.counters() == first[2], plan_name
+    assert np.isfinite(first[0][..., :3]).all() and first[0][..., :3].min() >= 0.0
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_properties_at_full_size(pbr, device, name):
+    """No schedule forced: the tuner screens its plans on these very frames — whichever renders which frame, the bits
+    are the same."""
+    sc, cfg, cam, px, w, h = full_scene(pbr, name)
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    device.render(0, pbr.frame_seeds(0, 3), px, cam)
+    a = device.read_output()
+    assert device.counters()["paths"] == w * h * 3
+    device.reset_accum()
+    device.render(0, pbr.frame_seeds(0, 3), px, cam)
+    assert same_values(device.read_output(), a)                        # run-to-run identical
+    device.reset_accum()
+    device.render(0, pbr.frame_seeds(0, 1), px, cam)
+    before = device.counters()
+    device.render(1, pbr.frame_seeds(1, 2), px, cam)
+    assert same_values(device.read_output(), a)                        # 1 + 2 frames == 3 frames
+    after = device.counters()
+    # the debug image holds the LAST frame's per-pixel counters (x = face tests / 1082, y = node visits / 1265,
+    # pathtracing.cl:73-78): rendered alone, its sums are that launch's counters
+    device.render(3, pbr.frame_seeds(3, 1), px, cam)
+    last = device.counters()
+    dbg = device.read_debug().astype(np.float64)
+    nodes = np.rint(dbg[..., 1] * 1265.0).sum()
+    tris = np.rint(dbg[..., 0] * 1082.0).sum()
+    assert int(nodes) == last["nodes"] - after["nodes"] and int(tris) == last["tris"] - after["tris"]
+    assert after["paths"] - before["paths"] == w * h * 2
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_eight_way_shards_equal_the_unsharded_frame(pbr, device, name):
+    import torch
+    sc, cfg, cam, px, w, h = full_scene(pbr, name)
+    world, seeds = 8, pbr.frame_seeds(0, 2)
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    device.render(0, seeds, px, cam)
+    want, total = device.read_output(), device.counters()
+    d = pbr.Device(0)
+    d.upload_scene(sc.desc)
+    gathered = None
+    summed = {k: 0 for k in total}
+    for rank in range(world):
+        c = pbr.Config.from_buffer_copy(cfg)
+        c.tile_world, c.tile_rank = world, rank
+        d.configure(c)
+        d.render(0, seeds, px, cam)
+        if gathered is None:
+            gathered = torch.zeros(world * d.tile_bytes() // 4, dtype=torch.float32, device="cuda")
+        d.export_tiles(gathered.data_ptr() + rank * d.tile_bytes())
+        for k, v in d.counters().items():
+            summed[k] += v
+    torch.cuda.synchronize()
+    d.import_tiles(gathered.data_ptr())
+    got = d.read_full()
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert summed == total                                             # every path walked exactly once, same visits
+    d.close()
+
+
+@pytest.mark.parametrize("name", ["sponza", "hairball"])
+def test_render_across_the_frame_buffer_cap(pbr, device, name):
+    """A multi-frame render keeps {finalColor, focus} of every (pixel, frame) in a buffer capped at 16 GiB; beyond it
+    the render runs as several launch pairs (1080p: 517 frames, 3840 x 2160: 129).  Two pairs == the frames one by one,
+    as the reference's viewer renders them (PathTracer.cpp:59-71)."""
+    sc, cfg, cam, px, w, h = full_scene(pbr, name)
+    cap = (16 << 30) // (16 * w * h)
+    frames = cap + 3
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    device.render(0, pbr.frame_seeds(0, frames), px, cam)
+    assert device.last_trace()[1] == 2                                 # two path-tracing launches
+    fused = device.read_output()
+    assert device.counters()["paths"] == w * h * frames
+    device.reset_accum()
+    for k in range(frames):
+        device.render(k, pbr.frame_seeds(k, 1), px, cam)
+    single = device.read_output()
+    assert same_values(fused, single), describe_mismatch(fused, single)
