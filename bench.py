@@ -10,8 +10,11 @@ over all (pixel, frame) units + one foldFrames launch that applies the running m
 frames — during which the library also times its six schedules on this scene and keeps the
 fastest (2 frames each, then the best two or three again on 32 frames each: W >= 112, the default, settles it
 before the timed region; with a smaller W the difference is rendered as untimed set-up before the warm-up).  Scene arrays and the
-accumulated image are resident in HBM before the timed region starts.  Default workload =
-BASELINE.json configs[1]: Cornell box, 1920x1080, 256 spp, depth 8, 1 GPU.
+accumulated image are resident in HBM before the timed region starts.  Default workload = the configuration
+BASELINE.json's metric and north_star are quoted on: configs[3], Sponza-class (260 k triangles), 1920x1080, depth 3
+(--scene cornell | dragon | hairball select configs[1] / [2] / [4]).  When the K timed steps take less than 250 ms
+the K-step render is repeated (each repetition bracketed by barrier + synchronize, continuing the accumulation) and
+the MEDIAN repetition is reported — `repeats` and `ms_per_step_all` say so.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): 8x8-pixel tiles are dealt
 round-robin to the ranks (along a row-rotated order, tiles.py: a rank never gets whole tile columns), the scene is replicated, no collective on the
@@ -50,19 +53,27 @@ def algorithmic_bytes(counters, pixel_frames, samples_per_frame=1):
     return 32 * counters["nodes"] + 36 * counters["tris"] + 52 * counters["hits"] + 32 * pixel_frames
 
 
-def recorded_traffic(scene, w, h, depth, brdf, samples):
-    """HBM-side bytes per launch from the committed PMC passes (profiles/r01/pmc_traffic.json:
-    rocprofv3 --pmc in separate runs, TCC_EA0_RDREQ_* x request size + WRITE_SIZE, i.e. the gfx950
-    corrected form of FETCH_SIZE + WRITE_SIZE).  Only for the exact workload that was profiled;
-    scaled by the number of samples; None otherwise (PMC counters cannot be read from inside this run)."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    try:
-        rec = json.load(open(path)).get(scene)
-    except (OSError, ValueError):
-        return None
-    if not rec or (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) != (w, h, depth, brdf):
-        return None
-    return rec["bytes_per_sample"] * samples
+GATHER_CEILING_LINES = 56e9   # random dependent 32-B gathers from a table beyond L2, 128-B lines per second (scripts/micro/gather_rate.hip: 55-57 G/s)
+
+# what the counters say binds the kernel on each workload; "hbm" is the contract's ceiling for this path
+MEASURED_BOUND = {"cornell": "valu-issue", "sponza": "dependent-gather latency", "dragon": "dependent-gather latency",
+                  "hairball": "dependent-gather latency"}
+
+
+def recorded_traffic(scene, w, h, depth, brdf):
+    """Fabric-side bytes PER SAMPLE from the committed PMC passes (profiles/rNN/pmc_traffic.json: rocprofv3 --pmc in
+    separate runs; read = 128 x TCC_EA0_RDREQ_128B + 64 x _64B + 32 x _32B = 2 x FETCH_SIZE[KB] x 1024 on gfx950,
+    write = WRITE_SIZE, calibrated with scripts/calibrate.py) of the newest round that profiled exactly this workload;
+    None otherwise (PMC counters cannot be read from inside this run)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path)).get(scene)
+        except (OSError, ValueError):
+            continue
+        if rec and (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) == (w, h, depth, brdf):
+            return dict(rec, source=os.path.relpath(path, ROOT))
+    return None
 
 
 def diff(a, b):
@@ -96,9 +107,9 @@ def cpu_baseline(pbr, scene, cfg, cam, px, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=112)
-    ap.add_argument("--scene", default="cornell", choices=sorted(WORKLOADS))
+    ap.add_argument("--scene", default="sponza", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--triangles", type=int, default=-1, help="override the scene's triangle budget")
@@ -108,6 +119,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device: rehearse the N > 1 path on a single GPU (tests); the gather then goes through host memory")
     ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
+    ap.add_argument("--repeats", type=int, default=0, help="repetitions of the K-step render (0 = until 250 ms have been timed, at most 15); the median is reported")
     ap.add_argument("--dump", default="", help="rank 0 writes the gathered / rendered frame to this .npy")
     args = ap.parse_args()
 
@@ -175,14 +187,26 @@ def main():
         dev.import_tiles(gather_out.data_ptr())
 
     # set-up, untimed and outside the W warm-up steps: the schedule tuner needs dev.tune_budget() frames of this scene +
-    # configuration once (the counterpart of the reference's per-scene clBuildProgram).  With the default
-    # W = 112 the warm-up itself covers it; a caller who asks for a shorter warm-up gets the difference here, and the
-    # warm-up then starts the accumulation again at frame 0.
-    setup_frames = max(0, dev.tune_budget() - args.warmup)     # 108 frames at 1080p on one GPU, N x as many on a rank of N
-    if any(os.environ.get(k) for k in ("PBR_PLAN", "PBR_SCHEDULE", "PBR_VARIANT")):
-        setup_frames = 0                                       # a forced schedule: nothing to tune (profiling passes)
-    if setup_frames > 0:
-        dev.render(0, pbr.frame_seeds(0, setup_frames), px, cam)
+    # configuration once (the counterpart of the reference's per-scene clBuildProgram), rendered in
+    # calls of the length that will be timed, so that it settles on the plan that is fastest for THAT length.
+    # N > 1: rank 0 tunes on its share, its choice is broadcast and pinned on every rank — all ranks run one schedule.
+    forced = any(os.environ.get(k) for k in ("PBR_PLAN", "PBR_SCHEDULE", "PBR_VARIANT"))
+    setup_frames, t_setup = 0, time.perf_counter()
+    if not forced and (world == 1 or rank == 0):
+        budget = dev.tune_budget()                             # 108 frames at 1080p on one GPU, N x as many on a rank of N
+        while setup_frames < budget or dev.last_plan()[1] < 0:
+            n = max(1, min(args.steps, 4 * budget - setup_frames))
+            dev.render(setup_frames, pbr.frame_seeds(setup_frames, n), px, cam)
+            setup_frames += n
+            if setup_frames >= 4 * budget:
+                break
+    if world > 1 and not forced:
+        choice = torch.tensor([dev.last_plan()[1] if rank == 0 else -1], dtype=torch.int32,
+                              device="cuda" if args.backend == "nccl" else "cpu")
+        dist.broadcast(choice, src=0)
+        dev.pin_plan(int(choice[0]))
+    t_setup = time.perf_counter() - t_setup
+    dev.reset_accum()
 
     # warm-up: W frames (their own launch), accumulated image stays on the device
     if args.warmup > 0:
@@ -190,35 +214,86 @@ def main():
     gather()          # RCCL connects its rings on first use: not a cost of the timed steps
     before = dev.counters()
 
-    sync()
-    t0 = time.perf_counter()
-    dev.render(args.warmup, pbr.frame_seeds(args.warmup, args.steps), px, cam)   # synchronous: returns after the launch completed
-    kernel_ms = dev.last_kernel_ms()            # the whole render: path tracing + foldFrames
-    trace_ms, trace_launches = dev.last_trace()  # the path-tracing launches alone
+    # the timed region: EXACTLY K steps between barrier + synchronize on both sides; repeated (continuing the
+    # accumulation) while the repetitions so far took less than 250 ms, at most 15 times; the median repetition counts
+    runs, first = [], args.warmup
+    while True:
+        sync()
+        t0 = time.perf_counter()
+        dev.render(first, pbr.frame_seeds(first, args.steps), px, cam)   # synchronous: returns after the launch completed
+        t_render = time.perf_counter() - t0
+        kernel_ms = dev.last_kernel_ms()            # the whole render: path tracing + foldFrames
+        trace_ms, trace_launches = dev.last_trace()  # the path-tracing launches alone
+        gather()
+        sync()
+        elapsed = time.perf_counter() - t0
+        runs.append({"elapsed": elapsed, "render": t_render, "kernel_ms": kernel_ms, "trace_ms": trace_ms, "launches": trace_launches})
+        first += args.steps
+        more = (len(runs) < args.repeats) if args.repeats > 0 else (sum(r["elapsed"] for r in runs) < 0.25 and len(runs) < 15)
+        if world > 1:                                  # every rank must take the same decision
+            flag = torch.tensor([1 if more else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.broadcast(flag, src=0)
+            more = bool(int(flag[0]))
+        if not more:
+            break
     plan, tuned = dev.last_plan()
-    gather()
-    sync()
-    elapsed = time.perf_counter() - t0
+    repeats = len(runs)
 
     counters = diff(dev.counters(), before)
-    stats = [elapsed, trace_ms / trace_launches / 1e3, float(counters["nodes"]), float(counters["tris"]), float(counters["hits"]), float(counters["paths"])]
+    # per repetition: max over ranks of the elapsed time and of the average launch duration; then the median repetition
+    per_run = [[r["elapsed"], r["trace_ms"] / r["launches"] / 1e3, r["render"], r["elapsed"] - r["render"]] for r in runs]
+    totals = [float(counters["nodes"]), float(counters["tris"]), float(counters["hits"]), float(counters["paths"])]
+    rank_ms = None
     if world > 1:
-        t = torch.tensor(stats, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        where = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor(per_run, dtype=torch.float64, device=where)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, kernel_s = float(tmax[0]), float(tmax[1])
-        counters = {"nodes": int(t[2]), "tris": int(t[3]), "hits": int(t[4]), "paths": int(t[5])}
-    else:
-        kernel_s = trace_ms / trace_launches / 1e3   # average duration of one path-tracing launch
+        mine = torch.zeros(world, 2, dtype=torch.float64, device=where)
+        mid = sorted(range(repeats), key=lambda i: float(tmax[i, 0]))[repeats // 2]
+        mine[rank, 0], mine[rank, 1] = per_run[mid][2] * 1e3, per_run[mid][3] * 1e3
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        rank_ms = {"render": [round(float(v), 3) for v in mine[:, 0]], "gather": [round(float(v), 3) for v in mine[:, 1]]}
+        c = torch.tensor(totals, dtype=torch.float64, device=where)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        counters = {"nodes": int(c[0]), "tris": int(c[1]), "hits": int(c[2]), "paths": int(c[3])}
+        per_run = [[float(v) for v in row] for row in tmax]
+    order = sorted(range(repeats), key=lambda i: per_run[i][0])
+    median = order[repeats // 2]
+    elapsed, kernel_s = per_run[median][0], per_run[median][1]
+    kernel_ms, trace_launches = runs[median]["kernel_ms"], runs[median]["launches"]
 
     if rank == 0:
         samples = w * h * args.steps * int(cfg.samples)
-        assert counters["paths"] == samples, (counters, samples)
+        assert counters["paths"] == samples * repeats, (counters, samples, repeats)
+        counters = {k: v / repeats for k, v in counters.items()}       # per K-step render (every repetition does the same work up to the seeds)
         algo = algorithmic_bytes(counters, w * h * args.steps)
         # per launch of the dominant kernel (the path-tracing kernel the auto-tuner settled on): each rank runs
         # trace_launches of them per render; the slowest rank's average launch duration
         achieved = algo / world / trace_launches / kernel_s / 1e9
+        traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf))
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "ptk::pathTracingPhased" if plan.startswith("phased") else "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
+            "algorithmic_bytes_per_launch": algo / world / trace_launches,
+            "bound_measured": MEASURED_BOUND.get(args.scene),
+        }
+        if traffic is not None:
+            # measured fabric traffic (reads + writes behind L2, Infinity-Cache hits included) of this workload, scaled to
+            # this run's samples; `measured` = that traffic / the launch time / the HBM peak — what the memory system
+            # actually moved, next to `frac`, which prices every node visit at 32 B whether or not it left the CU
+            per_launch = traffic["bytes_per_sample"] * samples / world / trace_launches
+            lines = traffic["fabric_read_bytes_per_launch"] / 128.0 * (samples / world / trace_launches) / (traffic["width"] * traffic["height"] * traffic["steps"])
+            roofline.update({
+                "traffic": per_launch,
+                "traffic_source": traffic["source"] + " (separate rocprofv3 --pmc passes of this workload with schedule %s, scaled to this run's samples)" % traffic["schedule"],
+                "measured": per_launch / kernel_s / 1e9 / HBM_PEAK_GBS,
+                "measured_GBs": per_launch / kernel_s / 1e9,
+                "gather_ceiling": lines / kernel_s / GATHER_CEILING_LINES,
+                "gather_ceiling_note": "128-B lines fetched per second / 56 G/s, this chip's rate of dependent random 32-B gathers beyond L2 (scripts/micro/gather_rate.hip)",
+            })
         out = {
             "metric": "Msamples/s (paths/s) @1080p fixed seed; 1/2/4/8 MI355X scaling",
             "value": samples / elapsed / 1e6,
@@ -240,20 +315,17 @@ def main():
                 "seeds": "seed_k = 0.0333 * (k + 1)", "tiles": "8x8 px, dealt round-robin to %d rank(s) along rows rotated by 5 * row columns" % world,
                 "host_bvh_build_s": round(t_build, 3),
             },
-            "setup_frames": setup_frames, "kernel_ms": kernel_ms, "schedule": plan, "schedule_tuned": tuned >= 0, "trace_launches": trace_launches,
+            "repeats": repeats, "ms_per_step_all": [round(r[0] * 1e3 / args.steps, 5) for r in per_run],
+            "setup_frames": setup_frames, "setup_s": round(t_setup, 3),
+            "kernel_ms": kernel_ms, "schedule": plan, "schedule_tuned": tuned >= 0, "trace_launches": trace_launches,
             "per_sample": {
                 "node_visits": counters["nodes"] / samples, "triangle_tests": counters["tris"] / samples,
                 "shaded_hits": counters["hits"] / samples, "algorithmic_bytes": algo / samples,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), samples) or 0) / world / trace_launches or None,
-                "traffic_source": "profiles/r01/pmc_traffic.json (separate rocprofv3 --pmc passes of this workload, scaled to this run's samples)",
-                "kernel": "ptk::pathTracingPhased" if plan.startswith("phased") else "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
-                "algorithmic_bytes_per_launch": algo / world / trace_launches,
-            },
+            "roofline": roofline,
         }
+        if rank_ms is not None:
+            out["per_rank_ms"] = rank_ms
         if world == 1 and args.cpu_seconds > 0:
             cfg1 = scene.config(w, h)
             out["cpu_baseline"] = cpu_baseline(pbr, scene, cfg1, cam, px, args.cpu_seconds)

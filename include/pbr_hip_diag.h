@@ -46,6 +46,13 @@ int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t r
  * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
 int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
 
+/* Render with plan 0..5 (the order of pbr_diag_last_plan's *tuned: refill-lean, refill-wide, phased-lean, phased-wide,
+ * phased-mid, refill-mid) from now on, without tuning; -1 hands the choice back to the tuner.  For the ranks of a
+ * multi-GPU run: rank 0 tunes, broadcasts its *tuned, every rank pins it — all ranks then run the same schedule and
+ * none is a straggler of the closing all-gather because its own timing noise picked a slower plan.  Survives
+ * pbr_upload_scene / pbr_configure. */
+int pbr_diag_pin_plan( pbr_ctx* ctx, int plan );
+
 /* How many frames of the configured size the schedule tuner wants to see before it settles (its launch lengths are
  * fixed in 1080p-frame equivalents, so a rank of an N-GPU run needs N times as many): a benchmark renders that many
  * before it starts its clock. */

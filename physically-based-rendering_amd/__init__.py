@@ -120,6 +120,7 @@ hip.pbr_diag_new_ray.argtypes = [_vp, _fp, ctypes.c_int, _fp]
 hip.pbr_diag_guard_trips.argtypes = [_vp, _up]
 hip.pbr_diag_last_trace.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
 hip.pbr_diag_last_plan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+hip.pbr_diag_pin_plan.argtypes = [_vp, ctypes.c_int]
 hip.pbr_diag_tune_budget.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint32)]
 
 host.pbrh_last_error.restype = ctypes.c_char_p
@@ -432,6 +433,12 @@ class Device:
         name, tuned = ctypes.create_string_buffer(48), ctypes.c_int(-1)
         self._check(hip.pbr_diag_last_plan(self._ctx, name, 48, ctypes.byref(tuned)))
         return name.value.decode(), int(tuned.value)
+
+    PLAN_NAMES = ("refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid")
+
+    def pin_plan(self, plan):
+        """Render with schedule `plan` (index into PLAN_NAMES) without tuning; -1 = let the tuner choose."""
+        self._check(hip.pbr_diag_pin_plan(self._ctx, int(plan)))
 
     def tune_budget(self):
         """Frames of the configured size after which the schedule tuner has settled."""

@@ -59,6 +59,7 @@ struct pbr_ctx {
 	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
 	// frames that are rendered anyway, then the fastest one is kept
 	int tunedPlan = -1;
+	int pinnedPlan = -1;                            // pbr_diag_pin_plan: >= 0 renders with this plan, no tuning (ranks of a multi-GPU run: all the same)
 	uint32_t tuneRenderFrames = 0;                  // the longest render (frames per call) this context has been asked for
 	uint32_t tunedAtFrames = 0;                     // the render length tunedPlan was chosen for
 	double tuneMs[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
@@ -682,6 +683,10 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 				return made;
 			}
 		}
+	}
+
+	if( ctx->pinnedPlan >= 0 ) {
+		forcedPlan = std::min( kPlans - 1, ctx->pinnedPlan );
 	}
 
 	if( const char* plan = std::getenv( "PBR_PLAN" ) ) {   // experiments: 0..5 = the candidates above, no tuning
@@ -2013,6 +2018,15 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned ) 
 		*tuned = ctx->tunedPlan;
 	}
 
+	return PBR_OK;
+}
+
+int pbr_diag_pin_plan( pbr_ctx* ctx, int plan ) {
+	if( ctx == nullptr || plan < -1 || plan > 5 ) {
+		return fail( ctx, PBR_EINVAL, "diag_pin_plan: plan must be -1 (auto-tune) or 0..5" );
+	}
+
+	ctx->pinnedPlan = plan;
 	return PBR_OK;
 }
 

@@ -37,9 +37,36 @@ inline float centre( const Tri& t, int axis ) {
 	return ( t.bbMin[axis] + t.bbMax[axis] ) * 0.5f;
 }
 
-// MathHelp::triCalcAABB without Phong tessellation (MathHelp.cpp:239-257, :11-31):
-// component-wise min / max of the three corners.
-void triBox( Tri* tri, const std::vector<float>& v ) {
+// ---- small vector helpers with glm's evaluation order (dot: ( x + y ) + z; normalize: v * ( 1 / sqrt( dot ) )) ----
+struct V3 {
+	float x, y, z;
+};
+
+inline V3 operator+( V3 a, V3 b ) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+inline V3 operator-( V3 a, V3 b ) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline V3 operator*( V3 a, float s ) { return { a.x * s, a.y * s, a.z * s }; }
+inline V3 operator*( float s, V3 a ) { return { s * a.x, s * a.y, s * a.z }; }
+inline float dot3( V3 a, V3 b ) { return ( a.x * b.x + a.y * b.y ) + a.z * b.z; }
+inline V3 cross3( V3 a, V3 b ) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+inline V3 normalize3v( V3 a ) { return a * ( 1.0f / std::sqrt( dot3( a, a ) ) ); }
+inline V3 min3v( V3 a, V3 b ) { return { minf( a.x, b.x ), minf( a.y, b.y ), minf( a.z, b.z ) }; }
+inline V3 max3v( V3 a, V3 b ) { return { maxf( a.x, b.x ), maxf( a.y, b.y ), maxf( a.z, b.z ) }; }
+
+// MathHelp::projectOnPlane / phongTessellate, MathHelp.cpp:213-231
+inline V3 onPlane( V3 q, V3 p, V3 n ) { return q - dot3( q - p, n ) * n; }
+
+V3 phongPoint( V3 p1, V3 p2, V3 p3, V3 n1, V3 n2, V3 n3, float alpha, float u, float v ) {
+	const float w = 1.0f - u - v;
+	const V3 bary = ( p1 * u + p2 * v ) + p3 * w;
+	const V3 tess = ( u * onPlane( bary, p1, n1 ) + v * onPlane( bary, p2, n2 ) ) + w * onPlane( bary, p3, n3 );
+	return ( 1.0f - alpha ) * bary + alpha * tess;
+}
+
+// MathHelp::triCalcAABB (MathHelp.cpp:250-310, getAABB :20-36): component-wise min / max of the three corners;
+// with render.phong_tessellation > 0 and unequal vertex normals the box also covers the Phong-tessellated patch —
+// its apex above the plane (triThicknessAndSidedrop, :325-378: the patch's extremum along the geometric normal) and
+// nine points along its curved edges ("sidedrop").
+void triBox( Tri* tri, const std::vector<float>& v, const std::vector<float>& normals, float alpha ) {
 	const uint32_t idx[3] = { tri->face.x, tri->face.y, tri->face.z };
 
 	for( int k = 0; k < 3; k++ ) {
@@ -55,6 +82,63 @@ void triBox( Tri* tri, const std::vector<float>& v ) {
 		tri->bbMin[k] = mn;
 		tri->bbMax[k] = mx;
 	}
+
+	if( !( alpha > 0.0f ) ) {
+		return;
+	}
+
+	const uint32_t nidx[3] = { tri->normals.x, tri->normals.y, tri->normals.z };
+	V3 p[3], n[3];
+
+	for( int c = 0; c < 3; c++ ) {
+		p[c] = { v.at( (size_t) idx[c] * 3 ), v.at( (size_t) idx[c] * 3 + 1 ), v.at( (size_t) idx[c] * 3 + 2 ) };
+		n[c] = { normals.at( (size_t) nidx[c] * 3 ), normals.at( (size_t) nidx[c] * 3 + 1 ), normals.at( (size_t) nidx[c] * 3 + 2 ) };
+	}
+
+	const V3 test = ( n[0] - n[1] ) + ( n[1] - n[2] );
+
+	if( std::fabs( test.x ) <= 0.000001f && std::fabs( test.y ) <= 0.000001f && std::fabs( test.z ) <= 0.000001f ) {
+		return;   // equal normals: nothing to tessellate
+	}
+
+	const V3 e12 = p[1] - p[0], e13 = p[2] - p[0], e23 = p[2] - p[1], e31 = p[0] - p[2];
+	const V3 c12 = alpha * ( dot3( n[1], e12 ) * n[1] - dot3( n[0], e12 ) * n[0] );
+	const V3 c23 = alpha * ( dot3( n[2], e23 ) * n[2] - dot3( n[1], e23 ) * n[1] );
+	const V3 c31 = alpha * ( dot3( n[0], e31 ) * n[0] - dot3( n[2], e31 ) * n[2] );
+	const V3 ng = normalize3v( cross3( e12, e13 ) );
+
+	const float kTmp = dot3( ng, c12 - c23 - c31 );
+	const float k = 1.0f / ( 4.0f * dot3( ng, c23 ) * dot3( ng, c31 ) - kTmp * kTmp );
+	float pu = k * ( 2.0f * dot3( ng, c23 ) * dot3( ng, c31 + e31 ) + dot3( ng, c23 - e23 ) * dot3( ng, c12 - c23 - c31 ) );
+	float pv = k * ( 2.0f * dot3( ng, c31 ) * dot3( ng, c23 - e23 ) + dot3( ng, c31 + e31 ) * dot3( ng, c12 - c23 - c31 ) );
+	pu = ( pu < 0.0f || pu > 1.0f ) ? 0.0f : pu;
+	pv = ( pv < 0.0f || pv > 1.0f ) ? 0.0f : pv;
+
+	const V3 apex = phongPoint( p[0], p[1], p[2], n[0], n[1], n[2], alpha, pu, pv );
+	const float thickness = dot3( ng, apex - p[0] );
+
+	static const float edgeUV[9][2] = {
+		{ 0.0f, 0.5f }, { 0.5f, 0.0f }, { 0.5f, 0.5f }, { 0.25f, 0.75f }, { 0.75f, 0.25f },
+		{ 0.25f, 0.0f }, { 0.75f, 0.0f }, { 0.0f, 0.25f }, { 0.0f, 0.75f }
+	};
+	V3 lo = { tri->bbMin[0], tri->bbMin[1], tri->bbMin[2] };
+	V3 hi = { tri->bbMax[0], tri->bbMax[1], tri->bbMax[2] };
+
+	// raised corners first, then the edge points (MathHelp.cpp:302-309; min / max commute, the values do not change)
+	for( int c = 0; c < 3; c++ ) {
+		const V3 raised = p[c] + thickness * ng;
+		lo = min3v( lo, raised );
+		hi = max3v( hi, raised );
+	}
+
+	for( int s = 0; s < 9; s++ ) {
+		const V3 q = phongPoint( p[0], p[1], p[2], n[0], n[1], n[2], alpha, edgeUV[s][0], edgeUV[s][1] );
+		lo = min3v( lo, q );
+		hi = max3v( hi, q );
+	}
+
+	tri->bbMin[0] = lo.x; tri->bbMin[1] = lo.y; tri->bbMin[2] = lo.z;
+	tri->bbMax[0] = hi.x; tri->bbMax[1] = hi.y; tri->bbMax[2] = hi.z;
 }
 
 // BVH::longestAxis, BVH.cpp:577-587
@@ -83,6 +167,11 @@ float BVH::getSurfaceArea( const float bbMin[3], const float bbMax[3] ) {
 }
 
 
+// Variants for scripts/bvh_sweep.py only (which settings would give the node count the reference quotes for its test
+// model, pathtracing.cl:75-76); 0 = the reference's builder as read from BVH.cpp.  Never set by the product.
+unsigned BVH::sLabFlags = 0u;
+
+
 BVHNode* BVH::newNode() {
 	mArena.emplace_back();
 	return &mArena.back();
@@ -96,16 +185,29 @@ BVH::BVH(
 	const std::vector<float>& vertices,
 	const std::vector<float>& normals
 ) {
-	(void) normals;
+	const float phongAlpha = Cfg::get().value<float>( Cfg::RENDER_PHONGTESS );
 	const int maxFaces = Cfg::get().value<int>( Cfg::BVH_MAXFACES );
 	mMaxFaces = (uint32_t) ( ( maxFaces > 1 ) ? maxFaces : 1 );
 	mSahFacesLimit = Cfg::get().value<uint32_t>( Cfg::BVH_SAHFACESLIMIT );
 
 	std::vector<BVHNode*> subTrees;
 	int32_t offset = 0;
+	std::vector<object3D> merged;
 
-	for( size_t i = 0; i < sceneObjects.size(); i++ ) {
-		const object3D& obj = sceneObjects[i];
+	if( ( sLabFlags & LAB_ONE_TREE ) != 0u && sceneObjects.size() > 1 ) {
+		merged.resize( 1 );
+		merged[0].oName = "all";
+
+		for( const object3D& obj : sceneObjects ) {
+			merged[0].facesV.insert( merged[0].facesV.end(), obj.facesV.begin(), obj.facesV.end() );
+			merged[0].facesVN.insert( merged[0].facesVN.end(), obj.facesVN.begin(), obj.facesVN.end() );
+		}
+	}
+
+	const std::vector<object3D>& objects = merged.empty() ? sceneObjects : merged;
+
+	for( size_t i = 0; i < objects.size(); i++ ) {
+		const object3D& obj = objects[i];
 		const size_t numFaces = obj.facesV.size() / 3;
 
 		if( numFaces == 0 ) {
@@ -126,7 +228,7 @@ BVH::BVH(
 				t.normals = { 0, 0, 0, t.face.w };
 			}
 
-			triBox( &t, vertices );
+			triBox( &t, vertices, normals, ( obj.facesVN.size() >= ( j + 1 ) * 3 ) ? phongAlpha : 0.0f );
 		}
 
 		offset += (int32_t) numFaces;
@@ -224,7 +326,13 @@ size_t BVH::splitBySAH( const std::vector<Tri>& tris, std::vector<uint32_t>& ord
 		}
 
 		const float* k = key.data();
-		std::sort( pos.begin(), pos.end(), [k]( uint32_t a, uint32_t b ) { return k[a] < k[b]; } );
+
+		if( ( sLabFlags & LAB_STABLE_SORT ) != 0u ) {
+			std::stable_sort( pos.begin(), pos.end(), [k]( uint32_t a, uint32_t b ) { return k[a] < k[b]; } );
+		}
+		else {
+			std::sort( pos.begin(), pos.end(), [k]( uint32_t a, uint32_t b ) { return k[a] < k[b]; } );
+		}
 
 		for( size_t i = 0; i < n; i++ ) {
 			sorted[i] = order[lo + pos[i]];
@@ -265,7 +373,7 @@ size_t BVH::splitBySAH( const std::vector<Tri>& tris, std::vector<uint32_t>& ord
 			const float numRight = (float) ( (uint32_t) n - i - 1u );
 			const float sah = leftSA[i] * numLeft + rightSA[i] * numRight;
 
-			if( sah < bestSAH ) {
+			if( sah < bestSAH || ( ( sLabFlags & LAB_LAST_BEST ) != 0u && sah == bestSAH ) ) {
 				bestSAH = sah;
 				splitAfter = i + 1;
 			}

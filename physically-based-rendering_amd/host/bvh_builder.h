@@ -68,6 +68,10 @@ class BVH : public AccelStructure {
 
 		static float getSurfaceArea( const float bbMin[3], const float bbMax[3] );
 
+		// scripts/bvh_sweep.py only (see bvh_builder.cpp); the product leaves it 0
+		enum { LAB_STABLE_SORT = 1, LAB_ONE_TREE = 2, LAB_LAST_BEST = 4 };
+		static unsigned sLabFlags;
+
 	private:
 		BVHNode* newNode();
 		BVHNode* buildTree( std::vector<Tri>& tris, std::vector<uint32_t>& order, size_t lo, size_t hi, uint32_t depth );

@@ -130,6 +130,11 @@ void pbrh_scene_info( void* scene, uint32_t* out ) {
 	out[9] = (uint32_t) s->loader.getObjParser()->model().objects.size();
 }
 
+// scripts/bvh_sweep.py: builder variants (BVH::LAB_*), 0 = the reference's builder
+void pbrh_lab_bvh_flags( unsigned flags ) {
+	BVH::sLabFlags = flags;
+}
+
 void pbrh_scene_config( void* scene, uint32_t width, uint32_t height, pbr_config* out ) {
 	*out = PathTracer::makeConfig( static_cast<HostScene*>( scene )->buffers, width, height );
 }

@@ -145,7 +145,7 @@ def test_eight_way_shards_equal_the_unsharded_frame(pbr, device, name):
 
 
 @pytest.mark.parametrize("name", ["sponza", "hairball"])
-def test_render_across_the_frame_buffer_cap(pbr, device, name):
+def test_render_across_the_frame_buffer_cap(pbr, device, monkeypatch, name):
     """A multi-frame render keeps {finalColor, focus} of every (pixel, frame) in a buffer capped at 16 GiB; beyond it
     the render runs as several launch pairs (1080p: 517 frames, 3840 x 2160: 129).  Two pairs == the frames one by one,
     as the reference's viewer renders them (PathTracer.cpp:59-71)."""
@@ -154,10 +154,12 @@ def test_render_across_the_frame_buffer_cap(pbr, device, name):
     frames = cap + 3
     device.upload_scene(sc.desc)
     device.configure(cfg)
+    monkeypatch.setenv("PBR_PLAN", "4")                                # one plan, no tuning chunks: the cap alone splits the render
     device.render(0, pbr.frame_seeds(0, frames), px, cam)
     assert device.last_trace()[1] == 2                                 # two path-tracing launches
     fused = device.read_output()
     assert device.counters()["paths"] == w * h * frames
+    monkeypatch.delenv("PBR_PLAN")                                     # frame by frame, whichever plans the tuner tries
     device.reset_accum()
     for k in range(frames):
         device.render(k, pbr.frame_seeds(k, 1), px, cam)

@@ -51,17 +51,32 @@ def _worker(rank, world, port, out_dir):
         dist.all_gather_into_tensor(gathered, local)
         frame = pbr.tiles.unpack_gathered(gathered.numpy(), W, H, world)
         np.save(os.path.join(out_dir, "rank%d.npy" % rank), frame)
+        # bench.py's control traffic at N > 1: rank 0's tuned plan to everybody, and "one more repetition?" from rank 0
+        choice = torch.tensor([4 if rank == 0 else -1], dtype=torch.int32)
+        dist.broadcast(choice, src=0)
+        more = torch.tensor([1 if rank == 0 else 0], dtype=torch.int32)
+        dist.broadcast(more, src=0)
+        # ... and its statistics: max over ranks of the elapsed time, per-rank slots summed into one table
+        slow = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(slow, op=dist.ReduceOp.MAX)
+        table = torch.zeros(world, dtype=torch.float64)
+        table[rank] = 10.0 + rank
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)
+        np.save(os.path.join(out_dir, "ctl%d.npy" % rank), np.array([float(choice[0]), float(more[0]), float(slow[0])] + table.tolist()))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gather_is_bit_identical_to_one_rank(tmp_path, pbr, oracle):
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_gather_is_bit_identical_to_one_rank(tmp_path, pbr, oracle, world):
+    """world = 8: the node the metric is quoted on (48 tiles: 6 per rank)."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     _, full = _render_rows(pbr, oracle, 1, 0)
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % rank))
         assert same_values(got, full), "rank %d" % rank
+        ctl = np.load(os.path.join(str(tmp_path), "ctl%d.npy" % rank))
+        assert ctl.tolist() == [4.0, 1.0, float(world)] + [10.0 + r for r in range(world)]
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])

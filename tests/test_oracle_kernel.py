@@ -261,3 +261,48 @@ def test_threads_do_not_change_results(cfg_defaults, oracle):
     a = oracle.Renderer(sc.desc, cfg, threads=1).render(0, pbr.frame_seeds(0, 2), px, cam)
     b = oracle.Renderer(sc.desc, cfg, threads=4).render(0, pbr.frame_seeds(0, 2), px, cam)
     assert same_values(a, b)
+
+
+# ----------------------------------------------------------------------------------------------
+# fixtures of the reference's own scenes (tests/golden/ref_*.npz, make_reference_scenes.py)
+# ----------------------------------------------------------------------------------------------
+
+import os  # noqa: E402
+import sys  # noqa: E402
+
+from conftest import REFERENCE_MODELS, ROOT  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_reference_scenes  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(make_reference_scenes.CASES))
+def test_oracle_reproduces_the_reference_scene_fixtures(pbr, oracle, name):
+    """The committed fixtures are self-contained (arrays + constants + camera + seeds): the oracle, fed from them
+    alone, gives the stored image / debug image / counters / ray batch — on this container and on the GPU box."""
+    data = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    desc, cfg, cam, keep = make_reference_scenes.scene_from_fixture(pbr, data)      # `keep` owns the arrays desc points at
+    assert pbr.validate_scene(desc) == ""
+    out = make_reference_scenes.outputs_of(pbr, oracle, data)
+    for key in ("image", "debug", "counters", "rays", "ray_t", "ray_counts"):
+        assert np.array_equal(out[key], data[key], equal_nan=True), key
+    # what makes these scenes worth having: glass, extreme lobes, lights
+    mats = data["materials"]
+    if "pillars" in name or "spheres" in name:
+        assert (mats[:, 0] < 1.0).any()                                          # d < 1: refraction on whole images
+    if "suzanne" in name and mats.shape[1] == 16:
+        assert (mats[:, 2] == 100000.0).any()                                    # nu = nv = 1e5
+    assert (data["lights"].shape[0] == 1) == ("shadow" in name)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_MODELS), reason="reference assets only exist in the build container")
+@pytest.mark.parametrize("name", sorted(make_reference_scenes.CASES))
+def test_loader_and_builder_reproduce_the_fixture_inputs(pbr, name):
+    """Container only: the reference's .obj / .mtl / .lights through host/model_io.cpp + host/bvh_builder.cpp still
+    give the arrays the fixtures hold."""
+    data = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    sc, cfg, cam, px, frames = make_reference_scenes.load_case(pbr, name)
+    fresh = make_reference_scenes.inputs_of(pbr, sc, cfg, cam, px, frames)
+    for key, value in fresh.items():
+        assert np.array_equal(np.asarray(value), data[key]), key
+    pbr.cfg_reset()
