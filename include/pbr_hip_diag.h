@@ -46,6 +46,10 @@ int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t r
  * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
 int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
 
+/* 1 if this build of the library also holds the three superseded schedules (PBR_SCHEDULE = tile | batched | wavefront;
+ * -DPBR_LEGACY_SCHEDULES, lab builds), 0 for the product build: forcing one of them then fails with PBR_EINVAL. */
+int pbr_diag_has_legacy_schedules( void );
+
 /* Render with plan 0..5 (the order of pbr_diag_last_plan's *tuned: refill-lean, refill-wide, phased-lean, phased-wide,
  * phased-mid, refill-mid) from now on, without tuning; -1 hands the choice back to the tuner.  For the ranks of a
  * multi-GPU run: rank 0 tunes, broadcasts its *tuned, every rank pins it — all ranks then run the same schedule and

@@ -15,11 +15,18 @@
 #include "pbr_hip.h"
 #include "pbr_hip_diag.h"
 #include "pt_kernel.hpp"
+// PBR_LEGACY_SCHEDULES (lab builds only, scripts/lab.sh): the three superseded schedules of DESIGN.md 5.1b — `tile`
+// (a wave walks whole tiles), `batched` (the flat lane state machine) and `wavefront` (pt_wavefront.hpp).  The tuner
+// never chose them; the product library holds the six plans it does choose from plus the Phong-tessellation variant.
+#ifdef PBR_LEGACY_SCHEDULES
 #include "pt_wavefront.hpp"
+#endif
 #include "bvh_build.hpp"
 
 using ptk::DevParams;
+#ifdef PBR_LEGACY_SCHEDULES
 using ptk::WfParams;
+#endif
 
 struct pbr_ctx {
 	int device = -1;
@@ -40,7 +47,6 @@ struct pbr_ctx {
 	uint32_t numHotAvail = 0;      // records at the head of the node stream that are ranked for LDS staging
 	int firstRef = 0;              // record of node 1
 	uint32_t numNodes = 0, numFaces = 0, numMaterials = 0, numLights = 0;
-	uint32_t tilesXMagic = 0;      // see pbr_configure
 	uint32_t sceneBrdf = 1;
 
 	// configuration + images
@@ -186,6 +192,7 @@ KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 #endif
 }
 
+#ifdef PBR_LEGACY_SCHEDULES
 #ifndef PBR_BATCHED_MINW
 #define PBR_BATCHED_MINW 4
 #endif
@@ -207,6 +214,8 @@ KernelFn pickKernelBatched( uint32_t brdf, bool shadow, bool lights ) {
 	return ptk::pathTracingBatched<1, false, false, PBR_BATCHED_MINW>;
 #endif
 }
+
+#endif   // PBR_LEGACY_SCHEDULES
 
 #ifndef PBR_LEAN_MINW
 #define PBR_LEAN_MINW 4
@@ -241,7 +250,10 @@ KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) 
 
 // the "mid" budget: <= 80 VGPRs, launched as two 768-thread blocks per CU = 6 waves / SIMD
 const int kMidMinWaves = 6;
-const int kMidBlockThreads = 768;
+#ifndef PBR_MID_THREADS   // lab builds only: other block shapes for the 6-waves kernels
+#define PBR_MID_THREADS 768
+#endif
+const int kMidBlockThreads = PBR_MID_THREADS;
 
 KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
 	return pickKernelPhasedMode<kMidMinWaves>( brdf, shadow, lights );
@@ -263,12 +275,16 @@ KernelFn pickKernelPhong( uint32_t brdf, bool shadow, bool lights ) {
 }
 
 KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights, bool refill, bool wide ) {
-	if( wide ) {
-		return refill ? pickKernelMode<true, PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelMode<false, PBR_WIDE_MINW>( brdf, shadow, lights );
+#ifdef PBR_LEGACY_SCHEDULES
+	if( !refill ) {
+		return wide ? pickKernelMode<false, PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelMode<false, PBR_LEAN_MINW>( brdf, shadow, lights );
 	}
-	return refill ? pickKernelMode<true, PBR_LEAN_MINW>( brdf, shadow, lights ) : pickKernelMode<false, PBR_LEAN_MINW>( brdf, shadow, lights );
+#endif
+	(void) refill;
+	return wide ? pickKernelMode<true, PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelMode<true, PBR_LEAN_MINW>( brdf, shadow, lights );
 }
 
+#ifdef PBR_LEGACY_SCHEDULES
 typedef void ( *WfKernelFn )( const DevParams, const WfParams );
 
 WfKernelFn pickWfShade( uint32_t brdf, bool shadow, bool lights ) {
@@ -328,12 +344,14 @@ int launchWavefront( pbr_ctx* ctx, DevParams P, bool shadow, bool lights ) {
 	}
 
 	P.numHot = (int) slots;
+	P.numHotBytes = (int) slots * 32;
 	const size_t ldsBytes = slots * 32;
 	HIP_TRY( ctx, hipFuncSetAttribute( (const void*) trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes ) );
 	const dim3 traceGrid( (unsigned) ctx->numCUs * 2 ), traceBlock( PBR_BLOCK );
 	const dim3 wideGrid( (unsigned) ctx->numCUs * 8 ), wideBlock( 256 );
 
 	DevParams Pshade = P;
+	Pshade.numHotBytes = 0;
 	Pshade.numHot = 0;   // shading kernels do not stage LDS (their shadow walks read nodes from memory)
 
 	const unsigned maxPasses = (unsigned) ( P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 2 );
@@ -376,6 +394,8 @@ int launchWavefront( pbr_ctx* ctx, DevParams P, bool shadow, bool lights ) {
 	ctx->lastPasses = passes;
 	return PBR_OK;
 }
+
+#endif   // PBR_LEGACY_SCHEDULES
 
 // {magic, shifts} with which ptk::divInvariant divides any 32-bit n by d exactly (d = 0 is never divided by: as 1)
 void invariantDivisor( unsigned d, unsigned out[2] ) {
@@ -460,6 +480,18 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		}
 	}
 
+	// launch-invariant sub-expressions of initRay (pt_kernel.hpp), same IEEE single operations as the kernel would do
+	// (this file is built with -ffp-contract=off like the kernels)
+	for( int k = 0; k < 3; k++ ) {
+		const float w = (float) ctx->cfg.width, h = (float) ctx->cfg.height;
+		const float cuW = P.cu[k] * w;
+		P.camA[k] = P.cu[k] - cuW;
+		P.cvH[k] = P.cv[k] * h;
+	}
+
+	P.halfPx = pxDim * 0.5f;
+	P.aperture = cam->lense[0] / cam->lense[1];
+	P.samplesF = (float) ctx->cfg.samples;
 	P.focusX = cam->focusPoint[0];
 	P.focusY = cam->focusPoint[1];
 	P.focusGiven = ( dof && ctx->focusGiven ) ? 1 : 0;
@@ -470,7 +502,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	P.width = (int) ctx->cfg.width;
 	P.height = (int) ctx->cfg.height;
 	P.tilesX = ctx->tilesX;
-	P.tilesXMagic = ctx->tilesXMagic;
+	invariantDivisor( (unsigned) ctx->tilesX, P.tilesXDiv );
 	P.numLocalTiles = ctx->numLocalTiles;
 	// the local tiles as a grid for the banded queue: its true shape when unsharded, about that when sharded
 	P.queueWidth = std::max( 1, ( ctx->tilesX + (int) ctx->cfg.tile_world - 1 ) / (int) ctx->cfg.tile_world );
@@ -513,10 +545,16 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		return fail( ctx, PBR_EINVAL, "Phong tessellation runs in the refill schedule only and needs a scene with usable vertex normals" );
 	}
 
+#ifdef PBR_LEGACY_SCHEDULES
 	if( forced( "wavefront" ) && !dof ) {
 		std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "wavefront" );
 		return launchWavefront( ctx, P, shadow, lights );
 	}
+#else
+	if( forced( "tile" ) || forced( "batched" ) || forced( "wavefront" ) ) {
+		return fail( ctx, PBR_EINVAL, "PBR_SCHEDULE=%s: the superseded schedules are not in the product library (build with -DPBR_LEGACY_SCHEDULES, scripts/lab.sh)", force );
+	}
+#endif
 
 	// A plan = kernel + persistent grid + LDS split.  Grid: as many blocks as stay resident, never more
 	// than there is work for.  LDS: each block stages a prefix of the node stream; the CU's 160 KB are
@@ -579,6 +617,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		const size_t needed = std::max<size_t>( 1, ( waveUnits + wavesPerBlock - 1 ) / wavesPerBlock );
 		const unsigned blocks = (unsigned) std::min<size_t>( (size_t) plan.blocks, needed );
 		P.numHot = plan.numHot;
+		P.numHotBytes = plan.numHot * 32;
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
 		P.parkEighths = plan.parkEighths;
@@ -587,6 +626,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		return PBR_OK;
 	};
 
+#ifdef PBR_LEGACY_SCHEDULES
 	if( forced( "tile" ) ) {
 		// tile-synchronous schedule: a wave walks whole 8x8 tiles, the running mean stays in registers
 		bool wide = ( ctx->numNodes >= kWideMinNodes );
@@ -621,6 +661,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "%s", plan.name );
 		return PBR_OK;
 	}
+
+#endif   // PBR_LEGACY_SCHEDULES
 
 	// Frame-parallel schedules: every (pixel, frame) is its own unit of work — the frames of a pixel are
 	// independent up to the running mean (pathtracing.cl:28,255,332) — so a launch ends with single
@@ -676,6 +718,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 		forcedPlan = forced( "phased" ) ? ( wide ? 3 : 2 ) : ( wide ? 1 : 0 );
 
+#ifdef PBR_LEGACY_SCHEDULES
 		if( forced( "batched" ) ) {
 			const int made = makePlan( pickKernelBatched( ctx->cfg.brdf, shadow, lights ), "batched", 0, 0, &batchedPlan );
 
@@ -683,6 +726,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 				return made;
 			}
 		}
+#endif
 	}
 
 	if( ctx->pinnedPlan >= 0 ) {
@@ -918,6 +962,10 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	ctx->lastKernelMs = (double) ms;
 	ctx->lastTraceMs = traceMs;
 	ctx->lastTraceLaunches = launches;
+
+	if( ( (const volatile unsigned*) ctx->dGuard )[3] != 0u ) {
+		return fail( ctx, PBR_EDEVICE, "the staged node prefix does not start at LDS address 0 (pt_kernel.hpp, stageHotNodes): this build of the kernels cannot be trusted" );
+	}
 
 	return PBR_OK;
 }
@@ -1192,8 +1240,9 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	}
 
 	// the walk stops outside (0, N), pt_bvh.cl:122
+	// a reference is the record's byte offset in the stream (pt_kernel.hpp, Cursor): record * 32 < 2^29 for N <= 2^24
 	auto refOf = [&]( long long node ) {
-		return ( node > 0 && node < (long long) N ) ? recordOf[(size_t) node] : -1;
+		return ( node > 0 && node < (long long) N ) ? recordOf[(size_t) node] * 32 : -1;
 	};
 
 	std::vector<float4> nodes( (size_t) N * 2, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );
@@ -1328,7 +1377,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	}
 
 	ctx->numHotAvail = numHot;
-	ctx->firstRef = recordOf[1];
+	ctx->firstRef = recordOf[1] * 32;
 	ctx->numNodes = s->num_nodes;
 	ctx->numFaces = s->num_faces;
 	ctx->numMaterials = s->num_materials;
@@ -1379,21 +1428,6 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	ctx->numTiles = ctx->tilesX * ctx->tilesY;
 	// tiles t = j * world + rank, j = 0 .. : count those below numTiles
 	ctx->numLocalTiles = ( ctx->numTiles - (int) cfg->tile_rank + (int) cfg->tile_world - 1 ) / (int) cfg->tile_world;
-
-	// beginPixel divides tile positions (and PT_DEAL_SHIFT x tile rows) by tilesX once per unit of work: as a
-	// multiplication where that is exact for every value that can occur — checked here, value by value
-	{
-		const uint64_t d = (uint64_t) ctx->tilesX;
-		const uint64_t magic = ( 1ull << 32 ) / d + 1ull;
-		const uint64_t largest = std::max<uint64_t>( (uint64_t) ctx->numTiles + cfg->tile_world, (uint64_t) PT_DEAL_SHIFT * ( (uint64_t) ctx->numTiles / d + 1 ) );
-		bool exact = ( magic < ( 1ull << 32 ) );
-
-		for( uint64_t x = 0; exact && x <= largest; x++ ) {
-			exact = ( ( x * magic ) >> 32 ) == x / d;
-		}
-
-		ctx->tilesXMagic = exact ? (uint32_t) magic : 0u;
-	}
 
 	// Every context can hold the full image (import_tiles scatters all ranks' tiles into imgOut).
 	const size_t fullBytes = sizeof( float4 ) * 64 * (size_t) ctx->numTiles;
@@ -1663,6 +1697,7 @@ DevParams sceneParams( pbr_ctx* ctx ) {
 	P.numNodes = (int) ctx->numNodes;
 	P.numLights = (int) ctx->numLights;
 	P.numHot = 0;
+	P.numHotBytes = 0;
 	P.firstRef = ctx->firstRef;
 	return P;
 }
@@ -1930,6 +1965,7 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 		size_t slots = std::min<size_t>( (size_t) mode, ctx->numHotAvail );
 		slots = std::min<size_t>( slots, ( 160 * 1024 / (size_t) blocksPerCU - 256 ) / 32 );
 		P.numHot = (int) slots;
+		P.numHotBytes = (int) slots * 32;
 		const dim3 grid( (unsigned) ( ctx->numCUs * blocksPerCU ) ), block( PBR_BLOCK );
 
 		if( slots == 0 ) {
@@ -2019,6 +2055,14 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned ) 
 	}
 
 	return PBR_OK;
+}
+
+int pbr_diag_has_legacy_schedules( void ) {
+#ifdef PBR_LEGACY_SCHEDULES
+	return 1;
+#else
+	return 0;
+#endif
 }
 
 int pbr_diag_pin_plan( pbr_ctx* ctx, int plan ) {

@@ -63,6 +63,14 @@ struct DevParams {
 	unsigned int* guard;    // [0] tile-loop, [1] path-loop, [2] traversal trips (PBR_GUARD builds only)
 
 	float eye[3], cw[3], cu[3], cv[3];
+	// launch-invariant sub-expressions of initRay, evaluated once on the host with the same IEEE operations (left in
+	// the kernel the compiler hoists them out of the path loop into vector registers — they are float arithmetic — and,
+	// at 80 registers, spills them: 40 of the 48 bytes of scratch per lane the 6-waves kernels had)
+	float camA[3];          // cu - cu * W
+	float cvH[3];           // cv * H
+	float halfPx;           // pxDim * 0.5f
+	float aperture;         // lenseFocal / lenseAperture
+	float samplesF;         // (float) samples
 	int focusX, focusY;
 	int focusGiven;         // tile sharding: the focus pixel's previous-frame distance comes from the caller (focusDepth) ...
 	float focusDepth;       // ... because its tile may live on another rank (pbr_set_focus_depth)
@@ -71,14 +79,15 @@ struct DevParams {
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
 	unsigned bandDiv[PT_BANDS * 2];   // per queue band: {magic, shifts} to divide by its rows (nextSlot, divInvariant)
 	unsigned framesDiv[2];            // {magic, shifts} to divide by nFrames (nextSlot)
-	unsigned tilesXMagic;   // floor( x / tilesX ) == umulhi( x, tilesXMagic ) for every x the kernels divide (checked by the host); 0: divide
+	unsigned tilesXDiv[2];  // {magic, shifts} to divide by tilesX (pixelOfSlot, divInvariant)
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
 	float phongAlpha;            // PHONGTESS_ALPHA (kernels built with PHONG = true only)
 	int parkEighths;             // traverse(): a node phase ends once this many eighths of the lanes that entered it have left it
 	int phPark, phShade;         // phased schedule: lanes that leave a node phase before it ends / lanes that wait before a shade phase runs
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
 	int numHot;             // records [0, numHot) of the node stream are resident in LDS
-	int firstRef;           // record of node 1, where every walk starts
+	int numHotBytes;        // = numHot * 32: a record reference (byte offset) below this is resident
+	int firstRef;           // reference (byte offset) of node 1's record, where every walk starts
 	int nFrames, firstCount;
 	int useExplicitWeight;
 	float explicitWeight;
@@ -663,13 +672,15 @@ PT_DEV void testLeaf( const DevParams& P, int face0, int face1, const Ray& ray, 
 //   n0 = {min.x, min.y, max.x, max.y}     n1 = {min.z, max.z, w0, w1}
 //   container  w0 = record to continue at when the box is hit    w1 = ... when it is missed
 //   leaf       w0 = 1 << 31 | hasSecondFace << 30 | face0         w1 = record to continue at (hit or miss)
-// A record reference < 0 ends the walk (the reference's `index > 0 && index < numNodes`, pt_bvh.cl:122).
+// A record reference is the record's BYTE OFFSET in the stream (record index * 32: the address operand of the LDS
+// read and of the global load as it stands, no shift per visit); a reference < 0 ends the walk (the reference's
+// `index > 0 && index < numNodes`, pt_bvh.cl:122).
 // The stream starts with the most-visited nodes, ranked by expected visit frequency (surface area of the
 // parent box); the rest follows in DFS order, so a cold node's hit successor is still the adjacent
 // 32 B.  A block stages any prefix [0, numHot) of the stream in LDS: "is my next node resident, and
 // where" is one compare on the reference itself.
 struct Cursor {
-	int ref;   // record in the node stream; < 0: the walk has ended
+	int ref;   // byte offset of a record in the node stream; < 0: the walk has ended
 };
 
 PT_DEV bool alive( Cursor c ) {
@@ -684,13 +695,15 @@ struct NodeLinks {
 
 template<bool USE_LDS>
 PT_DEV void fetchNode( const DevParams& P, const float4* lds, Cursor c, float4* n0, float4* n1 ) {
-	if( USE_LDS && c.ref < P.numHot ) {
-		*n0 = lds[c.ref * 2 + 0];
-		*n1 = lds[c.ref * 2 + 1];
+	if( USE_LDS && c.ref < P.numHotBytes ) {
+		const float4* rec = (const float4*) ( (const char*) lds + c.ref );
+		*n0 = rec[0];
+		*n1 = rec[1];
 	}
 	else {
-		*n0 = P.nodes[(size_t) c.ref * 2 + 0];
-		*n1 = P.nodes[(size_t) c.ref * 2 + 1];
+		const float4* rec = (const float4*) ( (const char*) P.nodes + (size_t) (unsigned) c.ref );
+		*n0 = rec[0];
+		*n1 = rec[1];
 	}
 }
 
@@ -737,35 +750,40 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 // unchanged), so results are bit-identical to the C++ loop, which stays in use for PBR_GUARD builds,
 // for USE_LDS = false and as the statement of what this does.
 // Registers v46-v63 are the block's temporaries: n0 = v[46:49], n1 = v[50:53], the three slab
-// pairs v[54:59], tNear / tFar and scratch v60-v63.
+// pairs v[54:59], tNear / tFar v60 / v61, scratch v62 / v63.  A record reference is its byte offset (see above) and
+// the staged prefix sits at LDS address 0 (the kernels have no other __shared__ data; checked in stageHotNodes),
+// so the reference itself is the address operand of both the LDS read and the global load.
+// The hit condition (pt_bvh.cl:107-110) is a chain of v_cmpx: each compare narrows EXEC to the lanes that still
+// qualify, so no scalar instruction merges the three masks — 8 scalar + 24 vector instructions per visit.
+//
+// Rejected after measurement (bit-identical, slower): requesting a parked lane's first face record from inside this
+// loop, into its own lanes of the temporaries (registers are per lane) — whether at once or behind the next
+// iteration's node loads with s_waitcnt vmcnt(3): the 6 scalar + 3 vector + 3 memory instructions it adds to every
+// iteration cost more (Sponza-class -11 %, Dragon-class -8 %, hairball -13 %) than the one latency per leaf phase it hides.
 #if !defined( PBR_GUARD ) && !defined( PBR_EXP_STATS ) && !defined( PBR_NODE_PHASE_CXX )
 #define PT_NODE_PHASE_ASM 1
 
 template<bool ANYHIT>
 PT_DEV void nodePhaseAsm(
-	const DevParams& P, const float4* lds, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep,
+	const DevParams& P, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep,
 	int& ref, unsigned& visits, int& leafWord, float& leafTNear, float& leafTFar, int& parked
 ) {
-	const unsigned ldsBase = (unsigned) (size_t) lds;   // low half of a generic LDS address = the LDS byte offset
 	const float eps = EPSILON5;
 	keep = __builtin_amdgcn_readfirstlane( keep );       // wave-uniform by construction; make it a scalar register
-	unsigned long long saved, active, parkMask, mA, mB, mH, mC;
+	unsigned long long saved, active, parkMask, mA;
 	int count;
 
 #define PT_NODE_PHASE_HEAD \
 		"s_mov_b64 %[saved], exec\n" \
 		"s_mov_b64 %[parkMask], 0\n" \
 	"1:\n" \
-		"v_cmp_gt_i32 vcc, %[numHot], %[ref]\n" \
-		"v_lshl_add_u32 v60, %[ref], 5, %[ldsBase]\n" \
-		"v_lshlrev_b32 v61, 5, %[ref]\n" \
-		"s_mov_b64 %[active], exec\n" \
-		"s_and_b64 exec, %[active], vcc\n" \
-		"ds_read_b128 v[46:49], v60\n" \
-		"ds_read_b128 v[50:53], v60 offset:16\n" \
-		"s_andn2_b64 exec, %[active], vcc\n" \
-		"global_load_dwordx4 v[46:49], v61, %[nodes]\n" \
-		"global_load_dwordx4 v[50:53], v61, %[nodes] offset:16\n" \
+		"v_cmp_gt_i32 vcc, %[numHotBytes], %[ref]\n" \
+		"s_and_saveexec_b64 %[active], vcc\n" \
+		"ds_read_b128 v[46:49], %[ref]\n" \
+		"ds_read_b128 v[50:53], %[ref] offset:16\n" \
+		"s_xor_b64 exec, exec, %[active]\n" \
+		"global_load_dwordx4 v[46:49], %[ref], %[nodes]\n" \
+		"global_load_dwordx4 v[50:53], %[ref], %[nodes] offset:16\n" \
 		"s_mov_b64 exec, %[active]\n" \
 		"v_add_u32 %[visits], 1, %[visits]\n" \
 		"s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
@@ -784,16 +802,18 @@ PT_DEV void nodePhaseAsm(
 		"v_max_f32 v62, v55, v57\n" \
 		"v_min_f32 v63, 0x7f800000, v63\n" \
 		"v_min3_f32 v61, v61, v62, v63\n" \
-		"v_cmp_lt_f32 %[mA], %[eps], v61\n"
+		"v_mov_b32 %[ref], v53\n" \
+		"v_cmpx_lt_f32 %[eps], v61\n"
 
+	// EXEC = the lanes whose box is hit.  A hit container continues at w0, everything else at w1 (set above);
+	// the lanes on a hit leaf park; then the lanes that go on: alive and not parked
 #define PT_NODE_PHASE_TAIL \
 		"v_cmp_gt_i32 vcc, 0, v52\n" \
-		"s_andn2_b64 %[mC], %[mH], vcc\n" \
-		"v_cndmask_b32 %[ref], v53, v52, %[mC]\n" \
-		"s_and_b64 %[mH], %[mH], vcc\n" \
-		"s_or_b64 %[parkMask], %[parkMask], %[mH]\n" \
-		"v_cmp_le_i32 vcc, 0, %[ref]\n" \
-		"s_andn2_b64 exec, vcc, %[mH]\n" \
+		"v_cndmask_b32 %[ref], v52, v53, vcc\n" \
+		"s_or_b64 %[parkMask], %[parkMask], vcc\n" \
+		"s_mov_b64 exec, %[active]\n" \
+		"v_cmp_le_i32 %[mA], 0, %[ref]\n" \
+		"s_andn2_b64 exec, %[mA], vcc\n" \
 		"s_bcnt1_i32_b64 %[count], exec\n" \
 		"s_cmp_gt_i32 %[count], %[keep]\n" \
 		"s_cbranch_scc1 1b\n" \
@@ -805,18 +825,16 @@ PT_DEV void nodePhaseAsm(
 
 #define PT_NODE_PHASE_OPERANDS \
 		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [leafTFar] "=v"( leafTFar ), [parked] "=v"( parked ), \
-		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [mB] "=&s"( mB ), [mH] "=&s"( mH ), \
-		  [mC] "=&s"( mC ), [count] "=&s"( count ) \
+		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [count] "=&s"( count ) \
 		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ), \
-		  [numHot] "s"( P.numHot ), [ldsBase] "s"( ldsBase ), [nodes] "s"( P.nodes ), [eps] "s"( eps ) \
+		  [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps ) \
 		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc"
 
 	if( ANYHIT ) {
 		// traverseShadows: no `ray.t > tNear` cull (pt_bvh.cl:151-154)
 		asm volatile(
 			PT_NODE_PHASE_HEAD
-			"v_cmp_le_f32 vcc, v60, v61\n"
-			"s_and_b64 %[mH], %[mA], vcc\n"
+			"v_cmpx_le_f32 v60, v61\n"
 			PT_NODE_PHASE_TAIL
 			PT_NODE_PHASE_OPERANDS
 		);
@@ -824,10 +842,8 @@ PT_DEV void nodePhaseAsm(
 	else {
 		asm volatile(
 			PT_NODE_PHASE_HEAD
-			"v_cmp_gt_f32 %[mB], %[rayT], v60\n"
-			"v_cmp_le_f32 vcc, v60, v61\n"
-			"s_and_b64 %[mH], %[mA], %[mB]\n"
-			"s_and_b64 %[mH], %[mH], vcc\n"
+			"v_cmpx_gt_f32 %[rayT], v60\n"
+			"v_cmpx_le_f32 v60, v61\n"
 			PT_NODE_PHASE_TAIL
 			PT_NODE_PHASE_OPERANDS
 		);
@@ -892,7 +908,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 #ifdef PT_NODE_PHASE_ASM
 			if( USE_LDS ) {
 				int parkedFlag;
-				nodePhaseAsm<ANYHIT>( P, lds, oxy, ozz, ixy, izz, hit.t, keep, cur.ref, visits, leafWord, leafTNear, leafTFar, parkedFlag );
+				nodePhaseAsm<ANYHIT>( P, oxy, ozz, ixy, izz, hit.t, keep, cur.ref, visits, leafWord, leafTNear, leafTFar, parkedFlag );
 				parked = ( parkedFlag != 0 );
 				walking = alive( cur );
 			}
@@ -934,7 +950,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 #ifdef PBR_EXP_PAD_VMEM
 				for( int k = 0; k < PBR_EXP_PAD_VMEM; k++ ) {
 					const volatile float4* vg = (const volatile float4*) P.nodes;
-					const float x = vg[cur.ref * 2 + ( k & 1 )].x;
+					const float x = vg[( cur.ref >> 4 ) + ( k & 1 )].x;
 					asm volatile( "" :: "v"( x ) );
 				}
 #endif
@@ -993,6 +1009,12 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 
 // Every block stages the hot nodes once (32 B x numHot, coalesced) before its waves start.
 PT_DEV void stageHotNodes( const DevParams& P, float4* lds ) {
+	// nodePhaseAsm reads the staged records at LDS address = record reference: the staged prefix must start at LDS address 0
+	// (it does: these kernels have no static __shared__ data).  Should a toolchain ever lay it out otherwise, say so loudly.
+	if( (unsigned) (size_t) lds != 0u && threadIdx.x == 0 && P.guard != nullptr ) {
+		P.guard[3] = 1u;
+	}
+
 	for( int i = (int) threadIdx.x; i < P.numHot * 2; i += (int) blockDim.x ) {
 		lds[i] = P.nodes[i];
 	}
@@ -1025,18 +1047,17 @@ PT_DEV f3 faceNormal( const DevParams& P, int face, int* material ) {
 PT_DEV Ray initRay( const DevParams& P, int px, int py, float& seed, float tFocus, float tObject ) {
 	const f3 cu = ld3( P.cu );
 	const f3 cv = ld3( P.cv );
-	const float W = (float) P.width;
-	const float H = (float) P.height;
 	const float fx = 2.0f * (float) px;
 	const float fy = 2.0f * (float) py;
 
-	f3 inner = cu - cu * W;
+	// pathtracing.cl:33-39, term by term: cu - cu * W (P.camA) and cv * H (P.cvH) do not depend on the pixel
+	f3 inner = ld3( P.camA );
 	inner = inner + cu * fx;
 	inner = inner + cv;
-	inner = inner - cv * H;
+	inner = inner - ld3( P.cvH );
 	inner = inner + cv * fy;
 
-	const float s = P.pxDim * 0.5f;
+	const float s = P.halfPx;
 	const f3 initial = ld3( P.cw ) + inner * s;
 
 	Ray ray;
@@ -1058,7 +1079,7 @@ PT_DEV Ray initRay( const DevParams& P, int px, int py, float& seed, float tFocu
 		}
 
 		if( tObject > 0.0f ) {
-			const float aperture = P.lenseFocal / P.lenseAperture;
+			const float aperture = P.aperture;
 			const float radius = rnd( seed ) * aperture * 0.5f;
 			const float angle = PI_X2 * rnd( seed );
 			float sa, ca;
@@ -1484,15 +1505,17 @@ PT_DEV void flushCounters( const DevParams& P, LaneCounters& c ) {
 // Image coordinates of a pixel slot of this rank: tileAtDealPosition with the divisions by tilesX as multiplications
 // (a 32-bit division is ~20 instructions).  Recomputed where a camera ray starts — once per path — rather than
 // kept in two registers for the whole path.
+PT_DEV unsigned divInvariant( unsigned n, unsigned magic, unsigned shifts );
+
 PT_DEV void pixelOfSlot( const DevParams& P, unsigned slot, int* px, int* py ) {
 	const unsigned tilesX = (unsigned) P.tilesX;
 	const unsigned position = ( slot >> 6 ) * (unsigned) P.tileWorld + (unsigned) P.tileRank;
-	const unsigned ty = ( P.tilesXMagic != 0u ) ? __umulhi( position, P.tilesXMagic ) : position / tilesX;
+	const unsigned ty = divInvariant( position, P.tilesXDiv[0], P.tilesXDiv[1] );
 	unsigned tx = position - ty * tilesX;
 
 	if( P.tileWorld > 1 ) {
 		const unsigned turn = (unsigned) PT_DEAL_SHIFT * ty;
-		const unsigned back = turn - ( ( P.tilesXMagic != 0u ) ? __umulhi( turn, P.tilesXMagic ) : turn / tilesX ) * tilesX;
+		const unsigned back = turn - divInvariant( turn, P.tilesXDiv[0], P.tilesXDiv[1] ) * tilesX;
 		tx = ( tx >= back ) ? tx - back : tx - back + tilesX;
 	}
 
@@ -1728,7 +1751,7 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 		finalColor = mk3( finalColor.x / sp, finalColor.y / sp, finalColor.z / sp );
 
 		if( P.samples > 1 ) {
-			const float ns = (float) P.samples;
+			const float ns = P.samplesF;
 			finalColor = mk3( finalColor.x / ns, finalColor.y / ns, finalColor.z / ns );
 		}
 
@@ -2243,16 +2266,17 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				const f2v ozz = { st.ray.origin.z, st.ray.origin.z };
 				const f2v ixy = { w.invDir.x, w.invDir.y };
 				const f2v izz = { w.invDir.z, w.invDir.z };
-				int leafWord, parkedFlag;
+				int leafWord = 0, parkedFlag;
 				float unusedTFar;
-				nodePhaseAsm<false>( P, lds, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
+				nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
+				st.dbgNodes += visits;
 
+				// ---- leaf phase: only lanes that have just come out of the node phase can stand on a leaf
 				if( parkedFlag != 0 ) {
-					w.leafFace0 = leafFace0( leafWord );
-					w.leafFace1 = leafFace1( leafWord );
-					mode = MODE_LEAF;
+					testLeaf<false, ( MINW <= 4 )>( P, leafFace0( leafWord ), leafFace1( leafWord ), st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
 				}
-				else if( !alive( w.cur ) ) {
+
+				if( !alive( w.cur ) ) {
 					mode = MODE_SHADE;
 				}
 			}
@@ -2284,17 +2308,19 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 					mode = MODE_SHADE;
 				}
 			} while( mode == MODE_NODE && __popcll( __ballot( mode == MODE_NODE ) ) > keep );
-#endif
 
 			st.dbgNodes += visits;
+#endif
 		}
 
+#ifndef PT_NODE_PHASE_ASM
 		// ---- leaf phase ---------------------------------------------------------------------
 		if( mode == MODE_LEAF ) {
 			PH_STAT( sLeafIt, sLeafAct )
 			testLeaf<false, ( MINW <= 4 )>( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
 			mode = alive( w.cur ) ? MODE_NODE : MODE_SHADE;
 		}
+#endif
 
 		// ---- shade phase --------------------------------------------------------------------
 		{

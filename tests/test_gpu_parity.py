@@ -25,6 +25,18 @@ def device(pbr, gpu_device):
     dev.close()
 
 
+LEGACY_SCHEDULES = ("tile", "batched", "wavefront")
+
+
+def force_schedule(pbr, monkeypatch, schedule):
+    """PBR_SCHEDULE for this test; the superseded schedules only exist in -DPBR_LEGACY_SCHEDULES builds of the library
+    (scripts/lab.sh legacy "-DPBR_LEGACY_SCHEDULES=1"; run the suite with PBR_HIP_LIB=lab/libpbrhip_legacy.so)."""
+    if schedule in LEGACY_SCHEDULES and not pbr.hip.pbr_diag_has_legacy_schedules():
+        pytest.skip("schedule %r is not in the product library" % schedule)
+    if schedule is not None:
+        monkeypatch.setenv("PBR_SCHEDULE", schedule)
+
+
 def make_scene(pbr, kind="cornell", seed=1, triangles=0, **cfg):
     pbr.cfg_reset()
     pbr.cfg_set(**cfg)
@@ -161,7 +173,7 @@ def test_brdf_and_new_ray_bit_exact(pbr, oracle, device, brdf, materials):
     {"render.antialiasing": 0.0, "render.max_depth": 1, "render.max_added_depth": 0},
 ])
 def test_cornell_image_bit_exact(pbr, oracle, device, monkeypatch, schedule, cfg):
-    monkeypatch.setenv("PBR_SCHEDULE", schedule)
+    force_schedule(pbr, monkeypatch, schedule)
     sc = make_scene(pbr, **cfg)
     got, want, ref = both_render(pbr, oracle, device, sc, 64, 48, 5)
     assert same_values(got, want), describe_mismatch(got, want)
@@ -175,7 +187,7 @@ def test_cornell_image_bit_exact(pbr, oracle, device, monkeypatch, schedule, cfg
 def test_larger_scenes_bit_exact(pbr, oracle, device, monkeypatch, kind, triangles, w, h, schedule, variant):
     """Every schedule (pt_kernel.hpp: tile / refill / batched / phased, pt_wavefront.hpp) and both register
     budgets, with the tree top staged in LDS, against the oracle."""
-    monkeypatch.setenv("PBR_SCHEDULE", schedule)
+    force_schedule(pbr, monkeypatch, schedule)
     monkeypatch.setenv("PBR_VARIANT", variant)
     sc = make_scene(pbr, kind, 4, triangles)
     got, want, ref = both_render(pbr, oracle, device, sc, w, h, 4)
@@ -243,11 +255,11 @@ def test_frame_parallel_chunks_fold_in_frame_order(pbr, oracle, device, monkeypa
 
 
 @pytest.mark.parametrize("w,h", [(8, 8), (24, 136), (200, 8), (72, 72)])
-@pytest.mark.parametrize("schedule", ["refill", "tile"])
+@pytest.mark.parametrize("schedule", ["refill", "phased", "tile"])
 def test_banded_queue_covers_every_pixel_once(pbr, oracle, device, monkeypatch, schedule, w, h):
     """The pixel-slot queue is cut into 8 bands (one head per XCD, tiles column by column inside a
     band); image shapes with fewer tile rows than bands, one row, one column."""
-    monkeypatch.setenv("PBR_SCHEDULE", schedule)
+    force_schedule(pbr, monkeypatch, schedule)
     sc = make_scene(pbr, **{"render.max_depth": 2})
     got, want, ref = both_render(pbr, oracle, device, sc, w, h, 4)
     assert same_values(got, want), describe_mismatch(got, want)
@@ -620,6 +632,8 @@ def test_random_configurations_bit_exact(pbr, oracle, device, monkeypatch, seed)
         "render.antialiasing": float(rng.choice([0.0, 0.7, 1.5])),
     }
     schedule = ["refill", "phased", "tile", "batched", "wavefront", None][rng.integers(6)]
+    if schedule in LEGACY_SCHEDULES and not pbr.hip.pbr_diag_has_legacy_schedules():
+        schedule = ["refill", "phased", None][LEGACY_SCHEDULES.index(schedule)]      # the product library: one of its own instead
     if schedule is not None:
         monkeypatch.setenv("PBR_SCHEDULE", schedule)
     if rng.integers(2):
