@@ -28,6 +28,18 @@ using ptk::DevParams;
 using ptk::WfParams;
 #endif
 
+typedef void ( *KernelFn )( const ptk::DevParams );
+
+// A plan = kernel + persistent grid + LDS split (launch()).  Built once per scene + configuration and kept in the
+// context: six occupancy queries and six function-attribute calls are host time a frame-by-frame caller would pay
+// on every frame.
+struct Plan {
+	KernelFn kernel = nullptr;
+	int blocks = 0, blockThreads = 0, numHot = 0, park = 0, shade = 0, parkEighths = 4;
+	size_t ldsBytes = 0;
+	const char* name = "";
+};
+
 struct pbr_ctx {
 	int device = -1;
 	hipStream_t stream = nullptr;
@@ -65,6 +77,13 @@ struct pbr_ctx {
 	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
 	// frames that are rendered anyway, then the fastest one is kept
 	int tunedPlan = -1;
+	Plan plans[6];                                  // the tuner's candidates, valid while plansBuilt (reset by pbr_upload_scene / pbr_configure)
+	Plan phongPlan;                                 // the Phong-tessellation build of the refill kernel (takes the place of plans[1])
+	bool plansBuilt = false, phongPlanBuilt = false;
+	int drainMode = 1;                              // pathTracingPhased, see launch()
+	bool workClean = false;                         // the queue heads are zero (foldFrames leaves them so)
+	float* hSeeds = nullptr;                        // pinned staging for the seeds of a launch
+	size_t hSeedCapacity = 0;
 	int pinnedPlan = -1;                            // pbr_diag_pin_plan: >= 0 renders with this plan, no tuning (ranks of a multi-GPU run: all the same)
 	uint32_t tuneRenderFrames = 0;                  // the longest render (frames per call) this context has been asked for
 	uint32_t tunedAtFrames = 0;                     // the render length tunedPlan was chosen for
@@ -168,7 +187,6 @@ const size_t kFrameBufBytes = (size_t) 16 << 30;
 // 4 public counters (pbr_counters) + 12 slots for experiment statistics (pbr_diag_raw_counters)
 const size_t kCounterSlots = 16;
 
-typedef void ( *KernelFn )( const DevParams );
 
 // PBR_LAB (experiments only, scripts/lab.sh): instantiate just the variants the four bench scenes run,
 // so that an A/B build of the library takes seconds.  Never defined for the product build.
@@ -249,7 +267,10 @@ KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) 
 }
 
 // the "mid" budget: <= 80 VGPRs, launched as two 768-thread blocks per CU = 6 waves / SIMD
-const int kMidMinWaves = 6;
+#ifndef PBR_MID_WAVES   // lab builds only
+#define PBR_MID_WAVES 6
+#endif
+const int kMidMinWaves = PBR_MID_WAVES;
 #ifndef PBR_MID_THREADS   // lab builds only: other block shapes for the 6-waves kernels
 #define PBR_MID_THREADS 768
 #endif
@@ -449,8 +470,25 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		ctx->seedCapacity = nFrames;
 	}
 
-	HIP_TRY( ctx, hipMemcpyAsync( ctx->dSeeds, seeds, sizeof( float ) * nFrames, hipMemcpyHostToDevice, ctx->stream ) );
-	HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, kWorkBytes, ctx->stream ) );
+	// the caller's seeds go through a pinned staging buffer: a copy from pageable memory is staged synchronously by the runtime
+	if( ctx->hSeedCapacity < nFrames ) {
+		(void) hipHostFree( ctx->hSeeds );
+		ctx->hSeeds = nullptr;
+		ctx->hSeedCapacity = 0;
+		HIP_TRY( ctx, hipHostMalloc( (void**) &ctx->hSeeds, sizeof( float ) * std::max<size_t>( nFrames, 64 ), hipHostMallocDefault ) );
+		ctx->hSeedCapacity = std::max<size_t>( nFrames, 64 );
+	}
+
+	std::memcpy( ctx->hSeeds, seeds, sizeof( float ) * nFrames );
+	HIP_TRY( ctx, hipMemcpyAsync( ctx->dSeeds, ctx->hSeeds, sizeof( float ) * nFrames, hipMemcpyHostToDevice, ctx->stream ) );
+
+	// the queue heads: foldFrames zeroes them behind every path-tracing launch, so only the first launch of a context
+	// (and any launch after one that did not end in foldFrames) has to
+	if( !ctx->workClean ) {
+		HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, kWorkBytes, ctx->stream ) );
+	}
+
+	ctx->workClean = false;
 
 	DevParams P;
 	std::memset( &P, 0, sizeof( P ) );
@@ -558,14 +596,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	// A plan = kernel + persistent grid + LDS split.  Grid: as many blocks as stay resident, never more
 	// than there is work for.  LDS: each block stages a prefix of the node stream; the CU's 160 KB are
-	// split between the blocks the register budget admits.
-	struct Plan {
-		KernelFn kernel;
-		int blocks, blockThreads, numHot, park, shade, parkEighths;
-		size_t ldsBytes;
-		const char* name;
-	};
-
+	// split between the blocks the register budget admits.  The experiment knobs (PBR_BLOCKS_PER_CU, PBR_LDS_SLOTS,
+	// PBR_PH_PARK, PBR_PH_SHADE, PBR_PARK_EIGHTHS, PBR_DRAIN_MODE) are read when the plans are built — once per
+	// scene + configuration — not per launch.
 	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK ) -> int {
 		int blocksPerCU = 0;
 		HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, blockThreads, 0 ) );
@@ -620,6 +653,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.numHotBytes = plan.numHot * 32;
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
+		P.drainMode = ctx->drainMode;   // 1: measured (single-frame 1080p launches): park share scaled, shade threshold as is: Dragon-class 2.99 -> 2.47 ms, hairball 4.26 -> 4.02 ms, Sponza- / Cornell-class unchanged; scaling the shade threshold too helps the first two further (2.26 / 3.56 ms) and costs the others 10 - 20 %
 		P.parkEighths = plan.parkEighths;
 		hipLaunchKernelGGL( plan.kernel, dim3( blocks ), dim3( (unsigned) plan.blockThreads ), plan.ldsBytes, ctx->stream, P );
 		HIP_TRY( ctx, hipGetLastError() );
@@ -689,9 +723,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	const uint32_t kTuneFrames = 2 * tuneScale;     // screening, per plan (or two launches, whichever comes first)
 	const uint32_t kRefineShort = 4 * tuneScale, kRefineLong = 12 * tuneScale;     // refinement: two chunks of each length per plan
 	const uint32_t kRefinePasses = 4;
-	Plan plans[kPlans];
-	{
+	if( !ctx->plansBuilt ) {
 		const uint32_t brdf = ctx->cfg.brdf;
+		Plan* plans = ctx->plans;
 		int status = makePlan( pickKernel( brdf, shadow, lights, true, false ), "refill-lean", 0, 0, &plans[0] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernel( brdf, shadow, lights, true, true ), "refill-wide", 0, 0, &plans[1] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2] );
@@ -702,6 +736,21 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		if( status != PBR_OK ) {
 			return status;
 		}
+
+		ctx->drainMode = 1;
+
+		if( const char* v = std::getenv( "PBR_DRAIN_MODE" ) ) {   // experiments
+			ctx->drainMode = std::atoi( v );
+		}
+
+		ctx->plansBuilt = true;
+		ctx->phongPlanBuilt = false;
+	}
+
+	Plan plans[kPlans];
+
+	for( int k = 0; k < kPlans; k++ ) {
+		plans[k] = ctx->plans[k];
 	}
 
 	auto screened = [&]( int plan ) { return ctx->tuneFrames[plan] >= kTuneFrames || ctx->tuneLaunches[plan] >= 2u; };
@@ -739,12 +788,17 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	if( phong ) {
 		// one plan: the Phong-tessellation build of the refill kernel takes the place of refill-wide
-		const int made = makePlan( pickKernelPhong( ctx->cfg.brdf, shadow, lights ), "refill-wide-phong", 0, 0, &plans[1] );
+		if( !ctx->phongPlanBuilt ) {
+			const int made = makePlan( pickKernelPhong( ctx->cfg.brdf, shadow, lights ), "refill-wide-phong", 0, 0, &ctx->phongPlan );
 
-		if( made != PBR_OK ) {
-			return made;
+			if( made != PBR_OK ) {
+				return made;
+			}
+
+			ctx->phongPlanBuilt = true;
 		}
 
+		plans[1] = ctx->phongPlan;
 		forcedPlan = 1;
 	}
 
@@ -883,9 +937,6 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.firstCount = (int) ( firstCount + done );
 		P.seeds = ctx->dSeeds + done;
 
-		if( done > 0 ) {
-			HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, kWorkBytes, ctx->stream ) );
-		}
 
 		HIP_TRY( ctx, hipEventRecord( ctx->evTraceStart, ctx->stream ) );
 
@@ -956,6 +1007,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
 	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	ctx->workClean = true;   // the last foldFrames left the queue heads at zero
 
 	float ms = 0.0f;
 	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
@@ -1043,6 +1095,7 @@ void pbr_destroy( pbr_ctx* ctx ) {
 		freeScene( ctx );
 		freeImages( ctx );
 		(void) hipFree( ctx->dSeeds );
+		(void) hipHostFree( ctx->hSeeds );
 		(void) hipFree( ctx->dCounters );
 		(void) hipFree( ctx->dWork );
 		(void) hipHostFree( ctx->dGuard );
@@ -1384,6 +1437,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	ctx->numLights = s->num_lights;
 	ctx->sceneBrdf = s->brdf;
 	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
+	ctx->plansBuilt = false;
 	ctx->tuneRenderFrames = ctx->tunedAtFrames = 0;
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
@@ -1441,6 +1495,7 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * kCounterSlots ) );
 	HIP_TRY( ctx, hipDeviceSynchronize() );   // the memsets ran on the null stream; launches use ctx->stream
 	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
+	ctx->plansBuilt = false;
 	ctx->tuneRenderFrames = ctx->tunedAtFrames = 0;
 	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
 	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
@@ -1954,6 +2009,7 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 	DevParams P = sceneParams( ctx );
 	P.workCounter = ctx->dWork;
 	P.counters = ctx->dCounters;
+	ctx->workClean = false;   // this probe uses the queue heads its own way
 	double best = 1e30;
 
 	for( int r = 0; r < repeats; r++ ) {

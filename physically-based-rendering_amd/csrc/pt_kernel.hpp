@@ -83,6 +83,7 @@ struct DevParams {
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
 	float phongAlpha;            // PHONGTESS_ALPHA (kernels built with PHONG = true only)
 	int parkEighths;             // traverse(): a node phase ends once this many eighths of the lanes that entered it have left it
+	int drainMode;               // phased schedule, once lanes are DONE: bit 0 scale phPark, bit 1 scale phShade with the lanes still at work
 	int phPark, phShade;         // phased schedule: lanes that leave a node phase before it ends / lanes that wait before a shade phase runs
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
 	int numHot;             // records [0, numHot) of the node stream are resident in LDS
@@ -2210,6 +2211,10 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const D
 template<int BRDF, bool SHADOW, bool LIGHTS, int MINW>
 __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const DevParams P ) {
 	const float4* lds = gHotNodes;
+#ifdef PBR_EXP_TAIL   // lab only: when does a wave start, when does it first find the queue empty, when does it end?
+	const unsigned long long tailStart = wall_clock64();
+	unsigned long long tailDry = 0ull;
+#endif
 	stageHotNodes( P, gHotNodes );
 
 	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
@@ -2251,9 +2256,21 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 			break;
 		}
 #endif
+		// Once the queue has run dry the wave shrinks: lanes whose last unit is finished are DONE for good.  The two
+		// thresholds are meant as shares of the wave (16 and 40 of 64 lanes); held at their absolute values, a wave of 30
+		// surviving lanes ends a node phase only when 16 of them have left it.  Measured with -DPBR_EXP_TAIL
+		// (scripts/tail_profile.py): a wave needs 0.47 ms (Sponza-class) to 1.4 ms (Dragon-class, hairball) from its first
+		// empty queue to its end, against 0.2 ms for a whole path in the steady state.  P.drainMode chooses which of the
+		// two scale with the lanes still at work (bit 0: the park count, bit 1: the shade threshold).
+		const int lanesAtWork = __popcll( __ballot( mode != MODE_DONE ) );
+		const int parkScaled = ( ( P.phPark * lanesAtWork ) >> 6 ) < 1 ? 1 : ( ( P.phPark * lanesAtWork ) >> 6 );
+		const int shadeScaled = ( ( P.phShade * lanesAtWork ) >> 6 ) < 1 ? 1 : ( ( P.phShade * lanesAtWork ) >> 6 );
+		const int parkNow = ( lanesAtWork >= 64 || !( P.drainMode & 1 ) ) ? P.phPark : parkScaled;
+		const int shadeNow = ( lanesAtWork >= 64 || !( P.drainMode & 2 ) ) ? P.phShade : shadeScaled;
+
 		// ---- node phase ---------------------------------------------------------------------
 		if( mode == MODE_NODE ) {
-			const int keep = __popcll( __ballot( 1 ) ) - P.phPark;
+			const int keep = __popcll( __ballot( 1 ) ) - parkNow;
 			unsigned visits = 0;
 
 #ifdef PBR_EXP_STATS
@@ -2323,11 +2340,16 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 #endif
 
 		// ---- shade phase --------------------------------------------------------------------
+		// (Measured and rejected: batching the two halves of shadeStep separately — shadeSurface for the lanes whose ray
+		// hit a face, endPath, with its camera ray, for the lanes whose path has ended, each behind its own threshold.
+		// Shading got cheaper per pass, but the lanes of a third waiting state are missing from the node phases:
+		// Sponza-class 0.91x, Dragon-class 0.90x, hairball 0.95x at the best thresholds; Cornell-class 1.09x, still
+		// behind its lock-step kernel.)
 		{
 			const int nShade = __popcll( __ballot( mode == MODE_SHADE ) );
 			const int nNode = __popcll( __ballot( mode == MODE_NODE ) );
 
-			if( mode == MODE_SHADE && ( nShade >= P.phShade || nNode == 0 ) ) {
+			if( mode == MODE_SHADE && ( nShade >= shadeNow || nNode == 0 ) ) {
 				PH_STAT( sShadeIt, sShadeAct )
 				if( shadeStep<BRDF, SHADOW, LIGHTS, true, false, ( MINW <= 4 ), true>( P, lds, st, cnt, w.hit ) ) {
 					finishPixel<true>( P, st );
@@ -2344,6 +2366,11 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 					}
 					else {
 						mode = MODE_DONE;
+#ifdef PBR_EXP_TAIL
+						if( tailDry == 0ull ) {
+							tailDry = wall_clock64();
+						}
+#endif
 					}
 				}
 				else {
@@ -2354,6 +2381,29 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 	}
 
 	flushCounters( P, cnt );
+#ifdef PBR_EXP_TAIL
+	{
+		// the first lane's view of the wave: start, first empty queue seen by any lane, end
+		unsigned long long dry = tailDry;
+
+		for( int off = 32; off > 0; off >>= 1 ) {
+			const unsigned long long other = ( (unsigned long long) __shfl_xor( (unsigned) ( dry >> 32 ), off, 64 ) << 32 ) | (unsigned long long) __shfl_xor( (unsigned) dry, off, 64 );
+			dry = ( dry == 0ull ) ? other : ( ( other != 0ull && other < dry ) ? other : dry );
+		}
+
+		if( ( threadIdx.x & 63u ) == 0u ) {
+			const unsigned long long tailEnd = wall_clock64();
+			atomicAdd( &P.counters[12], tailEnd - tailStart );
+			atomicMax( &P.counters[13], tailEnd );
+			atomicMax( &P.counters[14], ~tailStart );
+			atomicAdd( &P.counters[15], 1ull );
+			atomicAdd( &P.counters[4], ( dry != 0ull ) ? tailEnd - dry : 0ull );      // time spent draining, summed over the waves
+			atomicMax( &P.counters[5], ( dry != 0ull ) ? tailEnd - dry : 0ull );      // the longest drain
+			atomicMax( &P.counters[6], ~( ( dry != 0ull ) ? dry : tailEnd ) );        // the earliest "queue empty" of the launch
+			atomicMax( &P.counters[7], tailStart );                                    // the latest wave start
+		}
+	}
+#endif
 #ifdef PBR_EXP_STATS
 	atomicAdd( &P.counters[8], (unsigned long long) sNodeIt );
 	atomicAdd( &P.counters[9], (unsigned long long) sNodeAct );
@@ -2374,6 +2424,11 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 // all its frames.  imageOut.w = focus (first-hit distance) of the last frame.
 __global__ __launch_bounds__( 256 ) void foldFrames( const DevParams P, const float4* src, float4* dst ) {
 	const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+
+	// the path-tracing launch before this one has drained the queue: leave its heads at zero for the next launch
+	if( slot < (unsigned) PT_BANDS ) {
+		P.workCounter[slot * PT_BAND_STRIDE] = 0u;
+	}
 
 	if( slot >= P.frameStride ) {
 		return;
