@@ -1,8 +1,8 @@
-"""Copies what scripts/profile_round.sh collected (gpurun_out/<round>) into profiles/r01 — the files DESIGN.md §6 and
-bench.py (roofline.traffic) cite — and prints the table rows.  usage: python scripts/assemble_profiles.py gpurun_out/round1m"""
+"""Copies what scripts/profile_round.sh collected (gpurun_out/<dir>) into profiles/<round> — the files DESIGN.md §6 and
+bench.py (roofline.traffic) cite — and prints the table rows.  usage: python scripts/assemble_profiles.py gpurun_out/round2 r02"""
 import csv, glob, json, os, shutil, sys
 src = sys.argv[1]
-dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01")
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", sys.argv[2] if len(sys.argv) > 2 else "r02")
 d = json.load(open(src + "/summary.json"))
 traffic = {}
 how = ("rocprofv3 --pmc, separate passes of `python bench.py --scene S --steps K --cpu-seconds 0` with the tuned schedule forced (PBR_PLAN): "
