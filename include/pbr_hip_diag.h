@@ -50,6 +50,9 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
  * -DPBR_LEGACY_SCHEDULES, lab builds), 0 for the product build: forcing one of them then fails with PBR_EINVAL. */
 int pbr_diag_has_legacy_schedules( void );
 
+/* 1 if this build also holds the pooled schedule (pt_pool.hpp; -DPBR_POOLED_SCHEDULE, lab builds): PBR_PLAN=6. */
+int pbr_diag_has_pooled_schedule( void );
+
 /* Render with plan 0..5 (the order of pbr_diag_last_plan's *tuned: refill-lean, refill-wide, phased-lean, phased-wide,
  * phased-mid, refill-mid) from now on, without tuning; -1 hands the choice back to the tuner.  For the ranks of a
  * multi-GPU run: rank 0 tunes, broadcasts its *tuned, every rank pins it — all ranks then run the same schedule and

@@ -122,6 +122,7 @@ hip.pbr_diag_last_trace.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes
 hip.pbr_diag_last_plan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
 hip.pbr_diag_pin_plan.argtypes = [_vp, ctypes.c_int]
 hip.pbr_diag_has_legacy_schedules.argtypes = []
+hip.pbr_diag_has_pooled_schedule.argtypes = []
 hip.pbr_diag_tune_budget.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint32)]
 
 host.pbrh_last_error.restype = ctypes.c_char_p

@@ -15,6 +15,13 @@
 #include "pbr_hip.h"
 #include "pbr_hip_diag.h"
 #include "pt_kernel.hpp"
+// PBR_POOLED_SCHEDULE (lab builds only): the pooled schedule of pt_pool.hpp — the paths of a block in LDS, walker and
+// shader waves, queues drawn from by ballot + prefix sum.  Bit-identical, measured at 0.87 - 0.93x of the lane state
+// machine, so the product library does not carry it; PBR_PLAN=6 selects it where it is built.
+#if defined( PBR_POOLED_SCHEDULE ) && defined( PT_NODE_PHASE_ASM )
+#define PT_HAVE_POOLED 1
+#include "pt_pool.hpp"
+#endif
 // PBR_LEGACY_SCHEDULES (lab builds only, scripts/lab.sh): the three superseded schedules of DESIGN.md 5.1b — `tile`
 // (a wave walks whole tiles), `batched` (the flat lane state machine) and `wavefront` (pt_wavefront.hpp).  The tuner
 // never chose them; the product library holds the six plans it does choose from plus the Phong-tessellation variant.
@@ -36,6 +43,7 @@ typedef void ( *KernelFn )( const ptk::DevParams );
 struct Plan {
 	KernelFn kernel = nullptr;
 	int blocks = 0, blockThreads = 0, numHot = 0, park = 0, shade = 0, parkEighths = 4;
+	int poolShaders = 3, poolPatience = 8;   // pooled schedule only
 	size_t ldsBytes = 0;
 	const char* name = "";
 };
@@ -77,7 +85,7 @@ struct pbr_ctx {
 	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
 	// frames that are rendered anyway, then the fastest one is kept
 	int tunedPlan = -1;
-	Plan plans[6];                                  // the tuner's candidates, valid while plansBuilt (reset by pbr_upload_scene / pbr_configure)
+	Plan plans[7];                                  // [0..5] the tuner's candidates, [6] the pooled schedule (pt_pool.hpp); valid while plansBuilt (reset by pbr_upload_scene / pbr_configure)
 	Plan phongPlan;                                 // the Phong-tessellation build of the refill kernel (takes the place of plans[1])
 	bool plansBuilt = false, phongPlanBuilt = false;
 	int drainMode = 1;                              // pathTracingPhased, see launch()
@@ -275,6 +283,27 @@ const int kMidMinWaves = PBR_MID_WAVES;
 #define PBR_MID_THREADS 768
 #endif
 const int kMidBlockThreads = PBR_MID_THREADS;
+
+#ifdef PT_HAVE_POOLED
+KernelFn pickKernelPooled( uint32_t brdf, bool shadow, bool lights ) {
+#ifdef PBR_LAB
+	(void) brdf; (void) shadow; (void) lights;
+	return ptk::pathTracingPooled<1, false, false, PBR_MID_WAVES>;
+#else
+	if( brdf == 0 ) {
+		if( lights ) {
+			return shadow ? ptk::pathTracingPooled<0, true, true, PBR_MID_WAVES> : ptk::pathTracingPooled<0, false, true, PBR_MID_WAVES>;
+		}
+		return ptk::pathTracingPooled<0, false, false, PBR_MID_WAVES>;
+	}
+
+	if( lights ) {
+		return shadow ? ptk::pathTracingPooled<1, true, true, PBR_MID_WAVES> : ptk::pathTracingPooled<1, false, true, PBR_MID_WAVES>;
+	}
+	return ptk::pathTracingPooled<1, false, false, PBR_MID_WAVES>;
+#endif
+}
+#endif
 
 KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
 	return pickKernelPhasedMode<kMidMinWaves>( brdf, shadow, lights );
@@ -653,6 +682,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.numHotBytes = plan.numHot * 32;
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
+		P.poolShaders = plan.poolShaders;
+		P.poolPatience = plan.poolPatience;
 		P.drainMode = ctx->drainMode;   // 1: measured (single-frame 1080p launches): park share scaled, shade threshold as is: Dragon-class 2.99 -> 2.47 ms, hairball 4.26 -> 4.02 ms, Sponza- / Cornell-class unchanged; scaling the shade threshold too helps the first two further (2.26 / 3.56 ms) and costs the others 10 - 20 %
 		P.parkEighths = plan.parkEighths;
 		hipLaunchKernelGGL( plan.kernel, dim3( blocks ), dim3( (unsigned) plan.blockThreads ), plan.ldsBytes, ctx->stream, P );
@@ -737,6 +768,38 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			return status;
 		}
 
+#ifdef PT_HAVE_POOLED
+		{
+			// the pooled schedule: 768-thread blocks, all of a block's LDS share is the path pool (no staged nodes)
+			Plan& pool = plans[6];
+			pool.kernel = pickKernelPooled( brdf, shadow, lights );
+			pool.blockThreads = kMidBlockThreads;
+			pool.numHot = 0;
+			pool.ldsBytes = ptk::poolLdsBytes( (unsigned) kMidBlockThreads );
+			pool.park = 32;           // lanes (of 64 that entered) that leave a walker's node phase before it ends
+			pool.shade = 0;
+			pool.poolShaders = 3;     // shader waves of 12
+			pool.poolPatience = 16;   // polls before a shader wave takes a partial batch
+			pool.parkEighths = 4;
+			pool.name = "pooled-mid";
+
+			if( const char* v = std::getenv( "PBR_POOL_SHADERS" ) ) {    // experiments
+				pool.poolShaders = std::max( 1, std::min( kMidBlockThreads / 64 - 1, std::atoi( v ) ) );
+			}
+			if( const char* v = std::getenv( "PBR_POOL_PATIENCE" ) ) {
+				pool.poolPatience = std::max( 0, std::atoi( v ) );
+			}
+			if( const char* v = std::getenv( "PBR_PH_PARK" ) ) {
+				pool.park = std::max( 1, std::min( 64, std::atoi( v ) ) );
+			}
+
+			HIP_TRY( ctx, hipFuncSetAttribute( (const void*) pool.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pool.ldsBytes ) );
+			int blocksPerCU = 0;
+			HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) pool.kernel, pool.blockThreads, pool.ldsBytes ) );
+			pool.blocks = ctx->numCUs * std::max( 1, blocksPerCU );
+		}
+#endif
+
 		ctx->drainMode = 1;
 
 		if( const char* v = std::getenv( "PBR_DRAIN_MODE" ) ) {   // experiments
@@ -747,9 +810,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		ctx->phongPlanBuilt = false;
 	}
 
-	Plan plans[kPlans];
+	Plan plans[kPlans + 1];
 
-	for( int k = 0; k < kPlans; k++ ) {
+	for( int k = 0; k <= kPlans; k++ ) {
 		plans[k] = ctx->plans[k];
 	}
 
@@ -782,8 +845,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		forcedPlan = std::min( kPlans - 1, ctx->pinnedPlan );
 	}
 
-	if( const char* plan = std::getenv( "PBR_PLAN" ) ) {   // experiments: 0..5 = the candidates above, no tuning
-		forcedPlan = std::max( 0, std::min( kPlans - 1, std::atoi( plan ) ) );
+	if( const char* plan = std::getenv( "PBR_PLAN" ) ) {   // experiments: 0..5 = the candidates above, 6 = the pooled schedule; no tuning
+		forcedPlan = std::max( 0, std::min( kPlans, std::atoi( plan ) ) );
+	}
+
+	if( forcedPlan == kPlans && ( plans[kPlans].kernel == nullptr || dof || phong || ctx->cfg.samples > 255u || ctx->cfg.max_depth + ctx->cfg.max_added_depth > 255u ) ) {
+		return fail( ctx, PBR_EINVAL, "the pooled schedule is not available for this build / configuration (depth of field, Phong tessellation, samples or depth above 255)" );
 	}
 
 	if( phong ) {
@@ -2111,6 +2178,14 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned ) 
 	}
 
 	return PBR_OK;
+}
+
+int pbr_diag_has_pooled_schedule( void ) {
+#ifdef PT_HAVE_POOLED
+	return 1;
+#else
+	return 0;
+#endif
 }
 
 int pbr_diag_has_legacy_schedules( void ) {

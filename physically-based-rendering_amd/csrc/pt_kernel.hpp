@@ -83,6 +83,7 @@ struct DevParams {
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
 	float phongAlpha;            // PHONGTESS_ALPHA (kernels built with PHONG = true only)
 	int parkEighths;             // traverse(): a node phase ends once this many eighths of the lanes that entered it have left it
+	int poolShaders, poolPatience;   // pooled schedule (pt_pool.hpp, lab builds): shader waves per block; empty-handed polls before a shader wave takes a partial batch
 	int drainMode;               // phased schedule, once lanes are DONE: bit 0 scale phPark, bit 1 scale phShade with the lanes still at work
 	int phPark, phShade;         // phased schedule: lanes that leave a node phase before it ends / lanes that wait before a shade phase runs
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
@@ -1462,6 +1463,14 @@ PT_DEV bool shadowContribution(
 // ---------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------
+
+PT_DEV unsigned waveMax( unsigned v ) {
+	for( int off = 32; off > 0; off >>= 1 ) {
+		const unsigned o = (unsigned) __shfl_xor( (int) v, off, 64 );
+		v = ( o > v ) ? o : v;
+	}
+	return v;
+}
 
 PT_DEV unsigned waveSum( unsigned v ) {
 	for( int off = 32; off > 0; off >>= 1 ) {

@@ -214,6 +214,28 @@ def test_every_tuner_candidate_bit_exact(pbr, oracle, device, monkeypatch, plan,
     assert device.counters() == ref.counter_dict()
 
 
+@pytest.mark.parametrize("kind,triangles,cfg", [
+    ("cornell", 0, {"render.max_depth": 5, "render.max_added_depth": 2}),
+    ("cornell", 0, {"render.max_depth": 4, "render.brdf": 0, "render.samples": 2}),
+    ("sponza", 15000, {"render.max_depth": 3}),
+    ("hairball", 9000, {"render.max_depth": 3}),
+])
+def test_pooled_schedule_bit_exact(pbr, oracle, device, monkeypatch, kind, triangles, cfg):
+    """pt_pool.hpp (lab builds, -DPBR_POOLED_SCHEDULE; PBR_PLAN=6): the paths of a block in LDS, walker waves and shader
+    waves drawing from block-wide queues by ballot + prefix sum.  Which lane walks or shades a path changes; its node
+    visits, face tests and random draws do not."""
+    if not pbr.hip.pbr_diag_has_pooled_schedule():
+        pytest.skip("the pooled schedule is not in the product library (build pbr_hip.hip with -DPBR_POOLED_SCHEDULE=1 and no PBR_LAB, run with PBR_HIP_LIB)")
+    monkeypatch.setenv("PBR_PLAN", "6")
+    sc = make_scene(pbr, kind, 7, triangles, **cfg)
+    got, want, ref = both_render(pbr, oracle, device, sc, 88, 56, 6)
+    assert device.last_plan()[0] == "pooled-mid"
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert same_values(device.read_debug(), ref.debug)
+    assert device.counters() == ref.counter_dict()
+    assert device.guard_trips() == [0, 0, 0]
+
+
 def test_schedule_tuner_through_a_viewer_then_a_batch(pbr, oracle, device):
     """No schedule forced: launch() screens its six plans, times the finalists and keeps one (pbr_hip.hip) — on
     frame-by-frame calls first, as the reference's viewer renders (PathTracer.cpp:60-68), which cannot separate a
