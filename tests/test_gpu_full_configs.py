@@ -165,3 +165,68 @@ def test_render_across_the_frame_buffer_cap(pbr, device, monkeypatch, name):
         device.render(k, pbr.frame_seeds(k, 1), px, cam)
     single = device.read_output()
     assert same_values(fused, single), describe_mismatch(fused, single)
+
+
+@pytest.mark.parametrize("brdf,shadow", [(0, 1), (1, 1), (0, 0)])
+def test_lights_shadow_rays_and_schlick_at_full_size(pbr, oracle, device, monkeypatch, brdf, shadow):
+    """The kernel variants the three BASELINE configurations do not reach (BRDF 0, lights, shadow rays — K9, K10, K16) on
+    the Sponza-class scene at its own size: 260 k triangles, 1920 x 1080, an orb light and a point light, a 16-row band
+    of image + debug image against the oracle in the state machine and in the lock-step kernel."""
+    pbr.cfg_reset()
+    pbr.cfg_set(**{"render.max_depth": 3, "render.brdf": brdf})
+    sc = pbr.HostScene.generate("sponza", 2, 260000)
+    w, h, frames = 1920, 1080, 2
+    cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    cfg.shadow_rays = shadow
+    v = sc.arrays()["vertices"][:, :3]
+    centre, size = (v.min(0) + v.max(0)) / 2, (v.max(0) - v.min(0))
+    lights = np.zeros((2, 12), np.float32)
+    lights[0] = [centre[0], centre[1] + 0.2 * size[1], centre[2], 0, 4.0, 3.5, 3.0, 0, 2, 0.05 * float(size.max()), 0, 0]   # orb
+    lights[1] = [centre[0] - 0.2 * size[0], centre[1], centre[2] + 0.1 * size[2], 0, 1, 1, 1, 0, 1, 0, 0, 0]               # point
+    desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    desc.lights, desc.num_lights = lights.ctypes.data, 2
+    seeds = pbr.frame_seeds(0, frames)
+    rows = (h // 2 - 8, h // 2 + 8)
+    band = slice(rows[0], rows[1])
+    ref = oracle.Renderer(desc, cfg, threads=os.cpu_count() or 8)
+    for k, seed in enumerate(seeds):
+        out = ref.render_frame(float(seed), float(np.float32(k) / np.float32(k + 1)), px, cam, rows=rows)
+        ref.image[band] = out[band]
+    device.upload_scene(desc)
+    device.configure(cfg)
+    first = None
+    for plan in (4, 5):
+        monkeypatch.setenv("PBR_PLAN", str(plan))
+        device.reset_accum()
+        device.render(0, seeds, px, cam)
+        got, dbg = device.read_output(), device.read_debug()
+        assert same_values(got[band], ref.image[band]), describe_mismatch(got[band], ref.image[band])
+        assert same_values(dbg[band], ref.debug[band])
+        if first is None:
+            first = (got, dbg, device.counters())
+        else:
+            assert same_values(got, first[0]) and same_values(dbg, first[1]) and device.counters() == first[2]
+    assert first[2]["paths"] == w * h * frames
+
+
+def test_depth_of_field_at_full_size(pbr, oracle, device):
+    """K2's depth of field (pathtracing.cl:58-65, pt_utils.cl:344-373) at 1920 x 1080 on the Dragon-class scene: frame by
+    frame (every pixel reads the focus pixel's previous-frame distance), a 16-row band against the oracle."""
+    sc, cfg, cam, px, w, h = full_scene(pbr, "dragon")
+    cam.focusPoint[0], cam.focusPoint[1] = w // 2, h // 2
+    rows = (h // 2 - 8, h // 2 + 8)
+    band = slice(rows[0], rows[1])
+    ref = oracle.Renderer(sc.desc, cfg, threads=os.cpu_count() or 8)
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    for k, seed in enumerate(pbr.frame_seeds(0, 3)):
+        weight = float(np.float32(k) / np.float32(k + 1))
+        # the oracle needs the whole previous frame only through two of its pixels' .w: this pixel's (in the band) and the
+        # focus pixel's (in the band too) — rendering the band is enough as long as both lie inside it
+        out = ref.render_frame(float(seed), weight, px, cam, rows=rows)
+        ref.image[band] = out[band]
+        device.render_frame(float(seed), weight, px, cam)
+        got = device.read_output()
+        assert same_values(got[band], ref.image[band]), "frame %d: %s" % (k, describe_mismatch(got[band], ref.image[band]))
+        device.accumulate()
+    assert np.isfinite(ref.image[band][..., 3]).any()
