@@ -904,3 +904,30 @@ def test_hip_renders_the_reference_scenes(pbr, device, monkeypatch, name, plan):
     hit = np.isfinite(data["ray_t"])
     assert hit.sum() > 1000 and np.array_equal(face[hit], data["ray_face"][hit])
     assert device.guard_trips() == [0, 0, 0]
+
+
+def test_pinned_plan_is_the_plan_that_renders(pbr, oracle, device):
+    """pbr_diag_pin_plan (what the ranks of a multi-GPU run do with rank 0's choice): the pinned schedule renders every
+    launch, no tuning launches; -1 hands the choice back to the tuner; the pin survives upload / configure; the bits
+    do not depend on it."""
+    sc = make_scene(pbr, "sponza", 3, 9000, **{"render.max_depth": 3})
+    w, h = 72, 48
+    cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    want = oracle.Renderer(sc.desc, cfg, threads=8).render(0, pbr.frame_seeds(0, 5), px, cam)
+    for plan in (2, 5):
+        device.pin_plan(plan)
+        device.upload_scene(sc.desc)
+        device.configure(cfg)
+        device.render(0, pbr.frame_seeds(0, 2), px, cam)
+        assert device.last_plan() == (pbr.Device.PLAN_NAMES[plan], -1)       # pinned, and the tuner has not run
+        assert device.last_trace()[1] == 1                                    # one launch: no tuning chunks
+        device.render(2, pbr.frame_seeds(2, 3), px, cam)
+        assert device.last_plan()[0] == pbr.Device.PLAN_NAMES[plan]
+        assert same_values(device.read_output(), want)
+    device.pin_plan(-1)
+    device.reset_accum()
+    device.render(0, pbr.frame_seeds(0, 5), px, cam)
+    assert device.last_plan()[0] == pbr.Device.PLAN_NAMES[0]                  # the tuner is back: it screens its first candidate on these frames
+    assert same_values(device.read_output(), want)
+    with pytest.raises(pbr.PbrError):
+        device.pin_plan(9)
