@@ -152,6 +152,7 @@ host.pbrh_pt_generate_images.argtypes = [_vp, ctypes.c_uint32, _fp]
 host.pbrh_write_ppm.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
 host.pbrh_write_pfm.argtypes = [ctypes.c_char_p, _fp, ctypes.c_uint32, ctypes.c_uint32]
 host.pbrh_cl_adaptor_render.argtypes = [_vp, ctypes.c_uint32, ctypes.c_float, _fp, _fp]
+host.pbrh_cl_adaptor_render_ex.argtypes = [_vp, ctypes.c_uint32, ctypes.c_float, _fp, _fp, ctypes.c_uint32]
 host.pbrh_pt_set_focus.argtypes = [_vp, ctypes.c_int, ctypes.c_int]
 host.pbrh_pt_reset_sample_count.argtypes = [_vp]
 host.pbrh_pt_sample_count.argtypes = [_vp]
@@ -236,13 +237,13 @@ class HostScene:
     def __del__(self):
         self.close()
 
-    def render_through_cl_adaptor(self, frames, seed_step=0.0333):
+    def render_through_cl_adaptor(self, frames, seed_step=0.0333, refeed_every=0):
         """Drive the `CL` look-alike (host/cl_adaptor.h) the way the reference's PathTracer drives CL, at the
         configured window size (cfg window.width / window.height); returns (image, debug), row 0 = bottom."""
         w, h = int(cfg_get("window.width")), int(cfg_get("window.height"))
         image = np.empty((h, w, 4), np.float32)
         debug = np.empty((h, w, 4), np.float32)
-        if host.pbrh_cl_adaptor_render(self._h, frames, seed_step, image.ctypes.data_as(_fp), debug.ctypes.data_as(_fp)) != 0:
+        if host.pbrh_cl_adaptor_render_ex(self._h, frames, seed_step, image.ctypes.data_as(_fp), debug.ctypes.data_as(_fp), refeed_every) != 0:
             raise PbrError(host.pbrh_last_error().decode())
         return image, debug
 

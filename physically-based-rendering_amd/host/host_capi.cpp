@@ -279,7 +279,9 @@ void pbrh_pt_camera( void* tracer, pbr_camera* out ) {
 // (PathTracer.cpp:136-230 initOpenCLBuffers + initKernelArgs, :59-71 generateImage, :43-52 clPathTracing),
 // with the fixed seed sequence seedStep * ( n + 1 ).  Renders `frames` frames of `scene` at the
 // configured window size and returns the last accumulated image and debug image.
-int pbrh_cl_adaptor_render( void* scene, uint32_t frames, float seedStep, float* image, float* debug ) {
+// refeedEvery > 0: every refeedEvery-th frame feeds the input image twice before executing (a caller that re-uploads the
+// same buffer, e.g. after resetting its sample count): the reference uploads twice, the result is the same
+int pbrh_cl_adaptor_render_ex( void* scene, uint32_t frames, float seedStep, float* image, float* debug, uint32_t refeedEvery ) {
 	HostScene* s = static_cast<HostScene*>( scene );
 
 	try {
@@ -337,6 +339,11 @@ int pbrh_cl_adaptor_render( void* scene, uint32_t frames, float seedStep, float*
 		// generateImage x frames
 		for( uint32_t n = 0; n < frames; n++ ) {
 			cl.updateImageReadOnly( bufTextureIn, width, height, &textureOut[0] );
+
+			if( refeedEvery > 0 && ( n % refeedEvery ) == refeedEvery - 1 ) {
+				cl.updateImageReadOnly( bufTextureIn, width, height, &textureOut[0] );
+			}
+
 			cl_float timeSinceStart = seedStep * (float) ( n + 1 );
 			cl_float pixelWeight = (float) n / (float) ( n + 1 );
 			cl.setKernelArg( kernel, 0, sizeof( cl_float ), &timeSinceStart );
@@ -356,6 +363,10 @@ int pbrh_cl_adaptor_render( void* scene, uint32_t frames, float seedStep, float*
 		gError = e.what();
 		return -1;
 	}
+}
+
+int pbrh_cl_adaptor_render( void* scene, uint32_t frames, float seedStep, float* image, float* debug ) {
+	return pbrh_cl_adaptor_render_ex( scene, frames, seedStep, image, debug, 0 );
 }
 
 

@@ -491,6 +491,10 @@ def test_cl_adaptor_driven_like_the_reference(pbr, oracle, gpu_device, cfg):
     image, debug = sc.render_through_cl_adaptor(5)
     assert same_values(image, want), describe_mismatch(image, want)
     assert same_values(debug, ref.debug)
+    # feeding the read-back buffer twice before a frame (the adaptor's on-device swap must happen once, the second feed is
+    # an upload like the reference's): same frames
+    image, debug = sc.render_through_cl_adaptor(5, refeed_every=2)
+    assert same_values(image, want), describe_mismatch(image, want)
 
 
 def check_flat_tree(nodes, facesV_out, facesV_in, vertices):
