@@ -45,6 +45,16 @@ using namespace ptm;
 #define PT_BANDS 8
 #endif
 
+// A leaf's second face record is requested before the first face is tested (testLeaf, EAGER: 12 more registers during the
+// leaf phase, one memory latency less per two-face leaf) in kernels of up to this many waves / SIMD: the state machine /
+// the lock-step kernels
+#ifndef PT_EAGER_UP_TO
+#define PT_EAGER_UP_TO 8
+#endif
+#ifndef PT_EAGER_REFILL_UP_TO
+#define PT_EAGER_REFILL_UP_TO 8
+#endif
+
 struct DevParams {
 	const float4* nodes;    // the node stream: 2 x float4 per record {min.xy, max.xy}, {min.z, max.z, w0, w1}, see decodeNode;
 	                        // the most-visited nodes first (every block copies records [0, numHot) to LDS)
@@ -1814,13 +1824,14 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 }
 
 // One bounce of the lane's current path: traverse (pathtracing.cl:259), then shadeStep.
-template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false>
+// LEAF_EAGER: the closest-hit walk requests a leaf's second face before it tests the first (EAGER also steers the shading)
+template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false, bool LEAF_EAGER = EAGER>
 PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt ) {
 	Hit hit;
 	hit.t = inff();
 	hit.face = 0;
 	hit.normal = mk3( 0.0f, 0.0f, 0.0f );
-	traverse<false, LIGHTS, true, PHONG, EAGER>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
+	traverse<false, LIGHTS, true, PHONG, LEAF_EAGER>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
 	return shadeStep<BRDF, SHADOW, LIGHTS, FP, PHONG, EAGER, !EAGER, true>( P, lds, st, cnt, hit );
 }
 
@@ -1973,7 +1984,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 				break;
 			}
 #endif
-			if( stepPixel<BRDF, SHADOW, LIGHTS, true, PHONG, ( MINW <= 4 )>( P, lds, st, cnt ) ) {
+			if( stepPixel<BRDF, SHADOW, LIGHTS, true, PHONG, ( MINW <= 4 ), ( MINW <= PT_EAGER_REFILL_UP_TO )>( P, lds, st, cnt ) ) {
 				finishPixel<true>( P, st );
 
 				if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
@@ -2243,6 +2254,10 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 
 	WorkCursor work = beginWork();
 	unsigned frame = 0;
+#ifdef PBR_EXP_PHASE_TIME
+	unsigned long long phaseTime[3] = { 0ull, 0ull, 0ull };
+	const long long phaseStart = clock64();
+#endif
 
 	{
 		const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
@@ -2277,6 +2292,11 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 		const int parkNow = ( lanesAtWork >= 64 || !( P.drainMode & 1 ) ) ? P.phPark : parkScaled;
 		const int shadeNow = ( lanesAtWork >= 64 || !( P.drainMode & 2 ) ) ? P.phShade : shadeScaled;
 
+#ifdef PBR_EXP_PHASE_TIME   // lab only: where does a wave's time go?  (clock64 = the shader clock; taken where the wave is converged)
+		const unsigned long long maskNode = __ballot( mode == MODE_NODE );
+		const long long tNode0 = clock64();
+		long long leafDelta = 0;
+#endif
 		// ---- node phase ---------------------------------------------------------------------
 		if( mode == MODE_NODE ) {
 			const int keep = __popcll( __ballot( 1 ) ) - parkNow;
@@ -2296,11 +2316,17 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				float unusedTFar;
 				nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
 				st.dbgNodes += visits;
+#ifdef PBR_EXP_PHASE_TIME
+				const long long tPhase1 = clock64();
+#endif
 
 				// ---- leaf phase: only lanes that have just come out of the node phase can stand on a leaf
 				if( parkedFlag != 0 ) {
-					testLeaf<false, ( MINW <= 4 )>( P, leafFace0( leafWord ), leafFace1( leafWord ), st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
+					testLeaf<false, ( MINW <= PT_EAGER_UP_TO )>( P, leafFace0( leafWord ), leafFace1( leafWord ), st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
 				}
+#ifdef PBR_EXP_PHASE_TIME
+				leafDelta = clock64() - tPhase1;
+#endif
 
 				if( !alive( w.cur ) ) {
 					mode = MODE_SHADE;
@@ -2339,6 +2365,15 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 #endif
 		}
 
+#ifdef PBR_EXP_PHASE_TIME
+		if( maskNode != 0ull ) {
+			const long long both = clock64() - tNode0;
+			const int src = __ffsll( (long long) maskNode ) - 1;
+			const long long leafU = ( (long long) __shfl( (int) ( leafDelta >> 32 ), src, 64 ) << 32 ) | (long long) (unsigned) __shfl( (int) leafDelta, src, 64 );
+			phaseTime[1] += (unsigned long long) leafU;
+			phaseTime[0] += (unsigned long long) ( both - leafU );
+		}
+#endif
 #ifndef PT_NODE_PHASE_ASM
 		// ---- leaf phase ---------------------------------------------------------------------
 		if( mode == MODE_LEAF ) {
@@ -2358,6 +2393,9 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 			const int nShade = __popcll( __ballot( mode == MODE_SHADE ) );
 			const int nNode = __popcll( __ballot( mode == MODE_NODE ) );
 
+#ifdef PBR_EXP_PHASE_TIME
+			const long long tShade0 = clock64();
+#endif
 			if( mode == MODE_SHADE && ( nShade >= shadeNow || nNode == 0 ) ) {
 				PH_STAT( sShadeIt, sShadeAct )
 				if( shadeStep<BRDF, SHADOW, LIGHTS, true, false, ( MINW <= 4 ), true>( P, lds, st, cnt, w.hit ) ) {
@@ -2386,10 +2424,21 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 					mode = startWalk<LIGHTS>( P, st.ray, w );
 				}
 			}
+#ifdef PBR_EXP_PHASE_TIME
+			phaseTime[2] += (unsigned long long) ( clock64() - tShade0 );
+#endif
 		}
 	}
 
 	flushCounters( P, cnt );
+#ifdef PBR_EXP_PHASE_TIME
+	if( ( threadIdx.x & 63u ) == 0u ) {
+		atomicAdd( &P.counters[4], phaseTime[0] );                                    // node phases
+		atomicAdd( &P.counters[5], phaseTime[1] );                                    // leaf phases
+		atomicAdd( &P.counters[6], phaseTime[2] );                                    // shade checks + shading
+		atomicAdd( &P.counters[7], (unsigned long long) ( clock64() - phaseStart ) );  // the wave's whole life
+	}
+#endif
 #ifdef PBR_EXP_TAIL
 	{
 		// the first lane's view of the wave: start, first empty queue seen by any lane, end
