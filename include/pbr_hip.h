@@ -149,12 +149,13 @@ int pbr_render( pbr_ctx* ctx, uint32_t first_sample_count, uint32_t n_frames, co
 int pbr_read_output( pbr_ctx* ctx, float* rgba );
 int pbr_read_debug( pbr_ctx* ctx, float* rgba );
 
-/* Opt-in fast BVH build on the device: a linear BVH (Morton order, binary radix
- * tree, at most 2 faces per leaf) emitted in the reference's flat format — what BVH::getNodes + the packing loops of
- * PathTracer::initOpenCLBuffers_BVH / _Faces (PathTracer.cpp:238-352) produce: `nodes_out` in depth-first order with
- * miss links, `facesV_out` / `facesN_out` = the input faces re-ordered into leaf order.  NOT the reference's builder
+/* Opt-in fast BVH build on the device: faces in Morton order, clustered bottom-up by
+ * surface area, at most 2 faces per leaf, emitted in the reference's flat format — what BVH::getNodes + the packing
+ * loops of PathTracer::initOpenCLBuffers_BVH / _Faces (PathTracer.cpp:238-352) produce: `nodes_out` in depth-first order
+ * with miss links, `facesV_out` / `facesN_out` = the input faces re-ordered into leaf order.  NOT the reference's builder
  * (accelstructures/BVH.cpp, replicated on the host in host/bvh_builder.cpp): same format, different tree, so images agree
- * statistically, not bit for bit.  All pointers are host memory; nodes_out needs pbr_bvh_node_capacity( num_faces ) entries.
+ * statistically, not bit for bit.  All pointers are host memory; nodes_out needs pbr_bvh_node_capacity( num_faces )
+ * entries (2 * num_faces - 1: the count actually used comes back in *num_nodes_out).  Vertices must be finite.
  * pbr_last_kernel_ms then reports the device time of the build. */
 uint32_t pbr_bvh_node_capacity( uint32_t num_faces );
 int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertices, const pbr_uint4* facesV, const pbr_uint4* facesN,

@@ -347,7 +347,7 @@ class Device:
         return self._read(hip.pbr_read_full)
 
     def build_bvh(self, vertices, facesV, facesN):
-        """pbr_build_bvh: linear BVH on the device.  vertices (n, 4) float32, facesV / facesN (m, 4) uint32 ->
+        """pbr_build_bvh: BVH built on the device (Morton order + clustering by surface area).  vertices (n, 4) float32, facesV / facesN (m, 4) uint32 ->
         (nodes (k, 8) float32 in the reference's flat format, facesV and facesN in leaf order)."""
         vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 4)
         facesV = np.ascontiguousarray(facesV, np.uint32).reshape(-1, 4)

@@ -6,13 +6,14 @@
 //
 // It is NOT the reference's builder (accelstructures/BVH.cpp: per-object trees, SAH sweeps over
 // std::sort-ed faces, mean splits above 100 k faces, skip-ahead deletion): that one is replicated
-// on the host (host/bvh_builder.cpp), takes 25 s for 2 M triangles and defines the trees the parity
-// tests and the benchmark use.  This one is a linear BVH (Karras 2012: Morton order, binary radix
-// tree, bottom-up boxes), milliseconds for the same input, for callers who want a scene on the
-// device now and accept a tree of lower quality.  Images rendered over it agree with images over the
-// reference's tree statistically, not bit for bit (the walk order decides ties and the triangle
-// test starts from the leaf box's tNear, pt_intersect.cl:96-120).  Its result is deterministic: boxes
-// are exact min / max, the keys are unique.
+// on the host (host/bvh_builder.cpp), takes seconds for 2 M triangles and defines the trees the parity
+// tests and the benchmark use.  This one sorts the faces along a Morton curve and clusters them
+// bottom-up by surface area (PlocArrays below; round 1's binary radix tree over the same order is kept
+// as PBR_BVH_BUILDER=lbvh): milliseconds for the same input, for callers who want a scene on the
+// device now.  Images rendered over it agree with images over the reference's tree statistically,
+// not bit for bit (the walk order decides ties and the triangle test starts from the leaf box's
+// tNear, pt_intersect.cl:96-120).  Its result is deterministic: boxes are exact min / max, the keys
+// are unique, ties are ordered.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,7 +28,7 @@ struct BuildArrays {
 	const pbr_uint4* facesV;
 	const pbr_uint4* facesN;
 	unsigned numFaces, numLeaves;       // leaves hold faces 2l and 2l + 1 of the sorted order
-	unsigned long long* keys;           // Morton code << 32 | face index (unique)
+	unsigned long long* keys;           // Morton code << 24 | face index (unique)
 	unsigned long long* keysSorted;
 	float* sceneMin;                    // 3 floats each, centroid bounds
 	float* sceneMax;
@@ -97,12 +98,15 @@ __global__ void centroidBounds( const BuildArrays B ) {
 	atomicMaxFloat( &B.sceneMax[2], m.z );
 }
 
-__device__ __forceinline__ unsigned expandBits10( unsigned v ) {
-	v = ( v * 0x00010001u ) & 0xFF0000FFu;
-	v = ( v * 0x00000101u ) & 0x0F00F00Fu;
-	v = ( v * 0x00000011u ) & 0xC30C30C3u;
-	v = ( v * 0x00000005u ) & 0x49249249u;
-	return v;
+// spread the low 13 bits of v to every third bit of a 39-bit word
+__device__ __forceinline__ unsigned long long expandBits13( unsigned v ) {
+	unsigned long long x = (unsigned long long) ( v & 0x1FFFu );
+	x = ( x | ( x << 32 ) ) & 0x001F00000000FFFFull;
+	x = ( x | ( x << 16 ) ) & 0x001F0000FF0000FFull;
+	x = ( x | ( x << 8 ) ) & 0x100F00F00F00F00Full;
+	x = ( x | ( x << 4 ) ) & 0x10C30C30C30C30C3ull;
+	x = ( x | ( x << 2 ) ) & 0x1249249249249249ull;
+	return x;
 }
 
 __global__ void mortonKeys( const BuildArrays B ) {
@@ -123,11 +127,13 @@ __global__ void mortonKeys( const BuildArrays B ) {
 	for( int k = 0; k < 3; k++ ) {
 		const float extent = hi[k] - lo[k];
 		const float u = ( extent > 0.0f ) ? ( p[k] - lo[k] ) / extent : 0.0f;
-		q[k] = (unsigned) fminf( fmaxf( u * 1024.0f, 0.0f ), 1023.0f );
+		q[k] = (unsigned) fminf( fmaxf( u * 8192.0f, 0.0f ), 8191.0f );
 	}
 
-	const unsigned code = ( expandBits10( q[0] ) << 2 ) | ( expandBits10( q[1] ) << 1 ) | expandBits10( q[2] );
-	B.keys[face] = ( (unsigned long long) code << 32 ) | (unsigned long long) face;
+	// 39-bit Morton code (13 bits per axis: 8192 cells — with 10 bits, a 2 M-triangle mesh puts dozens of faces into one
+	// cell and their grouping is then the order of their indices) above the 24-bit face index (pbr_upload_scene's limit)
+	const unsigned long long code = ( expandBits13( q[0] ) << 2 ) | ( expandBits13( q[1] ) << 1 ) | expandBits13( q[2] );
+	B.keys[face] = ( code << 24 ) | (unsigned long long) face;
 }
 
 // length of the common prefix of the keys of leaves i and j, -1 outside the array (Karras 2012, delta)
@@ -210,7 +216,7 @@ __global__ void boxesBottomUp( const BuildArrays B ) {
 		const unsigned sorted = leaf * 2 + k;
 
 		if( sorted < B.numFaces ) {
-			const unsigned face = (unsigned) ( B.keysSorted[sorted] & 0xFFFFFFFFull );
+			const unsigned face = (unsigned) ( B.keysSorted[sorted] & 0xFFFFFFull );
 			float3 a, b, c;
 			faceCorners( B, face, &a, &b, &c );
 			lo.x = fminf( lo.x, fminf( a.x, fminf( b.x, c.x ) ) );
@@ -247,6 +253,19 @@ __global__ void boxesBottomUp( const BuildArrays B ) {
 		B.boxMin[up] = make_float4( fminf( lMin.x, rMin.x ), fminf( lMin.y, rMin.y ), fminf( lMin.z, rMin.z ), 0.0f );
 		B.boxMax[up] = make_float4( fmaxf( lMax.x, rMax.x ), fmaxf( lMax.y, rMax.y ), fmaxf( lMax.z, rMax.z ), 0.0f );
 		B.size[up] = 1u + B.size[l] + B.size[r];
+
+		// the child with the bigger surface area first, as BVH::combineNodes orders them (BVH.cpp:335-343): the walk visits
+		// children in array order, and a hit found early culls what follows (pt_bvh.cl:107)
+		{
+			const float lx = lMax.x - lMin.x, ly = lMax.y - lMin.y, lz = lMax.z - lMin.z;
+			const float rx = rMax.x - rMin.x, ry = rMax.y - rMin.y, rz = rMax.z - rMin.z;
+
+			if( rx * ry + rz * ry + rx * rz > lx * ly + lz * ly + lx * lz ) {
+				B.left[up] = r;
+				B.right[up] = l;
+			}
+		}
+
 		node = up;
 		up = B.parent[node];
 	}
@@ -278,6 +297,254 @@ __global__ void flatten( const BuildArrays B ) {
 		const unsigned first = ( id - internals ) * 2u;
 		out.bbMin.w = (float) first;
 		out.bbMax.w = ( first + 1u < B.numFaces ) ? (float) ( first + 1u ) : -1.0f;
+	}
+	else {
+		// on a miss the walk continues behind this subtree; -1 ends it (pt_bvh.cl:102,122)
+		const unsigned next = index + B.size[id];
+		out.bbMin.w = -1.0f;
+		out.bbMax.w = ( next < total ) ? (float) next : -1.0f;
+	}
+
+	B.nodesOut[index] = out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Locally-ordered agglomerative clustering over the Morton order (Meister & Bittner 2018, "PLOC"): the default builder.
+// Clusters start as single faces in Morton order; every round each cluster looks PLOC_RADIUS places to either side for
+// the partner with which it forms the box of the smallest surface area, mutual choices merge, the survivors are
+// compacted (prefix sum, order kept) and the round repeats until one cluster is left.  Two single faces merge into a
+// 2-face leaf (the reference's bvh.max_faces = 2, config.json:40), anything else into a container.  The surface-area
+// criterion sees the faces' real boxes, so a wall-sized triangle among small ones does not drag a spatial-median split
+// across them the way the radix tree's centroid-only splits do.  Deterministic: distances are symmetric in their
+// arguments, ties go to the lower position, node ids come from prefix sums.
+//
+// Node ids: [0, numFaces) = the faces in Morton order, [numFaces, 2 numFaces - 1) = merged clusters in creation order.
+struct PlocArrays {
+	const pbr_float4* vertices;
+	const pbr_uint4* facesV;
+	const pbr_uint4* facesN;
+	unsigned numFaces;
+	const unsigned long long* keysSorted;
+	int* left;                          // bigger surface area first (BVH.cpp:335-343); -1 for faces
+	int* right;
+	int* parent;                        // -1 while the node is still a cluster
+	unsigned* size;                     // records of the subtree in the flat format (a 2-face leaf is one record)
+	unsigned* faces;                    // faces in the subtree
+	float4* boxMin;
+	float4* boxMax;
+	int* clusters;                      // this round's clusters, in Morton order
+	int* clustersNext;
+	int* nearest;                       // position of the chosen partner
+	unsigned long long* flags;          // survives this round | merges this round << 32
+	unsigned long long* scan;           // exclusive prefix sums of flags
+	unsigned long long* totals;         // [0] = inclusive total of the round (pinned host memory is fine too)
+	pbr_bvh_node* nodesOut;
+	pbr_uint4* facesVOut;
+	pbr_uint4* facesNOut;
+};
+
+#define PLOC_MAX_RADIUS 64
+#define PLOC_THREADS 256
+
+__device__ __forceinline__ float halfArea( float3 lo, float3 hi ) {
+	const float x = hi.x - lo.x, y = hi.y - lo.y, z = hi.z - lo.z;
+	return x * y + z * y + x * z;
+}
+
+__device__ __forceinline__ unsigned pairKey( unsigned lo, unsigned hi ) {
+	unsigned h = lo * 0x9E3779B1u + hi * 0x85EBCA77u;
+	h ^= h >> 15;
+	h *= 0x2C1B3C6Du;
+	h ^= h >> 12;
+	return h;
+}
+
+// is the pair (i, a) before the pair (i, b) in (lower end, upper end) order?
+__device__ __forceinline__ bool pairBefore( int i, int a, int b ) {
+	const int aLo = ( a < i ) ? a : i, aHi = ( a < i ) ? i : a;
+	const int bLo = ( b < i ) ? b : i, bHi = ( b < i ) ? i : b;
+	return aLo < bLo || ( aLo == bLo && aHi < bHi );
+}
+
+__global__ void plocInit( const PlocArrays B ) {
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( i >= B.numFaces ) {
+		return;
+	}
+
+	const unsigned face = (unsigned) ( B.keysSorted[i] & 0xFFFFFFull );
+	const pbr_uint4 f = B.facesV[face];
+	const pbr_float4 a = B.vertices[f.x], b = B.vertices[f.y], c = B.vertices[f.z];
+	B.boxMin[i] = make_float4( fminf( a.x, fminf( b.x, c.x ) ), fminf( a.y, fminf( b.y, c.y ) ), fminf( a.z, fminf( b.z, c.z ) ), 0.0f );
+	B.boxMax[i] = make_float4( fmaxf( a.x, fmaxf( b.x, c.x ) ), fmaxf( a.y, fmaxf( b.y, c.y ) ), fmaxf( a.z, fmaxf( b.z, c.z ) ), 0.0f );
+	B.left[i] = -1;
+	B.right[i] = -1;
+	B.parent[i] = -1;
+	B.size[i] = 1u;
+	B.faces[i] = 1u;
+	B.clusters[i] = (int) i;
+}
+
+// one thread per cluster: the partner within `radius` places whose union with it has the smallest surface area
+__global__ void __launch_bounds__( PLOC_THREADS ) plocNearest( const PlocArrays B, const unsigned count, const int radius ) {
+	__shared__ float sLo[PLOC_THREADS + 2 * PLOC_MAX_RADIUS][3];
+	__shared__ float sHi[PLOC_THREADS + 2 * PLOC_MAX_RADIUS][3];
+	const int base = (int) ( blockIdx.x * PLOC_THREADS ) - radius;
+
+	for( int k = (int) threadIdx.x; k < PLOC_THREADS + 2 * radius; k += PLOC_THREADS ) {
+		const int pos = base + k;
+
+		if( pos >= 0 && pos < (int) count ) {
+			const int id = B.clusters[pos];
+			const float4 lo = B.boxMin[id], hi = B.boxMax[id];
+			sLo[k][0] = lo.x; sLo[k][1] = lo.y; sLo[k][2] = lo.z;
+			sHi[k][0] = hi.x; sHi[k][1] = hi.y; sHi[k][2] = hi.z;
+		}
+	}
+
+	__syncthreads();
+	const int i = (int) ( blockIdx.x * PLOC_THREADS + threadIdx.x );
+
+	if( i >= (int) count ) {
+		return;
+	}
+
+	const int me = (int) threadIdx.x + radius;
+	const float3 lo = make_float3( sLo[me][0], sLo[me][1], sLo[me][2] );
+	const float3 hi = make_float3( sHi[me][0], sHi[me][1], sHi[me][2] );
+	float best = __builtin_inff();
+	unsigned bestKey = 0;
+	int bestPos = -1;
+
+	for( int d = -radius; d <= radius; d++ ) {
+		const int pos = i + d;
+
+		if( d == 0 || pos < 0 || pos >= (int) count ) {
+			continue;
+		}
+
+		const int k = me + d;
+		const float3 ulo = make_float3( fminf( lo.x, sLo[k][0] ), fminf( lo.y, sLo[k][1] ), fminf( lo.z, sLo[k][2] ) );
+		const float3 uhi = make_float3( fmaxf( hi.x, sHi[k][0] ), fmaxf( hi.y, sHi[k][1] ), fmaxf( hi.z, sHi[k][2] ) );
+		const float area = halfArea( ulo, uhi );
+
+		// equal areas (regular meshes are full of them) are ordered by a hash of the PAIR, then by the pair itself: a
+		// total order over pairs that both ends evaluate alike, so the smallest pair of all is always mutual (progress
+		// every round) and ties pair up at random places instead of every cluster pointing at its lower neighbour
+		const unsigned key = pairKey( (unsigned) ( ( pos < i ) ? pos : i ), (unsigned) ( ( pos < i ) ? i : pos ) );
+
+		if( bestPos < 0 || area < best || ( area == best && ( key < bestKey || ( key == bestKey && pairBefore( i, pos, bestPos ) ) ) ) ) {
+			best = area;
+			bestKey = key;
+			bestPos = pos;
+		}
+	}
+
+	B.nearest[i] = bestPos;
+}
+
+__global__ void plocFlags( const PlocArrays B, const unsigned count ) {
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( i >= count ) {
+		return;
+	}
+
+	const int partner = B.nearest[i];
+	const bool mutual = partner >= 0 && B.nearest[partner] == (int) i;
+	const bool merges = mutual && (int) i < partner;
+	const bool absorbed = mutual && (int) i > partner;
+	B.flags[i] = ( absorbed ? 0ull : 1ull ) | ( merges ? ( 1ull << 32 ) : 0ull );
+}
+
+__global__ void plocMerge( const PlocArrays B, const unsigned count, const unsigned nextNode ) {
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( i >= count ) {
+		return;
+	}
+
+	const unsigned long long flag = B.flags[i], before = B.scan[i];
+
+	if( i == count - 1u ) {
+		B.totals[0] = before + flag;
+	}
+	if( ( flag & 1ull ) == 0ull ) {
+		return;
+	}
+
+	const unsigned slot = (unsigned) ( before & 0xFFFFFFFFull );
+	int id = B.clusters[i];
+
+	if( ( flag >> 32 ) != 0ull ) {
+		const int other = B.clusters[B.nearest[i]];
+		const int merged = (int) ( nextNode + (unsigned) ( before >> 32 ) );
+		const float4 aLo = B.boxMin[id], aHi = B.boxMax[id], bLo = B.boxMin[other], bHi = B.boxMax[other];
+		B.boxMin[merged] = make_float4( fminf( aLo.x, bLo.x ), fminf( aLo.y, bLo.y ), fminf( aLo.z, bLo.z ), 0.0f );
+		B.boxMax[merged] = make_float4( fmaxf( aHi.x, bHi.x ), fmaxf( aHi.y, bHi.y ), fmaxf( aHi.z, bHi.z ), 0.0f );
+		// the child with the bigger surface area first, as BVH::combineNodes orders them (BVH.cpp:335-343): the walk
+		// visits children in array order, and a hit found early culls what follows (pt_bvh.cl:107)
+		const bool swap = halfArea( make_float3( bLo.x, bLo.y, bLo.z ), make_float3( bHi.x, bHi.y, bHi.z ) )
+			> halfArea( make_float3( aLo.x, aLo.y, aLo.z ), make_float3( aHi.x, aHi.y, aHi.z ) );
+		B.left[merged] = swap ? other : id;
+		B.right[merged] = swap ? id : other;
+		B.parent[merged] = -1;
+		B.parent[id] = merged;
+		B.parent[other] = merged;
+		const bool leaf = id < (int) B.numFaces && other < (int) B.numFaces;
+		B.size[merged] = leaf ? 1u : 1u + B.size[id] + B.size[other];
+		B.faces[merged] = B.faces[id] + B.faces[other];
+		id = merged;
+	}
+
+	B.clustersNext[slot] = id;
+}
+
+// one thread per node id: its position in depth-first order (left subtree first) and the position of its first face,
+// then the record in the reference's wire format and, for leaves, the faces in leaf order
+__global__ void plocFlatten( const PlocArrays B, const unsigned numIds, const unsigned total ) {
+	const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if( id >= numIds ) {
+		return;
+	}
+
+	const int n = (int) B.numFaces;
+	const bool isFace = (int) id < n;
+	const int up0 = B.parent[id];
+
+	if( isFace && up0 >= 0 && B.left[up0] < n && B.right[up0] < n ) {
+		return;   // one of a 2-face leaf's faces: the leaf's thread emits it
+	}
+
+	unsigned index = 0, firstFace = 0;
+
+	for( int node = (int) id, up = up0; up >= 0; node = up, up = B.parent[up] ) {
+		const bool second = B.right[up] == node;
+		index += 1u + ( second ? B.size[B.left[up]] : 0u );
+		firstFace += second ? B.faces[B.left[up]] : 0u;
+	}
+
+	const float4 lo = B.boxMin[id], hi = B.boxMax[id];
+	pbr_bvh_node out;
+	out.bbMin.x = lo.x; out.bbMin.y = lo.y; out.bbMin.z = lo.z;
+	out.bbMax.x = hi.x; out.bbMax.y = hi.y; out.bbMax.z = hi.z;
+	const bool leaf2 = !isFace && B.left[id] < n && B.right[id] < n;
+
+	if( isFace || leaf2 ) {
+		const int members[2] = { isFace ? (int) id : B.left[id], leaf2 ? B.right[id] : -1 };
+
+		for( int k = 0; k < 2; k++ ) {
+			if( members[k] >= 0 ) {
+				const unsigned face = (unsigned) ( B.keysSorted[members[k]] & 0xFFFFFFull );
+				B.facesVOut[firstFace + k] = B.facesV[face];
+				B.facesNOut[firstFace + k] = B.facesN[face];
+			}
+		}
+
+		out.bbMin.w = (float) firstFace;
+		out.bbMax.w = leaf2 ? (float) ( firstFace + 1u ) : -1.0f;
 	}
 	else {
 		// on a miss the walk continues behind this subtree; -1 ends it (pt_bvh.cl:102,122)

@@ -1827,11 +1827,142 @@ DevParams sceneParams( pbr_ctx* ctx ) {
 }  // namespace
 
 uint32_t pbr_bvh_node_capacity( uint32_t num_faces ) {
-	const uint32_t leaves = ( num_faces + 1 ) / 2;
-	return ( leaves < 2 ) ? 2u : 2u * leaves - 1u;
+	// every face its own leaf is the most records a binary tree over them can have; at least a container and a leaf
+	return ( num_faces < 2 ) ? 2u : 2u * num_faces - 1u;
 }
 
-// Linear BVH on the device (csrc/bvh_build.hpp): Morton keys, radix sort, binary radix tree, bottom-up boxes,
+namespace {
+
+// the radix-tree builder of round 1 (Karras 2012), kept for comparison: PBR_BVH_BUILDER=lbvh
+int buildRadixTree( pbr_ctx* ctx, ptb::BuildArrays B, uint32_t num_faces, uint32_t* treeNodesOut ) {
+	const uint32_t leaves = ( num_faces + 1 ) / 2;
+	const uint32_t treeNodes = 2 * leaves - 1;
+	DevBuf dLeft, dRight, dParent, dSize, dArrived, dBoxMin, dBoxMax;
+	HIP_TRY( ctx, dLeft.alloc( sizeof( int ) * treeNodes ) );
+	HIP_TRY( ctx, dRight.alloc( sizeof( int ) * treeNodes ) );
+	HIP_TRY( ctx, dParent.alloc( sizeof( int ) * treeNodes ) );
+	HIP_TRY( ctx, dSize.alloc( sizeof( unsigned ) * treeNodes ) );
+	HIP_TRY( ctx, dArrived.alloc( sizeof( unsigned ) * treeNodes ) );
+	HIP_TRY( ctx, dBoxMin.alloc( sizeof( float4 ) * treeNodes ) );
+	HIP_TRY( ctx, dBoxMax.alloc( sizeof( float4 ) * treeNodes ) );
+	HIP_TRY( ctx, hipMemsetAsync( dParent.p, 0xFF, sizeof( int ) * treeNodes, ctx->stream ) );
+	HIP_TRY( ctx, hipMemsetAsync( dArrived.p, 0, sizeof( unsigned ) * treeNodes, ctx->stream ) );
+	B.numLeaves = leaves;
+	B.left = (int*) dLeft.p;
+	B.right = (int*) dRight.p;
+	B.parent = (int*) dParent.p;
+	B.size = (unsigned*) dSize.p;
+	B.arrived = (unsigned*) dArrived.p;
+	B.boxMin = (float4*) dBoxMin.p;
+	B.boxMax = (float4*) dBoxMax.p;
+	const unsigned threads = 256;
+	const unsigned leafBlocks = ( leaves + threads - 1 ) / threads;
+	const unsigned nodeBlocks = ( treeNodes + threads - 1 ) / threads;
+
+	if( leaves > 1 ) {
+		hipLaunchKernelGGL( ptb::radixTree, dim3( leafBlocks ), dim3( threads ), 0, ctx->stream, B );
+	}
+
+	hipLaunchKernelGGL( ptb::boxesBottomUp, dim3( leafBlocks ), dim3( threads ), 0, ctx->stream, B );
+	hipLaunchKernelGGL( ptb::flatten, dim3( nodeBlocks ), dim3( threads ), 0, ctx->stream, B );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );   // the buffers above are freed on return
+	*treeNodesOut = treeNodes;
+	return PBR_OK;
+}
+
+// locally-ordered clustering (csrc/bvh_build.hpp, PlocArrays): rounds of nearest-partner search, merge, compaction
+int buildClustered( pbr_ctx* ctx, const ptb::BuildArrays& A, uint32_t num_faces, uint32_t* treeNodesOut ) {
+	const uint32_t ids = 2 * num_faces - 1;
+	DevBuf dLeft, dRight, dParent, dSize, dFaces, dBoxMin, dBoxMax, dClusters, dClustersNext, dNearest, dFlags, dScan, dTotals, dTemp;
+	HIP_TRY( ctx, dLeft.alloc( sizeof( int ) * ids ) );
+	HIP_TRY( ctx, dRight.alloc( sizeof( int ) * ids ) );
+	HIP_TRY( ctx, dParent.alloc( sizeof( int ) * ids ) );
+	HIP_TRY( ctx, dSize.alloc( sizeof( unsigned ) * ids ) );
+	HIP_TRY( ctx, dFaces.alloc( sizeof( unsigned ) * ids ) );
+	HIP_TRY( ctx, dBoxMin.alloc( sizeof( float4 ) * ids ) );
+	HIP_TRY( ctx, dBoxMax.alloc( sizeof( float4 ) * ids ) );
+	HIP_TRY( ctx, dClusters.alloc( sizeof( int ) * num_faces ) );
+	HIP_TRY( ctx, dClustersNext.alloc( sizeof( int ) * num_faces ) );
+	HIP_TRY( ctx, dNearest.alloc( sizeof( int ) * num_faces ) );
+	HIP_TRY( ctx, dFlags.alloc( sizeof( unsigned long long ) * num_faces ) );
+	HIP_TRY( ctx, dScan.alloc( sizeof( unsigned long long ) * num_faces ) );
+	HIP_TRY( ctx, dTotals.alloc( sizeof( unsigned long long ) ) );
+
+	ptb::PlocArrays B;
+	B.vertices = A.vertices;
+	B.facesV = A.facesV;
+	B.facesN = A.facesN;
+	B.numFaces = num_faces;
+	B.keysSorted = A.keysSorted;
+	B.left = (int*) dLeft.p;
+	B.right = (int*) dRight.p;
+	B.parent = (int*) dParent.p;
+	B.size = (unsigned*) dSize.p;
+	B.faces = (unsigned*) dFaces.p;
+	B.boxMin = (float4*) dBoxMin.p;
+	B.boxMax = (float4*) dBoxMax.p;
+	B.clusters = (int*) dClusters.p;
+	B.clustersNext = (int*) dClustersNext.p;
+	B.nearest = (int*) dNearest.p;
+	B.flags = (unsigned long long*) dFlags.p;
+	B.scan = (unsigned long long*) dScan.p;
+	B.totals = (unsigned long long*) dTotals.p;
+	B.nodesOut = A.nodesOut;
+	B.facesVOut = A.facesVOut;
+	B.facesNOut = A.facesNOut;
+
+	int radius = 32;   // 4 .. 64 measured: within 3 % of each other on the Sponza- / Dragon-class scenes, 32 the best on the hairball
+
+	if( const char* e = std::getenv( "PBR_PLOC_RADIUS" ) ) {
+		radius = std::atoi( e );
+	}
+
+	radius = std::min( std::max( radius, 1 ), PLOC_MAX_RADIUS );
+	size_t tempBytes = 0;
+	HIP_TRY( ctx, hipcub::DeviceScan::ExclusiveSum( nullptr, tempBytes, B.flags, B.scan, (int) num_faces, ctx->stream ) );
+	HIP_TRY( ctx, dTemp.alloc( tempBytes ) );
+
+	const unsigned threads = PLOC_THREADS;
+	hipLaunchKernelGGL( ptb::plocInit, dim3( ( num_faces + threads - 1 ) / threads ), dim3( threads ), 0, ctx->stream, B );
+	uint32_t count = num_faces, nextNode = num_faces;
+
+	while( count > 1 ) {
+		const dim3 grid( ( count + threads - 1 ) / threads );
+		hipLaunchKernelGGL( ptb::plocNearest, grid, dim3( threads ), 0, ctx->stream, B, count, radius );
+		hipLaunchKernelGGL( ptb::plocFlags, grid, dim3( threads ), 0, ctx->stream, B, count );
+		HIP_TRY( ctx, hipcub::DeviceScan::ExclusiveSum( dTemp.p, tempBytes, B.flags, B.scan, (int) count, ctx->stream ) );
+		hipLaunchKernelGGL( ptb::plocMerge, grid, dim3( threads ), 0, ctx->stream, B, count, nextNode );
+		HIP_TRY( ctx, hipGetLastError() );
+		unsigned long long totals = 0;
+		HIP_TRY( ctx, hipMemcpyAsync( &totals, B.totals, sizeof( totals ), hipMemcpyDeviceToHost, ctx->stream ) );
+		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+		const uint32_t merged = (uint32_t) ( totals >> 32 ), left = (uint32_t) ( totals & 0xFFFFFFFFull );
+
+		if( merged == 0 || left + merged != count ) {
+			// the smallest pair of a total order is always mutual — unless the boxes do not compare (NaN corners)
+			return fail( ctx, PBR_EINVAL, "build_bvh: clustering made no progress with %u clusters left (non-finite vertices?)", count );
+		}
+
+		nextNode += merged;
+		count = left;
+		std::swap( B.clusters, B.clustersNext );
+	}
+
+	// one cluster is left: the root, the id created last (or face 0 of a single-face scene)
+	uint32_t total = 0;
+	HIP_TRY( ctx, hipMemcpyAsync( &total, B.size + ( nextNode - 1 ), sizeof( total ), hipMemcpyDeviceToHost, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	hipLaunchKernelGGL( ptb::plocFlatten, dim3( ( nextNode + threads - 1 ) / threads ), dim3( threads ), 0, ctx->stream, B, nextNode, total );
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	*treeNodesOut = total;
+	return PBR_OK;
+}
+
+}  // namespace
+
+// BVH on the device (csrc/bvh_build.hpp): Morton keys, radix sort, locally-ordered clustering by surface area,
 // depth-first flattening into the reference's node format.
 int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertices, const pbr_uint4* facesV, const pbr_uint4* facesN,
                    uint32_t num_faces, pbr_bvh_node* nodes_out, uint32_t* num_nodes_out, pbr_uint4* facesV_out, pbr_uint4* facesN_out ) {
@@ -1851,24 +1982,29 @@ int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertic
 		}
 	}
 
+	for( uint32_t v = 0; v < num_vertices; v++ ) {
+		if( !std::isfinite( vertices[v].x ) || !std::isfinite( vertices[v].y ) || !std::isfinite( vertices[v].z ) ) {
+			return fail( ctx, PBR_EINVAL, "build_bvh: vertex %u is not finite", v );
+		}
+	}
+
+	const char* which = std::getenv( "PBR_BVH_BUILDER" );
+	const bool radix = which != nullptr && std::strcmp( which, "lbvh" ) == 0;
+
+	if( which != nullptr && !radix && std::strcmp( which, "ploc" ) != 0 ) {
+		return fail( ctx, PBR_EINVAL, "build_bvh: PBR_BVH_BUILDER=%s (ploc or lbvh)", which );
+	}
+
 	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
-	const uint32_t leaves = ( num_faces + 1 ) / 2;
-	const uint32_t treeNodes = 2 * leaves - 1;
-	DevBuf dVertices, dFacesV, dFacesN, dKeys, dKeysSorted, dBounds, dLeft, dRight, dParent, dSize, dArrived, dBoxMin, dBoxMax, dNodes, dFacesVOut, dFacesNOut, dTemp;
+	const uint32_t capacity = pbr_bvh_node_capacity( num_faces );
+	DevBuf dVertices, dFacesV, dFacesN, dKeys, dKeysSorted, dBounds, dNodes, dFacesVOut, dFacesNOut, dTemp;
 	HIP_TRY( ctx, dVertices.alloc( sizeof( pbr_float4 ) * num_vertices ) );
 	HIP_TRY( ctx, dFacesV.alloc( sizeof( pbr_uint4 ) * num_faces ) );
 	HIP_TRY( ctx, dFacesN.alloc( sizeof( pbr_uint4 ) * num_faces ) );
 	HIP_TRY( ctx, dKeys.alloc( sizeof( unsigned long long ) * num_faces ) );
 	HIP_TRY( ctx, dKeysSorted.alloc( sizeof( unsigned long long ) * num_faces ) );
 	HIP_TRY( ctx, dBounds.alloc( sizeof( float ) * 8 ) );
-	HIP_TRY( ctx, dLeft.alloc( sizeof( int ) * treeNodes ) );
-	HIP_TRY( ctx, dRight.alloc( sizeof( int ) * treeNodes ) );
-	HIP_TRY( ctx, dParent.alloc( sizeof( int ) * treeNodes ) );
-	HIP_TRY( ctx, dSize.alloc( sizeof( unsigned ) * treeNodes ) );
-	HIP_TRY( ctx, dArrived.alloc( sizeof( unsigned ) * treeNodes ) );
-	HIP_TRY( ctx, dBoxMin.alloc( sizeof( float4 ) * treeNodes ) );
-	HIP_TRY( ctx, dBoxMax.alloc( sizeof( float4 ) * treeNodes ) );
-	HIP_TRY( ctx, dNodes.alloc( sizeof( pbr_bvh_node ) * treeNodes ) );
+	HIP_TRY( ctx, dNodes.alloc( sizeof( pbr_bvh_node ) * capacity ) );
 	HIP_TRY( ctx, dFacesVOut.alloc( sizeof( pbr_uint4 ) * num_faces ) );
 	HIP_TRY( ctx, dFacesNOut.alloc( sizeof( pbr_uint4 ) * num_faces ) );
 
@@ -1878,34 +2014,23 @@ int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertic
 	// order-preserving unsigned images of +inf (minima) and -inf (maxima), see ptb::atomicMinFloat
 	const unsigned bounds[8] = { 0xFF800000u, 0xFF800000u, 0xFF800000u, 0u, 0x007FFFFFu, 0x007FFFFFu, 0x007FFFFFu, 0u };
 	HIP_TRY( ctx, hipMemcpyAsync( dBounds.p, bounds, sizeof( bounds ), hipMemcpyHostToDevice, ctx->stream ) );
-	HIP_TRY( ctx, hipMemsetAsync( dParent.p, 0xFF, sizeof( int ) * treeNodes, ctx->stream ) );
-	HIP_TRY( ctx, hipMemsetAsync( dArrived.p, 0, sizeof( unsigned ) * treeNodes, ctx->stream ) );
 
 	ptb::BuildArrays B;
+	std::memset( &B, 0, sizeof( B ) );
 	B.vertices = (const pbr_float4*) dVertices.p;
 	B.facesV = (const pbr_uint4*) dFacesV.p;
 	B.facesN = (const pbr_uint4*) dFacesN.p;
 	B.numFaces = num_faces;
-	B.numLeaves = leaves;
 	B.keys = (unsigned long long*) dKeys.p;
 	B.keysSorted = (unsigned long long*) dKeysSorted.p;
 	B.sceneMin = (float*) dBounds.p;
 	B.sceneMax = (float*) dBounds.p + 4;
-	B.left = (int*) dLeft.p;
-	B.right = (int*) dRight.p;
-	B.parent = (int*) dParent.p;
-	B.size = (unsigned*) dSize.p;
-	B.arrived = (unsigned*) dArrived.p;
-	B.boxMin = (float4*) dBoxMin.p;
-	B.boxMax = (float4*) dBoxMax.p;
 	B.nodesOut = (pbr_bvh_node*) dNodes.p;
 	B.facesVOut = (pbr_uint4*) dFacesVOut.p;
 	B.facesNOut = (pbr_uint4*) dFacesNOut.p;
 
 	const unsigned threads = 256;
 	const unsigned faceBlocks = ( num_faces + threads - 1 ) / threads;
-	const unsigned leafBlocks = ( leaves + threads - 1 ) / threads;
-	const unsigned nodeBlocks = ( treeNodes + threads - 1 ) / threads;
 
 	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
 	hipLaunchKernelGGL( ptb::centroidBounds, dim3( faceBlocks ), dim3( threads ), 0, ctx->stream, B );
@@ -1913,27 +2038,27 @@ int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertic
 	HIP_TRY( ctx, hipGetLastError() );
 
 	size_t tempBytes = 0;
-	HIP_TRY( ctx, hipcub::DeviceRadixSort::SortKeys( nullptr, tempBytes, B.keys, B.keysSorted, (int) num_faces, 0, 62, ctx->stream ) );
+	HIP_TRY( ctx, hipcub::DeviceRadixSort::SortKeys( nullptr, tempBytes, B.keys, B.keysSorted, (int) num_faces, 0, 64, ctx->stream ) );
 	HIP_TRY( ctx, dTemp.alloc( tempBytes ) );
-	HIP_TRY( ctx, hipcub::DeviceRadixSort::SortKeys( dTemp.p, tempBytes, B.keys, B.keysSorted, (int) num_faces, 0, 62, ctx->stream ) );
+	HIP_TRY( ctx, hipcub::DeviceRadixSort::SortKeys( dTemp.p, tempBytes, B.keys, B.keysSorted, (int) num_faces, 0, 64, ctx->stream ) );
 
-	if( leaves > 1 ) {
-		hipLaunchKernelGGL( ptb::radixTree, dim3( leafBlocks ), dim3( threads ), 0, ctx->stream, B );
+	uint32_t treeNodes = 0;
+	const int built = radix ? buildRadixTree( ctx, B, num_faces, &treeNodes ) : buildClustered( ctx, B, num_faces, &treeNodes );
+
+	if( built != PBR_OK ) {
+		return built;
 	}
 
-	hipLaunchKernelGGL( ptb::boxesBottomUp, dim3( leafBlocks ), dim3( threads ), 0, ctx->stream, B );
-	hipLaunchKernelGGL( ptb::flatten, dim3( nodeBlocks ), dim3( threads ), 0, ctx->stream, B );
-	HIP_TRY( ctx, hipGetLastError() );
 	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
 
-	// a single leaf has no container above it, but the walk starts at node 1 (pt_bvh.cl:84): give it a root
-	pbr_bvh_node* firstTreeNode = ( leaves == 1 ) ? nodes_out + 1 : nodes_out;
+	// a tree that is a single leaf has no container above it, but the walk starts at node 1 (pt_bvh.cl:84): give it a root
+	pbr_bvh_node* firstTreeNode = ( treeNodes == 1 ) ? nodes_out + 1 : nodes_out;
 	HIP_TRY( ctx, hipMemcpyAsync( firstTreeNode, dNodes.p, sizeof( pbr_bvh_node ) * treeNodes, hipMemcpyDeviceToHost, ctx->stream ) );
 	HIP_TRY( ctx, hipMemcpyAsync( facesV_out, dFacesVOut.p, sizeof( pbr_uint4 ) * num_faces, hipMemcpyDeviceToHost, ctx->stream ) );
 	HIP_TRY( ctx, hipMemcpyAsync( facesN_out, dFacesNOut.p, sizeof( pbr_uint4 ) * num_faces, hipMemcpyDeviceToHost, ctx->stream ) );
 	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
 
-	if( leaves == 1 ) {
+	if( treeNodes == 1 ) {
 		nodes_out[0] = nodes_out[1];
 		nodes_out[0].bbMin.w = -1.0f;
 		nodes_out[0].bbMax.w = -1.0f;

@@ -1,4 +1,4 @@
-"""Device-built linear BVH vs the host replica of the reference's builder: build time and render rate.
+"""Device-built BVH (pbr_build_bvh; PBR_BVH_BUILDER=lbvh for round 1's radix tree) vs the host replica of the reference's builder: build time and render rate.
 usage: python scripts/lbvh_compare.py [scene ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ for name in (sys.argv[1:] or ["sponza", "dragon", "hairball"]):
     build_ms = dev.last_kernel_ms()
     cfg, cam, px = sc.config(W, H), sc.camera(), pbr.pixel_dimension(W, H)
     rates = {}
-    for label, desc in (("host SAH replica", sc.desc), ("device LBVH", None)):
+    for label, desc in (("host SAH replica", sc.desc), ("device build", None)):
         if desc is None:
             desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
             desc.bvh, desc.num_nodes, desc.facesV, desc.facesN = nodes.ctypes.data, nodes.shape[0], fv.ctypes.data, fn.ctypes.data
@@ -27,7 +27,7 @@ for name in (sys.argv[1:] or ["sponza", "dragon", "hairball"]):
         dev.render(0, pbr.frame_seeds(0, FRAMES), px, cam)
         c1 = dev.counters(); ms = dev.last_kernel_ms()
         rates[label] = (W * H * FRAMES / ms / 1e3, (c1["nodes"] - c0["nodes"]) / (W * H * FRAMES), dev.last_plan()[0])
-    print("%-9s %8d faces: host build (scene generation + SAH replica) %.1f s; device LBVH %.2f ms on the device, %.0f ms with transfers, %d nodes" % (
+    print("%-9s %8d faces: host build (scene generation + SAH replica) %.1f s; device build %.2f ms on the device, %.0f ms with transfers, %d nodes" % (
         name, arr["facesV"].shape[0], host_s, build_ms, wall * 1e3, nodes.shape[0]))
     for label, (rate, visits, plan) in rates.items():
         print("    %-18s %8.1f Msamples/s  %6.1f node visits/sample  (%s)" % (label, rate, visits, plan))

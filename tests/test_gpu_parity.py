@@ -540,11 +540,13 @@ def check_flat_tree(nodes, facesV_out, facesV_in, vertices):
         assert np.array_equal(nodes[i, 0:3], nodes[sub, 0:3].min(0)) and np.array_equal(nodes[i, 4:7], nodes[sub, 4:7].max(0))
 
 
+@pytest.mark.parametrize("builder", ["ploc", "lbvh"])
 @pytest.mark.parametrize("kind,triangles", [("cornell", 0), ("sponza", 6000), ("hairball", 30001)])
-def test_device_bvh_build_emits_the_reference_format(pbr, oracle, device, kind, triangles):
-    """pbr_build_bvh: the linear BVH built on the device is a valid tree in the reference's flat format
-    (structure, exact boxes, every face once); HIP and oracle agree bit for bit when both walk it; and the
-    hits are the geometric closest hits (brute force)."""
+def test_device_bvh_build_emits_the_reference_format(pbr, oracle, device, monkeypatch, kind, triangles, builder):
+    """pbr_build_bvh: the tree built on the device (locally-ordered clustering, or round 1's radix tree with
+    PBR_BVH_BUILDER=lbvh) is a valid tree in the reference's flat format (structure, exact boxes, every face once);
+    HIP and oracle agree bit for bit when both walk it; and the hits are the geometric closest hits (brute force)."""
+    monkeypatch.setenv("PBR_BVH_BUILDER", builder)
     sc = make_scene(pbr, kind, 5, triangles, **{"render.max_depth": 3})
     arr = sc.arrays()
     nodes, fv, fn = device.build_bvh(arr["vertices"], arr["facesV"], arr["facesN"])
@@ -578,6 +580,31 @@ def test_device_bvh_build_emits_the_reference_format(pbr, oracle, device, kind, 
         best = tt[ok].min() if ok.any() else np.inf
         if np.isfinite(best) or np.isfinite(t[k]):
             assert abs(float(t[k]) - best) <= 1e-3 * max(1.0, best), (k, float(t[k]), best)
+
+
+@pytest.mark.parametrize("faces", [1, 2, 3, 5, 64, 257])
+def test_device_bvh_build_small_and_regular_inputs(pbr, device, faces):
+    """1 and 2 faces (a single leaf under an added container), odd counts, and a regular strip of identical
+    triangles — all pair distances tie, the rounds must still pair clusters up instead of chaining."""
+    verts = np.zeros((faces + 2, 4), np.float32)
+    verts[:, 0] = np.arange(faces + 2) // 2
+    verts[:, 1] = np.arange(faces + 2) % 2
+    fv = np.zeros((faces, 4), np.uint32)
+    fv[:, 0], fv[:, 1], fv[:, 2] = np.arange(faces), np.arange(faces) + 1, np.arange(faces) + 2
+    fn = np.zeros_like(fv)
+    nodes, outV, outN = device.build_bvh(verts, fv, fn)
+    assert nodes.shape[0] <= 2 * faces - 1 or faces == 1
+    check_flat_tree(nodes, outV, fv, verts)
+    if faces <= 2:
+        assert nodes.shape[0] == 2 and nodes[1, 3] == 0 and nodes[1, 7] == (1 if faces == 2 else -1)
+
+
+def test_device_bvh_build_rejects_what_it_cannot_order(pbr, device):
+    verts = np.zeros((6, 4), np.float32)
+    verts[:, 0] = np.nan
+    fv = np.array([[0, 1, 2, 0], [3, 4, 5, 0], [0, 2, 4, 0]], np.uint32)
+    with pytest.raises(pbr.PbrError):
+        device.build_bvh(verts, fv, np.zeros_like(fv))
 
 
 def smooth_scene(pbr, tmp_path, **cfg):
