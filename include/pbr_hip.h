@@ -149,6 +149,32 @@ int pbr_render( pbr_ctx* ctx, uint32_t first_sample_count, uint32_t n_frames, co
 int pbr_read_output( pbr_ctx* ctx, float* rgba );
 int pbr_read_debug( pbr_ctx* ctx, float* rgba );
 
+/* The denoise half of the display step.  The reference's noise filter was never finished
+ * (source/opencl/noise_filtering.cl:386-401,417 are TODOs; PathTracer.cpp:155-160 never launches it), so there is no
+ * behaviour to match: this keeps its shape — per-pixel first-hit feature buffers (position, normal, texture colour;
+ * :441-455), several passes, feature distances over standard deviations (:6-7) — and fills the TODOs with the
+ * edge-avoiding a-trous wavelet filter: pass k weighs 5 x 5 taps 2^k pixels apart by
+ *   B3-spline * exp( -( |dc|^2 / (sigma_color / 2^k)^2 + |dn|^2 / sigma_normal^2 + |dx|^2 / (sigma_world * 2^k * pxDim * t)^2
+ *                       + |da|^2 / sigma_albedo^2 ) ),
+ * c the colour, n the first-hit normal (unit, towards the viewer), x the first-hit position, t the centre pixel's
+ * first-hit distance (so sigma_world is in pixel footprints), a the first-hit diffuse colour (Kd); taps across the
+ * hit / miss divide are left out; a standard deviation of 0 switches its term off.  Features come from one primary ray
+ * through every pixel centre over the uploaded scene (orb lights are not in that pass).
+ *   rgba      host, width x height x 4 floats, row 0 = bottom like pbr_read_output: filtered colour, .w = the
+ *             accumulated first-hit distance, unfiltered.  The accumulation itself is not modified.
+ *   features  optional (NULL): host, 3 x width x height x 4 floats — position {x, y, z, t (INFINITY: miss)},
+ *             normal {x, y, z, hit ? 1 : 0}, albedo {Kd, material index (-1: miss)}.
+ * With tile sharding the gathered frame is filtered: call pbr_import_tiles first.  pbr_last_kernel_ms reports the device
+ * time of feature pass + filter. */
+typedef struct pbr_denoise_params {
+	uint32_t passes;      /* 1 .. 8; 5 passes span 61 pixels */
+	float sigma_color;
+	float sigma_normal;
+	float sigma_world;
+	float sigma_albedo;
+} pbr_denoise_params;
+int pbr_denoise( pbr_ctx* ctx, float pxDim, const pbr_camera* cam, const pbr_denoise_params* params, float* rgba, float* features );
+
 /* Opt-in fast BVH build on the device: faces in Morton order, clustered bottom-up by
  * surface area, at most 2 faces per leaf, emitted in the reference's flat format — what BVH::getNodes + the packing
  * loops of PathTracer::initOpenCLBuffers_BVH / _Faces (PathTracer.cpp:238-352) produce: `nodes_out` in depth-first order

@@ -32,6 +32,16 @@ class Camera(ctypes.Structure):
                 ("focusPoint", ctypes.c_int32 * 2), ("lense", ctypes.c_float * 2)]
 
 
+class DenoiseParams(ctypes.Structure):
+    """pbr_denoise_params.  Defaults: what scripts/denoise_demo.py found best around 4 spp (sigma_color: 4.0 at 1 spp,
+    0.6 at 16, 0.3 at 64 — the noise it has to bridge shrinks with the sample count)."""
+    _fields_ = [("passes", ctypes.c_uint32), ("sigma_color", ctypes.c_float), ("sigma_normal", ctypes.c_float),
+                ("sigma_world", ctypes.c_float), ("sigma_albedo", ctypes.c_float)]
+
+    def __init__(self, passes=5, sigma_color=1.2, sigma_normal=0.25, sigma_world=3.0, sigma_albedo=0.1):
+        super().__init__(passes, sigma_color, sigma_normal, sigma_world, sigma_albedo)
+
+
 class SceneDesc(ctypes.Structure):
     """pbr_scene_desc"""
     _fields_ = [
@@ -98,6 +108,7 @@ hip.pbr_render.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32, _fp, ctypes.c_
 hip.pbr_read_output.argtypes = [_vp, _fp]
 hip.pbr_read_debug.argtypes = [_vp, _fp]
 hip.pbr_read_display.argtypes = [_vp, ctypes.c_void_p, ctypes.c_int]
+hip.pbr_denoise.argtypes = [_vp, ctypes.c_float, ctypes.POINTER(Camera), ctypes.POINTER(DenoiseParams), _fp, _fp]
 hip.pbr_bvh_node_capacity.argtypes = [ctypes.c_uint32]
 hip.pbr_bvh_node_capacity.restype = ctypes.c_uint32
 hip.pbr_build_bvh.argtypes = [_vp, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p, ctypes.c_void_p]
@@ -374,6 +385,17 @@ class Device:
         out = np.empty((self.height, self.width, 4), np.uint8)
         self._check(hip.pbr_read_display(self._ctx, out.ctypes.data, 1 if top_row_first else 0))
         return out
+
+    def denoise(self, px_dim, cam, params=None, features=False):
+        """pbr_denoise: the accumulated image after the edge-avoiding a-trous filter, (H, W, 4) float32 (the accumulation
+        is not modified); with features=True also the first-hit feature buffers (3, H, W, 4): position | t, normal | hit,
+        Kd | material."""
+        params = params if params is not None else DenoiseParams()
+        out = np.empty((self.height, self.width, 4), np.float32)
+        feat = np.empty((3, self.height, self.width, 4), np.float32) if features else None
+        self._check(hip.pbr_denoise(self._ctx, px_dim, ctypes.byref(cam), ctypes.byref(params), out.ctypes.data_as(_fp),
+                                    feat.ctypes.data_as(_fp) if features else None))
+        return (out, feat) if features else out
 
     def counters(self):
         c = Counters()

@@ -29,6 +29,7 @@
 #include "pt_wavefront.hpp"
 #endif
 #include "bvh_build.hpp"
+#include "pt_denoise.hpp"
 
 using ptk::DevParams;
 #ifdef PBR_LEGACY_SCHEDULES
@@ -1825,6 +1826,112 @@ DevParams sceneParams( pbr_ctx* ctx ) {
 }
 
 }  // namespace
+
+// The denoise half of the display step (csrc/pt_denoise.hpp): first-hit features from one primary ray per pixel, then
+// edge-avoiding a-trous passes over the accumulated image.  Leaves the accumulation untouched.
+int pbr_denoise( pbr_ctx* ctx, float pxDim, const pbr_camera* cam, const pbr_denoise_params* params, float* rgba, float* features ) {
+	if( ctx == nullptr || ctx->stream == nullptr ) {
+		return PBR_EINVAL;
+	}
+	if( !ctx->hasScene || !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "denoise before pbr_upload_scene / pbr_configure" );
+	}
+	if( cam == nullptr || params == nullptr || rgba == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "denoise: null camera, parameters or destination" );
+	}
+	if( params->passes < 1 || params->passes > 8 ) {
+		return fail( ctx, PBR_EINVAL, "denoise: 1 .. 8 passes (got %u)", params->passes );
+	}
+
+	const float sigmas[4] = { params->sigma_color, params->sigma_normal, params->sigma_world, params->sigma_albedo };
+
+	for( int k = 0; k < 4; k++ ) {
+		if( !( sigmas[k] >= 0.0f ) || !std::isfinite( sigmas[k] ) ) {
+			return fail( ctx, PBR_EINVAL, "denoise: standard deviations must be finite and >= 0 (0 switches a feature off)" );
+		}
+	}
+
+	const bool sharded = ctx->cfg.tile_world > 1;
+
+	if( sharded && ctx->dFull == nullptr ) {
+		return fail( ctx, PBR_ESTATE, "denoise with tile sharding filters the gathered frame: call pbr_import_tiles first" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	const int w = (int) ctx->cfg.width, h = (int) ctx->cfg.height;
+	const size_t pixels = (size_t) w * (size_t) h;
+	DevBuf dPosition, dNormal, dAlbedo, dPing, dPong;
+	HIP_TRY( ctx, dPosition.alloc( sizeof( float4 ) * pixels ) );
+	HIP_TRY( ctx, dNormal.alloc( sizeof( float4 ) * pixels ) );
+	HIP_TRY( ctx, dAlbedo.alloc( sizeof( float4 ) * pixels ) );
+	HIP_TRY( ctx, dPing.alloc( sizeof( float4 ) * pixels ) );
+	HIP_TRY( ctx, dPong.alloc( sizeof( float4 ) * pixels ) );
+
+	DevParams P = sceneParams( ctx );
+	const float* src[4] = { &cam->eye.x, &cam->w.x, &cam->u.x, &cam->v.x };
+	float* dst[4] = { P.eye, P.cw, P.cu, P.cv };
+
+	for( int i = 0; i < 4; i++ ) {
+		for( int k = 0; k < 3; k++ ) {
+			dst[i][k] = src[i][k];
+		}
+	}
+
+	for( int k = 0; k < 3; k++ ) {   // as launch() does for initRay
+		const float cuW = P.cu[k] * (float) w;
+		P.camA[k] = P.cu[k] - cuW;
+		P.cvH[k] = P.cv[k] * (float) h;
+	}
+
+	P.halfPx = pxDim * 0.5f;
+	P.pxDim = pxDim;
+	P.width = w;
+	P.height = h;
+
+	const dim3 block( 64, 4 );
+	const dim3 grid( ( w + 63 ) / 64, ( h + 3 ) / 4 );
+	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
+	hipLaunchKernelGGL( ptk::untile, grid, block, 0, ctx->stream, (const float4*) ( sharded ? ctx->dFull : ctx->dImgOut ), (float4*) dPing.p,
+		w, h, ctx->tilesX, 1, 0 );
+	hipLaunchKernelGGL( ptd::firstHitFeatures, grid, block, 0, ctx->stream, P, (float4*) dPosition.p, (float4*) dNormal.p, (float4*) dAlbedo.p );
+	HIP_TRY( ctx, hipGetLastError() );
+
+	auto inverseSquare = []( float sigma ) { return ( sigma > 0.0f ) ? 1.0f / ( sigma * sigma ) : 0.0f; };
+	float4* in = (float4*) dPing.p;
+	float4* out = (float4*) dPong.p;
+
+	for( uint32_t pass = 0; pass < params->passes; pass++ ) {
+		ptd::DenoiseArgs A;
+		A.width = w;
+		A.height = h;
+		A.step = 1 << pass;
+		// the colour's standard deviation halves from pass to pass (Dammertz et al. 2010, section 3.3): what the early
+		// passes smoothed, the late, wide ones must not blur again
+		A.invColor = inverseSquare( params->sigma_color / (float) ( 1u << pass ) );
+		A.invNormal = inverseSquare( params->sigma_normal );
+		A.invAlbedo = inverseSquare( params->sigma_albedo );
+		A.worldScale = params->sigma_world * (float) A.step * pxDim;
+		hipLaunchKernelGGL( ptd::atrousPass, grid, block, 0, ctx->stream, A, (const float4*) in, out,
+			(const float4*) dPosition.p, (const float4*) dNormal.p, (const float4*) dAlbedo.p );
+		std::swap( in, out );
+	}
+
+	HIP_TRY( ctx, hipGetLastError() );
+	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpyAsync( rgba, in, sizeof( float4 ) * pixels, hipMemcpyDeviceToHost, ctx->stream ) );
+
+	if( features != nullptr ) {
+		HIP_TRY( ctx, hipMemcpyAsync( features, dPosition.p, sizeof( float4 ) * pixels, hipMemcpyDeviceToHost, ctx->stream ) );
+		HIP_TRY( ctx, hipMemcpyAsync( features + 4 * pixels, dNormal.p, sizeof( float4 ) * pixels, hipMemcpyDeviceToHost, ctx->stream ) );
+		HIP_TRY( ctx, hipMemcpyAsync( features + 8 * pixels, dAlbedo.p, sizeof( float4 ) * pixels, hipMemcpyDeviceToHost, ctx->stream ) );
+	}
+
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	float ms = 0.0f;
+	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
+	ctx->lastKernelMs = (double) ms;
+	return PBR_OK;
+}
 
 uint32_t pbr_bvh_node_capacity( uint32_t num_faces ) {
 	// every face its own leaf is the most records a binary tree over them can have; at least a container and a leaf
