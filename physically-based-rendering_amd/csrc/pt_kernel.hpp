@@ -49,6 +49,14 @@ using namespace ptm;
 // leaf phase, one memory latency less per two-face leaf) in kernels of up to this many waves / SIMD: the state machine /
 // the lock-step kernels
 #ifndef PT_EAGER_UP_TO
+// Wave priority (s_setprio) while a wave walks: a SIMD arbitrates between its waves by it.  A walking wave issues a
+// handful of instructions and then waits on a fetch; a shading wave issues hundreds back to back.  With the walkers
+// ahead of the shaders a node visit's loads go out as soon as its wave can issue, and shading fills the gaps: measured
+// +2.0 % (Sponza-class), +0.6 % (Dragon-class), 0 (hairball) in the lane state machine with the leaf phase included,
+// +3.2 % on Cornell and +2.2 % on the Sponza-class scene in the lock-step kernels (node phase only); the other way
+// round — shading ahead — costs 2.7 %.  Priorities 1, 2 and 3 measure alike (profiles/r02/experiments/prio.txt).
+#define PT_WALK_PRIO 1
+
 #define PT_EAGER_UP_TO 8
 #endif
 #ifndef PT_EAGER_REFILL_UP_TO
@@ -920,7 +928,9 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 #ifdef PT_NODE_PHASE_ASM
 			if( USE_LDS ) {
 				int parkedFlag;
+				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );
 				nodePhaseAsm<ANYHIT>( P, oxy, ozz, ixy, izz, hit.t, keep, cur.ref, visits, leafWord, leafTNear, leafTFar, parkedFlag );
+				__builtin_amdgcn_s_setprio( 0 );
 				parked = ( parkedFlag != 0 );
 				walking = alive( cur );
 			}
@@ -2314,6 +2324,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				const f2v izz = { w.invDir.z, w.invDir.z };
 				int leafWord = 0, parkedFlag;
 				float unusedTFar;
+				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );   // through the leaf phase below
 				nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
 				st.dbgNodes += visits;
 #ifdef PBR_EXP_PHASE_TIME
@@ -2324,6 +2335,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				if( parkedFlag != 0 ) {
 					testLeaf<false, ( MINW <= PT_EAGER_UP_TO )>( P, leafFace0( leafWord ), leafFace1( leafWord ), st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
 				}
+				__builtin_amdgcn_s_setprio( 0 );
 #ifdef PBR_EXP_PHASE_TIME
 				leafDelta = clock64() - tPhase1;
 #endif

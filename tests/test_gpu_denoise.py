@@ -143,15 +143,20 @@ def test_open_sky_is_a_fixed_point_and_is_not_mixed_with_geometry(pbr, device):
     w, h = 96, 64
     sc, cam, px = rendered(pbr, device, "dragon", 4000, w, h, 2, **{"render.antialiasing": 0.0})
     noisy = device.read_output()
-    out, feat = device.denoise(px, cam, features=True)
+    out, feat = device.denoise(px, cam, pbr.DenoiseParams(passes=2), features=True)      # taps reach 2 * (1 + 2) = 6 pixels
     miss = feat[1][..., 3] == 0
     assert 0.02 < miss.mean() < 0.98
-    # (a handful of silhouette pixels: the renderer normalises the direction once more, pt_utils.cl:327-340, and lands on
-    # the other side of an edge; they are miss-class taps with a surface's colour, held down by the colour term)
-    pure = miss & np.isinf(noisy[..., 3])
-    assert (miss & ~pure).mean() < 0.01
-    assert np.abs(out[pure][:, :3] - noisy[pure][:, :3]).max() < 5e-3
-    assert np.median(np.abs(out[pure][:, :3] - noisy[pure][:, :3])) < 1e-6
+    # (a handful of silhouette pixels are miss-class by their centre ray and carry a surface's colour: the renderer
+    # normalises the direction once more, pt_utils.cl:327-340, and lands on the other side of an edge; whatever they
+    # can reach is set aside)
+    impure = miss & ~np.isinf(noisy[..., 3])
+    assert impure.mean() < 0.01
+    reach = np.zeros_like(impure)
+    for y, x in zip(*np.nonzero(impure)):
+        reach[max(0, y - 6): y + 7, max(0, x - 6): x + 7] = True
+    pure = miss & ~reach
+    assert pure.mean() > 0.02
+    assert np.allclose(out[pure][:, :3], noisy[pure][:, :3], rtol=1e-6)
     hit = ~miss
     assert np.abs(out[hit][:, :3] - noisy[hit][:, :3]).max() > 1e-3          # while the surfaces were filtered
 
