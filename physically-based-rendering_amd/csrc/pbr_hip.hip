@@ -882,9 +882,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	}
 
 	if( ctx->frameBufFrames < chunkCap ) {
-		// sized once for renders of up to 256 frames (or the cap): a longer render after a short one must not pay
-		// for a multi-GB reallocation (288 GB of HBM: 8.5 GB at 1080p is not the constraint)
-		const size_t frames = std::max<size_t>( chunkCap, std::min<size_t>( 256, std::max<size_t>( 1, kFrameBufBytes / frameBytes ) ) );
+		// sized at most twice: for renders of up to 256 frames, and — the first time a render is longer than that — for the
+		// cap.  A longer render after a shorter one must not pay for a multi-GB reallocation inside the call (measured:
+		// 432 -> 512 frames at 1080p, hipFree + hipMalloc of 16 GiB = 0.4 - 0.7 s when the pages have had other owners;
+		// 288 GB of HBM: 16 GiB is not the constraint)
+		const size_t capFrames = std::max<size_t>( 1, kFrameBufBytes / frameBytes );
+		const size_t frames = ( chunkCap <= 256 ) ? std::max<size_t>( chunkCap, std::min<size_t>( 256, capFrames ) ) : std::max<size_t>( chunkCap, capFrames );
 		(void) hipFree( ctx->dFrameBuf );
 		ctx->dFrameBuf = nullptr;
 		ctx->frameBufFrames = 0;
