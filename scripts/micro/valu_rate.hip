@@ -26,6 +26,15 @@ __global__ __launch_bounds__( 1024 ) void rate( float* out, int iters ) {
 			REP8( asm volatile( "v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n v_add_f32 %4, %4, %4\n v_add_f32 %5, %5, %5\n v_add_f32 %6, %6, %6\n v_add_f32 %7, %7, %7"
 				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ), "+v"( a7 ) ); )
 		}
+		else if( MODE == 9 || MODE == 10 || MODE == 11 ) {
+			// the same 64 v_add_f32 with part of EXEC switched off: does the SIMD skip an idle half (quarter) of a wave?
+			const unsigned long long mask = ( MODE == 9 ) ? 0x00000000FFFFFFFFull : ( MODE == 10 ) ? 0x000000000000FFFFull : 0x0000FFFF0000FFFFull;
+			unsigned long long saved;
+			asm volatile( "s_mov_b64 %0, exec\n s_mov_b64 exec, %1" : "=&s"( saved ) : "s"( mask ) );
+			REP8( asm volatile( "v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n v_add_f32 %4, %4, %4\n v_add_f32 %5, %5, %5\n v_add_f32 %6, %6, %6\n v_add_f32 %7, %7, %7"
+				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ), "+v"( a7 ) ); )
+			asm volatile( "s_mov_b64 exec, %0" :: "s"( saved ) );
+		}
 		else if( MODE == 1 ) {
 			REP8( asm volatile( "v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3\n v_pk_add_f32 %4, %4, %4\n v_pk_add_f32 %5, %5, %5\n v_pk_add_f32 %6, %6, %6\n v_pk_add_f32 %7, %7, %7"
 				: "+v"( p0 ), "+v"( p1 ), "+v"( p2 ), "+v"( p3 ), "+v"( p4 ), "+v"( p5 ), "+v"( p6 ), "+v"( p7 ) ); )
@@ -114,6 +123,9 @@ int main() {
 	float* out;
 	hipMalloc( &out, sizeof( float ) * cus * 2 * 1024 );
 	run<0>( "v_add_f32", cus, out );
+	run<9>( "v_add_f32, EXEC = low 32 lanes", cus, out );
+	run<10>( "v_add_f32, EXEC = low 16 lanes", cus, out );
+	run<11>( "v_add_f32, EXEC = 16 + 16 lanes", cus, out );
 	run<1>( "v_pk_add_f32", cus, out );
 	run<2>( "v_min3_f32", cus, out );
 	run<3>( "v_cndmask/v_mov", cus, out );
