@@ -5,7 +5,8 @@
 SURVEY.md section 8(c) asks for fixtures of the scenes the reference ships —
 resources/models/testing/{pillars,suzanne,spheres}.obj|.mtl|.lights: reference-authored material sets (glass d = 0,
 the nu = nv = 100000 lobes of suzanne.mtl / spheres.mtl, `light` flags), a real .lights file with shadow rays — as
-flat arrays plus expected outputs.  The .obj / .mtl / .lights files are loaded through this repository's stand-ins for
+flat arrays plus expected outputs; and, beyond what was asked, the other four models the reference ships
+(applejack2, applejack3, squirrel-mirror, squirrels).  The .obj / .mtl / .lights files are loaded through this repository's stand-ins for
 the reference's loaders (host/model_io.cpp) and its BVH builder replica (host/bvh_builder.cpp); what is stored is DATA:
 
   inputs    the seven wire-format arrays PathTracer::initOpenCLBuffers would upload (bvh, facesV, facesN, vertices,
@@ -43,6 +44,15 @@ CASES = {
     # spheres: two glass spheres + a mirror-like one in a Cornell box
     "ref_spheres_sa": ("spheres.obj", {"render.brdf": 1, "render.max_depth": 4}, 64, 48, 3),
     "ref_spheres_schlick": ("spheres.obj", {"render.brdf": 0, "render.max_depth": 4}, 64, 48, 3),
+    # the rest of what the reference ships (resources/models/testing/README): applejack2 / applejack3 — 8 k faces,
+    # 6 / 2 objects (per-object trees under one root), anisotropic lobes (nu = 2, nv = 5), a `light 0` flag
+    "ref_applejack2_sa": ("applejack2.obj", {"render.brdf": 1}, 64, 48, 2),
+    "ref_applejack3_schlick": ("applejack3.obj", {"render.brdf": 0}, 64, 48, 2),
+    # squirrel-mirror: a nu = nv = 400, Rs = 0.95 mirror wall; squirrels: a glass squirrel (d = 0, Ni = 1.5) in a Cornell box
+    "ref_squirrel_mirror_sa": ("squirrel-mirror.obj", {"render.brdf": 1, "render.max_depth": 4}, 64, 48, 3),
+    "ref_squirrel_mirror_schlick": ("squirrel-mirror.obj", {"render.brdf": 0, "render.max_depth": 4}, 64, 48, 3),
+    "ref_squirrels_sa": ("squirrels.obj", {"render.brdf": 1, "render.max_depth": 4}, 64, 48, 3),
+    "ref_squirrels_schlick": ("squirrels.obj", {"render.brdf": 0, "render.max_depth": 4}, 64, 48, 3),
 }
 
 CONFIG_FIELDS = ("width", "height", "brdf", "shadow_rays", "max_depth", "max_added_depth", "samples", "anti_aliasing", "phong_tessellation")
