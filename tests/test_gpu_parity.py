@@ -675,7 +675,7 @@ def test_phong_tessellation_bit_exact(pbr, oracle, device, tmp_path, brdf):
 def test_random_configurations_bit_exact(pbr, oracle, device, monkeypatch, seed):
     """Seeded differential sweep over the configuration space: scene kind / size, image shape, depths, samples,
     BRDF, anti-aliasing, lights + shadow rays, schedule, register budget, LDS share, frames per launch pair.
-    24 seeds in the suite; PBR_SOAK_SEEDS=n runs the first n (a soak of 600 is logged in profiles/r02/soak.txt)."""
+    24 seeds in the suite; PBR_SOAK_SEEDS=n runs the first n (a soak of 6000 is logged in profiles/r02/soak.txt)."""
     rng = np.random.default_rng(1000 + seed)
     kind = ["cornell", "sponza", "dragon", "hairball"][rng.integers(4)]
     tris = 0 if kind == "cornell" else int(rng.integers(300, 6000))
