@@ -10,8 +10,10 @@ i.e. million-node streams with the full LDS prefix and cold DFS tails, 8.3 M-pix
 face-test counters, pathtracing.cl:73-78) against the oracle, for every one of the six schedules; (b) size-independent
 properties: run-to-run identical, 1 + 2 == 3 frames, paths == W * H * frames, the debug image sums to the launch's
 counters; (c) 8-way tile shards re-assemble the unsharded frame; (d) a render long enough for two launch pairs equals
-the same frames rendered in one-frame launches.  Walk: pt_bvh.cl:82-123; kernel: pathtracing.cl:207-334."""
+the same frames rendered in one-frame launches; (e) 2^21 random rays through the walk over each full-size tree.
+Walk: pt_bvh.cl:82-123; kernel: pathtracing.cl:207-334."""
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pytest
@@ -230,3 +232,37 @@ def test_depth_of_field_at_full_size(pbr, oracle, device):
         assert same_values(got[band], ref.image[band]), "frame %d: %s" % (k, describe_mismatch(got[band], ref.image[band]))
         device.accumulate()
     assert np.isfinite(ref.image[band][..., 3]).any()
+
+
+@pytest.mark.parametrize("kind,seed,triangles", [("sponza", 2, 260000), ("dragon", 1, 870000), ("hairball", 3, 2000000)])
+def test_traversal_soak_on_the_large_scenes(pbr, oracle, gpu_device, kind, seed, triangles):
+    """2^21 random rays (origins in and around the scene, directions uniform, some axis-parallel and some with one
+    exactly-zero component: 1 / 0 in the slab test) through the walk over the full-size trees: distance, face, normal and
+    the node / face-test counts of every ray against the oracle's walk."""
+    from conftest import same_values, describe_mismatch
+    pbr.cfg_reset()
+    sc = pbr.HostScene.generate(kind, seed, triangles)
+    cfg = sc.config(64, 64)
+    v = sc.arrays()["vertices"][:, :3]
+    rng = np.random.default_rng(5)
+    n = 1 << 21
+    rays = np.concatenate([rng.uniform(v.min(0) - 0.3, v.max(0) + 0.3, (n, 3)), rng.normal(size=(n, 3))], axis=1).astype(np.float32)
+    k = np.arange(n // 16)
+    rays[k, 3 + k % 3] = 0.0                                                  # one exactly-zero component
+    rays[:, 3:] /= np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+    rays[7:16, 3:] = np.nan                                                   # and a few rays that are not rays at all
+    rays[:7, 3:] = [[1, 0, 0], [0, 1, 0], [0, 0, -1], [0, -1, 0], [1, 1, 0], [0, 0, 1], [-1, 0, 0]]
+    dev = pbr.Device(gpu_device)
+    dev.upload_scene(sc.desc)
+    t, face, normal, counts = dev.diag_trace(rays)
+    pieces = [(a, min(a + (1 << 15), n)) for a in range(0, n, 1 << 15)]
+    with ThreadPoolExecutor(min(64, os.cpu_count() or 8)) as pool:
+        parts = list(pool.map(lambda s: oracle.trace_rays(sc.desc, cfg, rays[s[0]:s[1]]), pieces))
+    ot, oface, onormal, ocounts = (np.concatenate([p[k] for p in parts]) for k in range(4))
+    assert same_values(t, ot), describe_mismatch(t, ot)
+    hit = np.isfinite(ot)
+    assert hit.sum() > n // 20
+    assert np.array_equal(face[hit], oface[hit]) and same_values(normal[hit], onormal[hit])
+    assert np.array_equal(counts, ocounts)
+    assert dev.guard_trips() == [0, 0, 0]
+    dev.close()
