@@ -109,3 +109,22 @@ def test_scene_validation_without_a_device(pbr):
     d = pbr.SceneDesc.from_buffer_copy(sc.desc)
     d.num_nodes = 1
     assert "root is never tested" in pbr.validate_scene(d)
+
+
+def test_entry_points_refuse_a_missing_context(pbr):
+    """Every entry point that takes a context returns an error for NULL (no crash, no fallback), the round-2 additions
+    included; pbr_bvh_node_capacity is context-free: 2 n - 1 records at most, 2 at least (a root above a single leaf)."""
+    hip = pbr.hip
+    null = ctypes.c_void_p()
+    cam, par = pbr.Camera(), pbr.DenoiseParams()
+    buf = (ctypes.c_float * 16)()
+    count = ctypes.c_uint32()
+    assert hip.pbr_denoise(null, 0.01, ctypes.byref(cam), ctypes.byref(par), buf, None) != 0
+    assert hip.pbr_build_bvh(null, None, 0, None, None, 0, None, ctypes.byref(count), None, None) != 0
+    assert hip.pbr_reset_accum(null) != 0 and hip.pbr_read_output(null, buf) != 0 and hip.pbr_read_full(null, buf) != 0
+    assert hip.pbr_render_frame(null, 0.5, 0.5, 0.01, ctypes.byref(cam)) != 0
+    assert hip.pbr_diag_pin_plan(null, 0) != 0
+    assert [hip.pbr_bvh_node_capacity(n) for n in (0, 1, 2, 3, 1000)] == [2, 2, 3, 5, 1999]
+    p = pbr.DenoiseParams()
+    assert (p.passes, round(p.sigma_color, 3), round(p.sigma_normal, 3), round(p.sigma_world, 3), round(p.sigma_albedo, 3)) == (5, 1.2, 0.25, 3.0, 0.1)
+    assert ctypes.sizeof(pbr.DenoiseParams) == 20
