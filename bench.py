@@ -16,7 +16,9 @@ BASELINE.json's metric and north_star are quoted on: configs[3], Sponza-class (2
 the K-step render is repeated (each repetition bracketed by barrier + synchronize, continuing the accumulation) and
 the MEDIAN repetition is reported — `repeats` and `ms_per_step_all` say so.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): 8x8-pixel tiles are dealt
+N > 1 (one rank per GPU; launched by torch.distributed.run — or by this script itself: `python bench.py --gpus N`
+without RANK / WORLD_SIZE in the environment starts its N ranks as child processes before anything touches a GPU, waits
+for them and forwards rank 0's line): 8x8-pixel tiles are dealt
 round-robin to the ranks (along a row-rotated order, tiles.py: a rank never gets whole tile columns), the scene is replicated, no collective on the
 data path; the timed region ends with one RCCL all-gather of the compact tile buffers
 (W*H*16/N bytes per rank) and the scatter into the full frame.  The total work is fixed, so
@@ -27,6 +29,8 @@ Prints ONE JSON line (rank 0).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,6 +41,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4 copy ~6290
+HBM_ACHIEVABLE_GBS = 6300.0
+L2_PEAK_GBS = 18000.0   # rows of an L2-resident table gathered by every workgroup: 16.8-18.8 TB/s (MI355X_MICROARCH.md)
+NUM_SIMDS = 1024        # 256 CUs x 4
 
 WORKLOADS = {
     # scene: (generator kind, seed, triangles, max_depth, BASELINE.json config it stands for)
@@ -68,11 +75,12 @@ def recorded_traffic(scene, w, h, depth, brdf):
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         try:
-            rec = json.load(open(path)).get(scene)
+            records = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if rec and (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) == (w, h, depth, brdf):
-            return dict(rec, source=os.path.relpath(path, ROOT))
+        for key, rec in records.items():      # keys: the scene, or scene_suffix for another size of it ("hairball_4k")
+            if rec.get("scene", key.split("_")[0]) == scene and (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) == (w, h, depth, brdf):
+                return dict(rec, source=os.path.relpath(path, ROOT))
     return None
 
 
@@ -104,6 +112,57 @@ def cpu_baseline(pbr, scene, cfg, cam, px, budget_s):
     }
 
 
+def elect_plan(votes):
+    """The schedule most ranks' tuners settled on (-1 = a rank that has not settled does not vote); ties go to the
+    plan the lowest rank voted for.  Every rank evaluates this on the same gathered list."""
+    valid = [v for v in votes if v >= 0]
+    if not valid:
+        return -1
+    return max(valid, key=lambda v: (valid.count(v), -valid.index(v)))
+
+
+def launch_ranks(n, argv, popen=subprocess.Popen, environ=None):
+    """`--gpus N` without a launcher: start the N ranks ourselves — N copies of this script with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, the rendezvous on 127.0.0.1 — and return the child processes.  Runs in
+    a parent that has not imported torch or the HIP library: a process that has initialised the GPU must neither fork
+    nor exec.  Rank 0 inherits stdout (its one JSON line is the run's output); the other ranks' stdout goes to stderr."""
+    environ = dict(os.environ if environ is None else environ)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's only working transport on this pool
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                           stdout=None if rank == 0 else sys.stderr))
+    return procs
+
+
+def wait_ranks(procs, poll_s=0.05):
+    """Wait for every rank; the first one that fails ends the others (their exact PIDs), and its code is the run's."""
+    code = 0
+    while any(p.poll() is None for p in procs):
+        failed = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if failed:
+            code = failed[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(poll_s)
+    for p in procs:
+        if p.returncode not in (0, None) and code == 0:
+            code = p.returncode
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,15 +179,18 @@ def main():
                     help="gloo + --one-device: rehearse the N > 1 path on a single GPU (tests); the gather then goes through host memory")
     ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
     ap.add_argument("--repeats", type=int, default=0, help="repetitions of the K-step render (0 = until 250 ms have been timed, at most 15); the median is reported")
+    ap.add_argument("--plan", type=int, default=int(os.environ.get("PBR_PLAN", "-1")),
+                    help="pin schedule 0..5 (refill-lean, refill-wide, phased-lean, phased-wide, phased-mid, refill-mid) instead of tuning; profiling runs")
     ap.add_argument("--dump", default="", help="rank 0 writes the gathered / rendered frame to this .npy")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes the parent of N ranks.  Nothing GPU-related has been imported yet.
+        sys.exit(wait_ranks(launch_ranks(args.gpus, sys.argv[1:])))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus %d needs a torch.distributed.run launch (one rank per GPU)" % args.gpus)
         args.gpus = world
 
     import pbr_loader
@@ -189,22 +251,29 @@ def main():
     # set-up, untimed and outside the W warm-up steps: the schedule tuner needs dev.tune_budget() frames of this scene +
     # configuration once (the counterpart of the reference's per-scene clBuildProgram), rendered in
     # calls of the length that will be timed, so that it settles on the plan that is fastest for THAT length.
-    # N > 1: rank 0 tunes on its share, its choice is broadcast and pinned on every rank — all ranks run one schedule.
-    forced = any(os.environ.get(k) for k in ("PBR_PLAN", "PBR_SCHEDULE", "PBR_VARIANT"))
+    # N > 1: every rank tunes on its own share AT THE SAME TIME (the set-up takes as long as on one GPU, whatever N),
+    # then the ranks vote — the plan most ranks settled on is pinned on all of them, so that all run one schedule and
+    # none is a straggler of the closing all-gather because its own timing noise picked another plan.
+    forced = args.plan >= 0
+    if forced:
+        dev.pin_plan(args.plan)
     setup_frames, t_setup = 0, time.perf_counter()
-    if not forced and (world == 1 or rank == 0):
-        budget = dev.tune_budget()                             # 108 frames at 1080p on one GPU, N x as many on a rank of N
+    if not forced:
+        budget = dev.tune_budget()                             # 108 frames at 1080p on one GPU, N x as many on a rank of N (1/N of the pixels each)
         while setup_frames < budget or dev.last_plan()[1] < 0:
             n = max(1, min(args.steps, 4 * budget - setup_frames))
             dev.render(setup_frames, pbr.frame_seeds(setup_frames, n), px, cam)
             setup_frames += n
             if setup_frames >= 4 * budget:
                 break
+    plan_votes = None
     if world > 1 and not forced:
-        choice = torch.tensor([dev.last_plan()[1] if rank == 0 else -1], dtype=torch.int32,
-                              device="cuda" if args.backend == "nccl" else "cpu")
-        dist.broadcast(choice, src=0)
-        dev.pin_plan(int(choice[0]))
+        where = "cuda" if args.backend == "nccl" else "cpu"
+        mine = torch.tensor([dev.last_plan()[1]], dtype=torch.int32, device=where)
+        votes = torch.zeros(world, dtype=torch.int32, device=where)
+        dist.all_gather_into_tensor(votes, mine)
+        plan_votes = [int(v) for v in votes.cpu()]
+        dev.pin_plan(elect_plan(plan_votes))
     t_setup = time.perf_counter() - t_setup
     dev.reset_accum()
 
@@ -270,30 +339,48 @@ def main():
         algo = algorithmic_bytes(counters, w * h * args.steps)
         # per launch of the dominant kernel (the path-tracing kernel the auto-tuner settled on): each rank runs
         # trace_launches of them per render; the slowest rank's average launch duration
-        achieved = algo / world / trace_launches / kernel_s / 1e9
+        algo_launch = algo / world / trace_launches          # SURVEY 8(d)'s per-sample figure x the samples one launch processes
         traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf))
+        # The roofline of the dominant kernel, physical: `achieved` = bytes the memory system moved behind L2 for one
+        # launch (fabric reads + writes from the committed PMC passes of this workload, Infinity-Cache hits included,
+        # scaled to this run's samples) / the launch's duration measured live (HIP events on the context's stream);
+        # `frac` = that / the HBM peak, <= 1 by construction.  The contract's algorithmic figure (every node visit priced
+        # at 32 B whether or not it left the CU) is `algorithmic_GBs`: it exceeds the peak on cache-resident scenes and
+        # ranks nothing.  `issue` and `l2` say what binds a scene whose working set lives in L2 / Infinity Cache.
         roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
             "kernel": "ptk::pathTracingPhased" if plan.startswith("phased") else "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
-            "algorithmic_bytes_per_launch": algo / world / trace_launches,
+            "algorithmic_bytes_per_launch": algo_launch, "algorithmic_GBs": algo_launch / kernel_s / 1e9,
             "bound_measured": MEASURED_BOUND.get(args.scene),
         }
         if traffic is not None:
-            # measured fabric traffic (reads + writes behind L2, Infinity-Cache hits included) of this workload, scaled to
-            # this run's samples; `measured` = that traffic / the launch time / the HBM peak — what the memory system
-            # actually moved, next to `frac`, which prices every node visit at 32 B whether or not it left the CU
-            per_launch = traffic["bytes_per_sample"] * samples / world / trace_launches
-            lines = traffic["fabric_read_bytes_per_launch"] / 128.0 * (samples / world / trace_launches) / (traffic["width"] * traffic["height"] * traffic["steps"])
+            per_launch_samples = samples / world / trace_launches
+            per_launch = traffic["bytes_per_sample"] * per_launch_samples
+            lines = traffic["fabric_read_bytes_per_launch"] / 128.0 * per_launch_samples / (traffic["width"] * traffic["height"] * traffic["steps"])
             roofline.update({
+                "achieved": per_launch / kernel_s / 1e9, "frac": per_launch / kernel_s / 1e9 / HBM_PEAK_GBS,
                 "traffic": per_launch,
                 "traffic_source": traffic["source"] + " (separate rocprofv3 --pmc passes of this workload with schedule %s, scaled to this run's samples)" % traffic["schedule"],
-                "measured": per_launch / kernel_s / 1e9 / HBM_PEAK_GBS,
-                "measured_GBs": per_launch / kernel_s / 1e9,
+                "achievable_frac": per_launch / kernel_s / 1e9 / HBM_ACHIEVABLE_GBS,
                 "gather_ceiling": lines / kernel_s / GATHER_CEILING_LINES,
                 "gather_ceiling_note": "128-B lines fetched per second / 56 G/s, this chip's rate of dependent random 32-B gathers beyond L2 (scripts/micro/gather_rate.hip)",
             })
+            sq = traffic.get("sq")
+            if sq:
+                # vector issue: wave-instructions x 2.4 cycles each (scripts/micro/valu_rate.hip) over the chip's 1024 SIMDs
+                # at 2.4 GHz = instructions / (1024 x 1e9 x t); useful lanes = thread-cycles / (64 x instructions)
+                scale = per_launch_samples / (traffic["width"] * traffic["height"] * traffic["steps"])
+                insts, threads = sq["SQ_INSTS_VALU"] * scale, sq["SQ_THREAD_CYCLES_VALU"] * scale
+                busy = insts / (NUM_SIMDS * 1e9 * kernel_s)
+                roofline["issue"] = {
+                    "valu_busy": busy, "lane_utilisation": threads / (64.0 * insts), "frac": busy * threads / (64.0 * insts),
+                    "wave_wait_fraction": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                    "note": "frac = share of the chip's vector lane-throughput doing useful work = SQ_THREAD_CYCLES_VALU x 2.4 cycles / (64 lanes x SIMD-cycles)",
+                }
+            if traffic.get("l2_requests_per_launch"):
+                req = traffic["l2_requests_per_launch"] * per_launch_samples / (traffic["width"] * traffic["height"] * traffic["steps"])
+                roofline["l2"] = {"request_GBs": req * 128.0 / kernel_s / 1e9, "peak": L2_PEAK_GBS, "frac": req * 128.0 / kernel_s / 1e9 / L2_PEAK_GBS,
+                                  "hit_rate": traffic.get("l2_hit_rate"), "note": "TCC_REQ x 128 B against the 17-19 TB/s the guide measures for L2-resident gathers"}
         out = {
             "metric": "Msamples/s (paths/s) @1080p fixed seed; 1/2/4/8 MI355X scaling",
             "value": samples / elapsed / 1e6,
@@ -326,6 +413,8 @@ def main():
         }
         if rank_ms is not None:
             out["per_rank_ms"] = rank_ms
+        if plan_votes is not None:
+            out["plan_votes"] = plan_votes
         if world == 1 and args.cpu_seconds > 0:
             cfg1 = scene.config(w, h)
             out["cpu_baseline"] = cpu_baseline(pbr, scene, cfg1, cam, px, args.cpu_seconds)

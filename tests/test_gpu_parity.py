@@ -898,10 +898,35 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
     j2 = json.loads(two.stdout.strip().splitlines()[-1])
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2
     assert j1["per_sample"] == j2["per_sample"]                     # same work, counted once
-    assert j2["roofline"]["frac"] > 0 and j2["value"] > 0
+    assert j2["roofline"]["algorithmic_GBs"] > 0 and j2["value"] > 0
     assert j1["repeats"] == j2["repeats"] == 2 and len(j2["per_rank_ms"]["render"]) == 2
-    assert j1["config"]["scene"] == "sponza" and j2["schedule_tuned"]     # rank 0's tuned plan, pinned on both ranks
+    assert j1["config"]["scene"] == "sponza" and j2["schedule_tuned"]     # the elected plan, pinned on both ranks
+    assert len(j2["plan_votes"]) == 2 and j2["schedule"] in [pbr_plan_name(v) for v in j2["plan_votes"]]
     assert same_values(np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy"))
+
+
+def pbr_plan_name(index):
+    return ("refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid")[index]
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """The driver's command shape: `python bench.py --gpus N ...` with no launcher around it.  bench.py must start its N
+    ranks itself (before anything touches the GPU in the parent) and print ONE line: here N = 2 on one GPU over gloo."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                          "--steps", "3", "--warmup", "1", "--width", "256", "--height", "144", "--cpu-seconds", "0", "--triangles", "20000",
+                          "--dump", str(tmp_path / "two.npy")],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1
+    assert len(j["per_rank_ms"]["render"]) == 2 and len(j["per_rank_ms"]["gather"]) == 2
+    assert j["value"] > 0 and j["scaling"] == "strong"
 
 
 # ----------------------------------------------------------------------------------------------

@@ -111,3 +111,68 @@ def test_dealing_order_spreads_every_rank_over_columns_and_rows(pbr, w, h, world
         assert cols.max() - cols.min() <= 2, (rank, cols.min(), cols.max())
         assert rows.max() - rows.min() <= 2, (rank, rows.min(), rows.max())
     assert (seen == 1).all()
+
+
+# ----------------------------------------------------------------------------------------------
+# bench.py --gpus N without a launcher: it starts its own ranks
+# ----------------------------------------------------------------------------------------------
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)          # importing bench.py imports neither torch nor the HIP library
+    return mod
+
+
+def test_bench_launches_one_rank_per_gpu_with_a_local_rendezvous():
+    bench = _bench_module()
+    started = []
+
+    class Fake:
+        def __init__(self, cmd, env=None, stdout=None):
+            started.append((cmd, env, stdout))
+
+    procs = bench.launch_ranks(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], popen=Fake, environ={"PATH": os.environ["PATH"]})
+    assert len(procs) == len(started) == 8
+    ports = set()
+    for rank, (cmd, env, stdout) in enumerate(started):
+        assert cmd[0] == sys.executable and cmd[1] == os.path.join(ROOT, "bench.py") and cmd[2:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"]) == (str(rank), str(rank), "8")
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        ports.add(env["MASTER_PORT"])
+        assert (stdout is None) == (rank == 0)          # only rank 0 writes to the run's stdout
+    assert len(ports) == 1 and 0 < int(ports.pop()) < 65536
+
+
+def test_bench_plan_election():
+    bench = _bench_module()
+    assert bench.elect_plan([4, 4, 5, 4, 5, 4, 4, 2]) == 4
+    assert bench.elect_plan([5, 4]) == 5                 # tie: the lowest rank's vote
+    assert bench.elect_plan([-1, 2, -1]) == 2            # ranks that have not settled do not vote
+    assert bench.elect_plan([-1, -1]) == -1
+
+
+def test_bench_first_failing_rank_ends_the_run():
+    import subprocess
+    bench = _bench_module()
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(60)"]),
+             subprocess.Popen([sys.executable, "-c", "import sys; sys.exit(7)"])]
+    assert bench.wait_ranks(procs) == 7
+    assert all(p.poll() is not None for p in procs)
+
+
+def test_bench_gpus_8_without_a_launcher_spawns_instead_of_refusing():
+    """`python bench.py --gpus 8` with no WORLD_SIZE must not stop at argument parsing (round 2 did: "needs a
+    torch.distributed.run launch").  Here there is no GPU, so the eight ranks it starts fail loudly at their first device call —
+    the product has no CPU fallback — and the parent reports that failure."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                          "--scene", "cornell", "--width", "64", "--height", "48", "--cpu-seconds", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run (covered by the gpu suite)")
+    assert "torch.distributed.run launch" not in run.stderr
+    # the ranks were started and refused to run without a device (torch.cuda.set_device or pbr_create, whichever comes first)
+    assert run.returncode != 0 and ("No HIP GPUs" in run.stderr or "PbrError" in run.stderr)
