@@ -21,9 +21,15 @@ _SRC = [os.path.join(_HERE, "pt_oracle.c"), os.path.join(_HERE, "pt_oracle.h")]
 def build(force=False):
     stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in _SRC)
     if stale:
-        subprocess.check_call([
-            "gcc", "-O2", "-std=c11", "-ffp-contract=off", "-mfma", "-mavx2", "-fopenmp", "-fPIC", "-shared",
-            "-o", _LIB, _SRC[0], "-lm"])
+        tmp = "%s.%d.tmp" % (_LIB, os.getpid())       # built aside and moved into place: never a half-written library under its name
+        try:
+            subprocess.check_call([
+                "gcc", "-O2", "-std=c11", "-ffp-contract=off", "-mfma", "-mavx2", "-fopenmp", "-fPIC", "-shared",
+                "-o", tmp, _SRC[0], "-lm"])
+            os.replace(tmp, _LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return _LIB
 
 

@@ -6,6 +6,8 @@
 Contraction is OFF everywhere (-ffp-contract=off): the path's arithmetic is defined
 operation by operation, and the HIP kernels must reproduce it bit for bit.
 """
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -54,8 +56,38 @@ def _stale(target, sources, flags=""):
 
 
 def _stamp(target, sources, flags=""):
-    with open(target + ".srchash", "w") as f:
+    tmp = "%s.srchash.%d.tmp" % (target, os.getpid())
+    with open(tmp, "w") as f:
         f.write(_digest(sources, flags) + "\n")
+    os.replace(tmp, target + ".srchash")
+
+
+@contextlib.contextmanager
+def _locked(target):
+    """One builder at a time per library: the ranks of a torchrun / mp.spawn job all import the package, all see the
+    same stale library after a source edit, and must not all run the compiler into the same file while others dlopen it.
+    The first rank builds (to a temporary name, moved into place atomically); the rest wait here, re-check and load."""
+    with open(target + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _have_compiler(name):
+    try:
+        return bool(_hipcc() if name == "hipcc" else shutil.which(name))
+    except RuntimeError:
+        return False
+
+
+def _keep_prebuilt(target, compiler):
+    """A library that is there, on a machine that cannot rebuild it (no compiler): load it as it is, and say so."""
+    if os.path.exists(target) and not _have_compiler(compiler):
+        sys.stderr.write("[pbr build] %s: no %s here — loading the prebuilt library without checking it against the sources\n" % (os.path.basename(target), compiler))
+        return True
+    return False
 
 
 def _run(cmd):
@@ -70,17 +102,30 @@ def build_hip(force=False, guard=False):
     sources = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
     sources += [os.path.join(INCLUDE, f) for f in ("pbr_hip.h", "pbr_hip_diag.h")]
     target = HIP_GUARD_LIB if guard else HIP_LIB
-    if not force and not _stale(target, sources):
+    if not force and (not _stale(target, sources) or _keep_prebuilt(target, "hipcc")):
         return target
+    with _locked(target):
+        if not force and not _stale(target, sources):     # another process built it while this one waited
+            return target
+        return _build_hip_locked(target, sources, guard)
+
+
+def _build_hip_locked(target, sources, guard):
+    tmp = "%s.%d.tmp" % (target, os.getpid())
     cmd = [
         _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
         # hipcc's SLP vectoriser packs adjacent scalar f32 operations into v_pk_* instructions, which issue at
         # half rate on gfx950 and need v_mov shuffles + hazard s_nops around them: same bits, 3-9 % slower kernels
         "-fno-slp-vectorize",
         "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC, *(["-DPBR_GUARD=1"] if guard else []),
-        "-o", target, os.path.join(CSRC, "pbr_hip.hip"),
+        "-o", tmp, os.path.join(CSRC, "pbr_hip.hip"),
     ]
-    _run(cmd)
+    try:
+        _run(cmd)
+        os.replace(tmp, target)         # a process that has the old file mapped keeps the old inode
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     _stamp(target, sources)
     return target
 
@@ -88,15 +133,28 @@ def build_hip(force=False, guard=False):
 def build_host(force=False):
     sources = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".cpp", ".h"))] + [os.path.join(INCLUDE, "pbr_hip.h")]
     build_hip()
-    if not force and not _stale(HOST_LIB, sources):
+    if not force and (not _stale(HOST_LIB, sources) or _keep_prebuilt(HOST_LIB, "g++")):
         return HOST_LIB
+    with _locked(HOST_LIB):
+        if not force and not _stale(HOST_LIB, sources):
+            return HOST_LIB
+        return _build_host_locked(sources)
+
+
+def _build_host_locked(sources):
+    tmp = "%s.%d.tmp" % (HOST_LIB, os.getpid())
     cmd = [
         "g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra",
         "-I", INCLUDE, "-I", HOST, "-I", "/opt/rocm/include",   # <CL/cl.h> for the cl_* types of host/cl_adaptor.h
         *[os.path.join(HOST, f) for f in HOST_SOURCES],
-        "-o", HOST_LIB, "-L", CSRC, "-lpbrhip", "-Wl,-rpath,$ORIGIN/../csrc",
+        "-o", tmp, "-L", CSRC, "-lpbrhip", "-Wl,-rpath,$ORIGIN/../csrc",
     ]
-    _run(cmd)
+    try:
+        _run(cmd)
+        os.replace(tmp, HOST_LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     _stamp(HOST_LIB, sources)
     return HOST_LIB
 

@@ -128,3 +128,24 @@ def test_entry_points_refuse_a_missing_context(pbr):
     p = pbr.DenoiseParams()
     assert (p.passes, round(p.sigma_color, 3), round(p.sigma_normal, 3), round(p.sigma_world, 3), round(p.sigma_albedo, 3)) == (5, 1.2, 0.25, 3.0, 0.1)
     assert ctypes.sizeof(pbr.DenoiseParams) == 20
+
+
+def test_concurrent_builders_never_publish_a_half_written_library(tmp_path):
+    """The ranks of a multi-process job all import the package and may all find a library stale: builds are serialised by
+    a file lock, written aside and moved into place, so every process loads a complete library."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes; sys.path.insert(0, %r)\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('pbr_build', %r)\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "lib = b.build_host(force=True)\n"
+        "ctypes.CDLL(lib, mode=ctypes.RTLD_GLOBAL).pbrh_cfg_reset()\n"
+        "print('loaded')\n" % (ROOT, os.path.join(ROOT, "physically-based-rendering_amd", "build.py")))
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(3)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and "loaded" in out, err[-2000:]
+    leftovers = [f for f in os.listdir(os.path.join(ROOT, "physically-based-rendering_amd", "host")) if f.endswith(".tmp")]
+    assert not leftovers
