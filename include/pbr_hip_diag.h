@@ -41,17 +41,23 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int lds_slots, const float* rays8, uint
  * records) so that rocprofv3's FETCH_SIZE / TCC_EA0_RDREQ_* can be interpreted. */
 int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t reads, double* ms_out );
 
-/* Which schedule rendered (the largest chunk of) the last render: "refill-lean", "refill-wide",
- * "phased-lean", "phased-wide", "tile-*", "batched"; *tuned = index of the schedule the auto-tuner
+/* Which schedule rendered (the largest chunk of) the last render: "refill-lean", "refill-wide", "phased-lean",
+ * "phased-wide", "phased-mid", "refill-mid" ("refill-wide-phong" with Phong tessellation); *tuned = index of the schedule the auto-tuner
  * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
 int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
 
-/* 1 if this build of the library also holds the three superseded schedules (PBR_SCHEDULE = tile | batched | wavefront;
- * -DPBR_LEGACY_SCHEDULES, lab builds), 0 for the product build: forcing one of them then fails with PBR_EINVAL. */
-int pbr_diag_has_legacy_schedules( void );
-
-/* 1 if this build also holds the pooled schedule (pt_pool.hpp; -DPBR_POOLED_SCHEDULE, lab builds): PBR_PLAN=6. */
-int pbr_diag_has_pooled_schedule( void );
+/* Experiment and test knobs, per context; value -1 = the built-in default.  The library reads NO environment variable:
+ * lab scripts and tests that need a knob set it here (the Python harness maps PBR_* variables onto this call).
+ *   "lds_slots"     cap of the node records a block stages in LDS (0 = none)
+ *   "blocks_per_cu" run below the resident maximum
+ *   "ph_park" / "ph_shade"  lane state machine thresholds; "park_eighths": the lock-step walk's park share
+ *   "drain_mode"    bit 0 / 1: scale ph_park / ph_shade with the lanes still at work once the queue is empty
+ *   "chunk_frames"  cap of the frames per launch pair of pbr_render (tests: several launch pairs)
+ *   "face_normals"  0 = recompute the face normal on every hit (takes effect at the next pbr_upload_scene)
+ *   "bvh_builder"   pbr_build_bvh: 0 clustering (default), 1 round 1's radix tree; "ploc_radius": its search radius
+ *   "tune_log"      1 = the schedule tuner logs its launches to stderr
+ * Setting a knob rebuilds the plans and restarts the schedule tuner. */
+int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value );
 
 /* Render with plan 0..5 (the order of pbr_diag_last_plan's *tuned: refill-lean, refill-wide, phased-lean, phased-wide,
  * phased-mid, refill-mid) from now on, without tuning; -1 hands the choice back to the tuner.  For the ranks of a
@@ -71,7 +77,7 @@ int pbr_diag_tune_budget( pbr_ctx* ctx, uint32_t* frames );
 int pbr_diag_last_trace( pbr_ctx* ctx, double* trace_ms, uint32_t* launches );
 
 /* All 16 device counter slots: [0..3] = pbr_counters; [4..15] are written only by experiment
- * builds (-DPBR_EXP_STATS: wave iterations / active lanes of the lock-step walk) and stay 0 otherwise. */
+ * builds (-DPBR_LAB_HOOKS, lab/src/pt_lab_hooks.hpp) and stay 0 otherwise. */
 int pbr_diag_raw_counters( pbr_ctx* ctx, uint64_t out[16] );
 
 /* Loop-bound trips recorded by a PBR_GUARD build ([0] tile loop, [1] path loop, [2] traversal);

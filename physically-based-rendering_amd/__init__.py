@@ -132,8 +132,8 @@ hip.pbr_diag_guard_trips.argtypes = [_vp, _up]
 hip.pbr_diag_last_trace.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
 hip.pbr_diag_last_plan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
 hip.pbr_diag_pin_plan.argtypes = [_vp, ctypes.c_int]
-hip.pbr_diag_has_legacy_schedules.argtypes = []
-hip.pbr_diag_has_pooled_schedule.argtypes = []
+if hasattr(hip, "pbr_diag_set_knob"):       # absent from round 2's library (A/B runs against it: PBR_HIP_LIB)
+    hip.pbr_diag_set_knob.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int]
 hip.pbr_diag_tune_budget.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint32)]
 
 host.pbrh_last_error.restype = ctypes.c_char_p
@@ -294,6 +294,15 @@ class HostScene:
 # Device context: the C ABI of include/pbr_hip.h
 # ----------------------------------------------------------------------------------------------
 
+# Lab scripts and A/B runs steer the library through environment variables; the LIBRARY reads none (include/pbr_hip_diag.h,
+# pbr_diag_set_knob) — this harness maps them onto knobs when a context is created.
+_ENV_KNOBS = {
+    "PBR_LDS_SLOTS": "lds_slots", "PBR_BLOCKS_PER_CU": "blocks_per_cu", "PBR_PH_PARK": "ph_park", "PBR_PH_SHADE": "ph_shade",
+    "PBR_PARK_EIGHTHS": "park_eighths", "PBR_DRAIN_MODE": "drain_mode",
+    "PBR_CHUNK_FRAMES": "chunk_frames", "PBR_FACE_NORMALS": "face_normals", "PBR_PLOC_RADIUS": "ploc_radius", "PBR_TUNE_LOG": "tune_log",
+}
+
+
 class Device:
     def __init__(self, device=0):
         self._ctx = _vp()
@@ -305,6 +314,17 @@ class Device:
                 self._ctx = None
             raise PbrError(msg)
         self.width = self.height = 0
+        for var, knob in _ENV_KNOBS.items():
+            if os.environ.get(var) and hasattr(hip, "pbr_diag_set_knob"):
+                self.set_knob(knob, int(os.environ[var]))
+        if os.environ.get("PBR_BVH_BUILDER"):
+            self.set_knob("bvh_builder", {"ploc": 0, "lbvh": 1}[os.environ["PBR_BVH_BUILDER"]])
+        if os.environ.get("PBR_PLAN"):
+            self.pin_plan(int(os.environ["PBR_PLAN"]))
+
+    def set_knob(self, name, value):
+        """pbr_diag_set_knob: experiment / test knobs of this context (include/pbr_hip_diag.h); -1 = the default."""
+        self._check(hip.pbr_diag_set_knob(self._ctx, name.encode(), int(value)))
 
     def close(self):
         if getattr(self, "_ctx", None):

@@ -15,26 +15,12 @@
 #include "pbr_hip.h"
 #include "pbr_hip_diag.h"
 #include "pt_kernel.hpp"
-// PBR_POOLED_SCHEDULE (lab builds only): the pooled schedule of pt_pool.hpp — the paths of a block in LDS, walker and
-// shader waves, queues drawn from by ballot + prefix sum.  Bit-identical, measured at 0.87 - 0.93x of the lane state
-// machine, so the product library does not carry it; PBR_PLAN=6 selects it where it is built.
-#if defined( PBR_POOLED_SCHEDULE ) && defined( PT_NODE_PHASE_ASM )
-#define PT_HAVE_POOLED 1
-#include "pt_pool.hpp"
-#endif
-// PBR_LEGACY_SCHEDULES (lab builds only, scripts/lab.sh): the three superseded schedules of DESIGN.md 5.1b — `tile`
-// (a wave walks whole tiles), `batched` (the flat lane state machine) and `wavefront` (pt_wavefront.hpp).  The tuner
-// never chose them; the product library holds the six plans it does choose from plus the Phong-tessellation variant.
-#ifdef PBR_LEGACY_SCHEDULES
-#include "pt_wavefront.hpp"
-#endif
+// The schedules that were measured and rejected in rounds 1 - 2 (tile, batched, wavefront, pooled: DESIGN.md 5.1b / 5.1d)
+// are no longer part of this source; their kernels are kept for the record under lab/src/.
 #include "bvh_build.hpp"
 #include "pt_denoise.hpp"
 
 using ptk::DevParams;
-#ifdef PBR_LEGACY_SCHEDULES
-using ptk::WfParams;
-#endif
 
 typedef void ( *KernelFn )( const ptk::DevParams );
 
@@ -44,13 +30,28 @@ typedef void ( *KernelFn )( const ptk::DevParams );
 struct Plan {
 	KernelFn kernel = nullptr;
 	int blocks = 0, blockThreads = 0, numHot = 0, park = 0, shade = 0, parkEighths = 4;
-	int poolShaders = 3, poolPatience = 8;   // pooled schedule only
 	size_t ldsBytes = 0;
 	const char* name = "";
 };
 
+// Experiment and test knobs (pbr_diag_set_knob, include/pbr_hip_diag.h): per context, -1 = the built-in value.  This
+// library reads no environment variable; lab scripts and tests set knobs through the diagnostic entry point.
+struct Knobs {
+	int ldsSlots = -1;      // cap of the node records staged in LDS per block (0 = none)
+	int blocksPerCU = -1;   // run below the resident maximum
+	int phPark = -1, phShade = -1;   // lane state machine: lanes that leave a node phase before it ends / that wait before a shade phase
+	int parkEighths = -1;   // lock-step walk: share of the lanes (in eighths) that leave a node phase before it ends
+	int drainMode = -1;     // lane state machine once lanes are DONE: bit 0 scale phPark, bit 1 scale phShade
+	int chunkFrames = -1;   // cap of the frames per launch pair (tests: force several launch pairs)
+	int faceNormals = -1;   // 0 = recompute the face normal on every hit instead of reading the stored one
+	int bvhBuilder = -1;    // pbr_build_bvh: 1 = round 1's radix tree instead of the clustering builder
+	int plocRadius = -1;    // pbr_build_bvh: search radius of the clustering builder
+	int tuneLog = -1;       // 1 = the schedule tuner logs its launches to stderr
+};
+
 struct pbr_ctx {
 	int device = -1;
+	Knobs knobs;
 	hipStream_t stream = nullptr;
 	hipEvent_t evStart = nullptr, evStop = nullptr, evTraceStart = nullptr, evTraceStop = nullptr;
 	std::string error;
@@ -86,8 +87,9 @@ struct pbr_ctx {
 	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
 	// frames that are rendered anyway, then the fastest one is kept
 	int tunedPlan = -1;
-	Plan plans[7];                                  // [0..5] the tuner's candidates, [6] the pooled schedule (pt_pool.hpp); valid while plansBuilt (reset by pbr_upload_scene / pbr_configure)
+	Plan plans[6];                                  // the tuner's candidates; valid while plansBuilt (reset by pbr_upload_scene / pbr_configure / pbr_diag_set_knob)
 	Plan phongPlan;                                 // the Phong-tessellation build of the refill kernel (takes the place of plans[1])
+
 	bool plansBuilt = false, phongPlanBuilt = false;
 	int drainMode = 1;                              // pathTracingPhased, see launch()
 	bool workClean = false;                         // the queue heads are zero (foldFrames leaves them so)
@@ -111,13 +113,6 @@ struct pbr_ctx {
 	unsigned long long* dCounters = nullptr;
 	unsigned int* dWork = nullptr;
 	unsigned int* dGuard = nullptr;
-
-	// wavefront schedule (pt_wavefront.hpp): per-pixel state, two ray queues, {count[2], head[2]}
-	float4* dWfState = nullptr;
-	unsigned int* dWfQueue[2] = { nullptr, nullptr };
-	unsigned int* dWfCtl = nullptr;
-	size_t wfPixels = 0;
-	unsigned int lastPasses = 0;
 };
 
 namespace {
@@ -157,19 +152,19 @@ void freeScene( pbr_ctx* ctx ) {
 	ctx->hasScene = false;
 }
 
-void freeWavefront( pbr_ctx* ctx ) {
-	(void) hipFree( ctx->dWfState );
-	(void) hipFree( ctx->dWfQueue[0] );
-	(void) hipFree( ctx->dWfQueue[1] );
-	(void) hipFree( ctx->dWfCtl );
-	ctx->dWfState = nullptr;
-	ctx->dWfQueue[0] = ctx->dWfQueue[1] = nullptr;
-	ctx->dWfCtl = nullptr;
-	ctx->wfPixels = 0;
+// The schedule tuner starts over (a new scene, a new configuration, a changed knob).
+void resetTuning( pbr_ctx* ctx ) {
+	ctx->tunedPlan = -1;
+	ctx->tuneRenderFrames = ctx->tunedAtFrames = 0;
+	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
+	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
+	std::memset( ctx->tuneLaunches, 0, sizeof( ctx->tuneLaunches ) );
+	ctx->refineCount = 0;
+	ctx->refineChunks = 0;
+	std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
 }
 
 void freeImages( pbr_ctx* ctx ) {
-	freeWavefront( ctx );
 	(void) hipFree( ctx->dImgIn );
 	(void) hipFree( ctx->dImgOut );
 	(void) hipFree( ctx->dImgDbg );
@@ -199,50 +194,26 @@ const size_t kCounterSlots = 16;
 
 // PBR_LAB (experiments only, scripts/lab.sh): instantiate just the variants the four bench scenes run,
 // so that an A/B build of the library takes seconds.  Never defined for the product build.
-template<bool REFILL, int MINW, bool PHONG = false>
+template<int MINW, bool PHONG = false>
 KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 #ifdef PBR_LAB
 	(void) brdf; (void) shadow; (void) lights;
-	return ptk::pathTracing<1, false, false, REFILL, MINW, PHONG>;
+	return ptk::pathTracing<1, false, false, MINW, PHONG>;
 #else
 	if( brdf == 0 ) {
 		if( lights ) {
-			return shadow ? ptk::pathTracing<0, true, true, REFILL, MINW, PHONG> : ptk::pathTracing<0, false, true, REFILL, MINW, PHONG>;
+			return shadow ? ptk::pathTracing<0, true, true, MINW, PHONG> : ptk::pathTracing<0, false, true, MINW, PHONG>;
 		}
-		return ptk::pathTracing<0, false, false, REFILL, MINW, PHONG>;
+		return ptk::pathTracing<0, false, false, MINW, PHONG>;
 	}
 
 	if( lights ) {
-		return shadow ? ptk::pathTracing<1, true, true, REFILL, MINW, PHONG> : ptk::pathTracing<1, false, true, REFILL, MINW, PHONG>;
+		return shadow ? ptk::pathTracing<1, true, true, MINW, PHONG> : ptk::pathTracing<1, false, true, MINW, PHONG>;
 	}
-	return ptk::pathTracing<1, false, false, REFILL, MINW, PHONG>;
+	return ptk::pathTracing<1, false, false, MINW, PHONG>;
 #endif
 }
 
-#ifdef PBR_LEGACY_SCHEDULES
-#ifndef PBR_BATCHED_MINW
-#define PBR_BATCHED_MINW 4
-#endif
-
-KernelFn pickKernelBatched( uint32_t brdf, bool shadow, bool lights ) {
-#ifdef PBR_LAB
-	return pickKernelMode<true, 8>( brdf, shadow, lights );
-#else
-	if( brdf == 0 ) {
-		if( lights ) {
-			return shadow ? ptk::pathTracingBatched<0, true, true, PBR_BATCHED_MINW> : ptk::pathTracingBatched<0, false, true, PBR_BATCHED_MINW>;
-		}
-		return ptk::pathTracingBatched<0, false, false, PBR_BATCHED_MINW>;
-	}
-
-	if( lights ) {
-		return shadow ? ptk::pathTracingBatched<1, true, true, PBR_BATCHED_MINW> : ptk::pathTracingBatched<1, false, true, PBR_BATCHED_MINW>;
-	}
-	return ptk::pathTracingBatched<1, false, false, PBR_BATCHED_MINW>;
-#endif
-}
-
-#endif   // PBR_LEGACY_SCHEDULES
 
 #ifndef PBR_LEAN_MINW
 #define PBR_LEAN_MINW 4
@@ -285,26 +256,6 @@ const int kMidMinWaves = PBR_MID_WAVES;
 #endif
 const int kMidBlockThreads = PBR_MID_THREADS;
 
-#ifdef PT_HAVE_POOLED
-KernelFn pickKernelPooled( uint32_t brdf, bool shadow, bool lights ) {
-#ifdef PBR_LAB
-	(void) brdf; (void) shadow; (void) lights;
-	return ptk::pathTracingPooled<1, false, false, PBR_MID_WAVES>;
-#else
-	if( brdf == 0 ) {
-		if( lights ) {
-			return shadow ? ptk::pathTracingPooled<0, true, true, PBR_MID_WAVES> : ptk::pathTracingPooled<0, false, true, PBR_MID_WAVES>;
-		}
-		return ptk::pathTracingPooled<0, false, false, PBR_MID_WAVES>;
-	}
-
-	if( lights ) {
-		return shadow ? ptk::pathTracingPooled<1, true, true, PBR_MID_WAVES> : ptk::pathTracingPooled<1, false, true, PBR_MID_WAVES>;
-	}
-	return ptk::pathTracingPooled<1, false, false, PBR_MID_WAVES>;
-#endif
-}
-#endif
 
 KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
 	return pickKernelPhasedMode<kMidMinWaves>( brdf, shadow, lights );
@@ -316,137 +267,21 @@ KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights );
 // not fit the staged LDS prefix get "wide" (pt_kernel.hpp), small scenes "lean".  Unforced renders are auto-tuned.
 const uint32_t kWideMinNodes = 2048;
 
+
 KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights ) {
-	return pickKernelMode<true, kMidMinWaves>( brdf, shadow, lights );
+	return pickKernelMode<kMidMinWaves>( brdf, shadow, lights );
 }
 
 // PHONGTESS == 1: the refill schedule in the wide budget only (the long cubic solve spills either way)
 KernelFn pickKernelPhong( uint32_t brdf, bool shadow, bool lights ) {
-	return pickKernelMode<true, PBR_WIDE_MINW, true>( brdf, shadow, lights );
+	return pickKernelMode<PBR_WIDE_MINW, true>( brdf, shadow, lights );
 }
 
 KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights, bool refill, bool wide ) {
-#ifdef PBR_LEGACY_SCHEDULES
-	if( !refill ) {
-		return wide ? pickKernelMode<false, PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelMode<false, PBR_LEAN_MINW>( brdf, shadow, lights );
-	}
-#endif
 	(void) refill;
-	return wide ? pickKernelMode<true, PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelMode<true, PBR_LEAN_MINW>( brdf, shadow, lights );
+	return wide ? pickKernelMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelMode<PBR_LEAN_MINW>( brdf, shadow, lights );
 }
 
-#ifdef PBR_LEGACY_SCHEDULES
-typedef void ( *WfKernelFn )( const DevParams, const WfParams );
-
-WfKernelFn pickWfShade( uint32_t brdf, bool shadow, bool lights ) {
-#ifdef PBR_LAB
-	(void) brdf; (void) shadow; (void) lights;
-	return ptk::wfShade<1, false, false>;
-#else
-	if( brdf == 0 ) {
-		if( lights ) {
-			return shadow ? ptk::wfShade<0, true, true> : ptk::wfShade<0, false, true>;
-		}
-		return ptk::wfShade<0, false, false>;
-	}
-
-	if( lights ) {
-		return shadow ? ptk::wfShade<1, true, true> : ptk::wfShade<1, false, true>;
-	}
-	return ptk::wfShade<1, false, false>;
-#endif
-}
-
-// The wavefront schedule of one fused launch: wfInit, then { wfTrace, wfShade } until no pixel has
-// a ray left, then wfReduce.  The host only reads the queue length back every few passes.
-int launchWavefront( pbr_ctx* ctx, DevParams P, bool shadow, bool lights ) {
-	const size_t pixels = (size_t) ctx->numLocalTiles * 64;
-
-	if( ctx->wfPixels != pixels ) {
-		freeWavefront( ctx );
-		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWfState, sizeof( float4 ) * ptk::WF_CHUNKS * pixels ) );
-		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWfQueue[0], sizeof( unsigned ) * pixels ) );
-		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWfQueue[1], sizeof( unsigned ) * pixels ) );
-		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dWfCtl, sizeof( unsigned ) * 4 ) );
-		ctx->wfPixels = pixels;
-	}
-
-	WfParams W;
-	W.state = ctx->dWfState;
-	W.stride = (unsigned) pixels;
-	W.queue[0] = ctx->dWfQueue[0];
-	W.queue[1] = ctx->dWfQueue[1];
-	W.count = ctx->dWfCtl;
-	W.head = ctx->dWfCtl + 2;
-	W.cur = 0;
-
-#ifdef PBR_LAB
-	const WfKernelFn trace = ptk::wfTrace<false>;
-#else
-	const WfKernelFn trace = lights ? ptk::wfTrace<true> : ptk::wfTrace<false>;
-#endif
-	const WfKernelFn shade = pickWfShade( ctx->cfg.brdf, shadow, lights );
-
-	// traversal: 2 blocks of 1024 threads per CU (8 waves / SIMD), each stages its share of the hot nodes
-	size_t slots = std::min<size_t>( ctx->numHotAvail, ( 80 * 1024 - 1024 ) / 32 );
-
-	if( const char* cap = std::getenv( "PBR_LDS_SLOTS" ) ) {
-		slots = std::min<size_t>( slots, (size_t) std::max( 0, std::atoi( cap ) ) );
-	}
-
-	P.numHot = (int) slots;
-	P.numHotBytes = (int) slots * 32;
-	const size_t ldsBytes = slots * 32;
-	HIP_TRY( ctx, hipFuncSetAttribute( (const void*) trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes ) );
-	const dim3 traceGrid( (unsigned) ctx->numCUs * 2 ), traceBlock( PBR_BLOCK );
-	const dim3 wideGrid( (unsigned) ctx->numCUs * 8 ), wideBlock( 256 );
-
-	DevParams Pshade = P;
-	Pshade.numHotBytes = 0;
-	Pshade.numHot = 0;   // shading kernels do not stage LDS (their shadow walks read nodes from memory)
-
-	const unsigned maxPasses = (unsigned) ( P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 2 );
-	unsigned passes = 0;
-	unsigned batch = 8;
-	unsigned remaining = (unsigned) pixels;
-
-	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
-	hipLaunchKernelGGL( ptk::wfInit, wideGrid, wideBlock, 0, ctx->stream, Pshade, W );
-	HIP_TRY( ctx, hipGetLastError() );
-
-	while( remaining != 0 && passes < maxPasses ) {
-		const unsigned todo = std::min( batch, maxPasses - passes );
-
-		for( unsigned b = 0; b < todo; b++ ) {
-			hipLaunchKernelGGL( trace, traceGrid, traceBlock, ldsBytes, ctx->stream, P, W );
-			hipLaunchKernelGGL( shade, wideGrid, wideBlock, 0, ctx->stream, Pshade, W );
-			W.cur ^= 1;
-		}
-
-		HIP_TRY( ctx, hipGetLastError() );
-		passes += todo;
-		HIP_TRY( ctx, hipMemcpyAsync( &remaining, ctx->dWfCtl + W.cur, sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream ) );
-		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
-		batch = 16;
-	}
-
-	if( remaining != 0 ) {
-		return fail( ctx, PBR_EDEVICE, "wavefront schedule did not drain after %u passes (%u rays left)", passes, remaining );
-	}
-
-	hipLaunchKernelGGL( ptk::wfReduce, wideGrid, wideBlock, 0, ctx->stream, Pshade, W );
-	HIP_TRY( ctx, hipGetLastError() );
-	HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
-	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
-
-	float ms = 0.0f;
-	HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
-	ctx->lastKernelMs = (double) ms;
-	ctx->lastPasses = passes;
-	return PBR_OK;
-}
-
-#endif   // PBR_LEGACY_SCHEDULES
 
 // {magic, shifts} with which ptk::divInvariant divides any 32-bit n by d exactly (d = 0 is never divided by: as 1)
 void invariantDivisor( unsigned d, unsigned out[2] ) {
@@ -602,27 +437,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	const bool lights = ( ctx->numLights > 0 );
 	const bool shadow = ( ctx->cfg.shadow_rays == 1 ) && lights;
-	// experiments / A-B measurements: PBR_SCHEDULE = tile | refill | batched | phased | wavefront, PBR_VARIANT = lean | wide
-	const char* force = std::getenv( "PBR_SCHEDULE" );
-	const char* variant = std::getenv( "PBR_VARIANT" );
-	auto forced = [&]( const char* name ) { return force != nullptr && std::strcmp( force, name ) == 0; };
-
+	const Knobs& knobs = ctx->knobs;
 	const bool phong = ( ctx->cfg.phong_tessellation > 0.0f );
 
-	if( phong && ( ctx->dTriPN == nullptr || forced( "tile" ) || forced( "phased" ) || forced( "batched" ) || forced( "wavefront" ) ) ) {
-		return fail( ctx, PBR_EINVAL, "Phong tessellation runs in the refill schedule only and needs a scene with usable vertex normals" );
+	if( phong && ctx->dTriPN == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "Phong tessellation needs a scene with usable vertex normals" );
 	}
-
-#ifdef PBR_LEGACY_SCHEDULES
-	if( forced( "wavefront" ) && !dof ) {
-		std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "wavefront" );
-		return launchWavefront( ctx, P, shadow, lights );
-	}
-#else
-	if( forced( "tile" ) || forced( "batched" ) || forced( "wavefront" ) ) {
-		return fail( ctx, PBR_EINVAL, "PBR_SCHEDULE=%s: the superseded schedules are not in the product library (build with -DPBR_LEGACY_SCHEDULES, scripts/lab.sh)", force );
-	}
-#endif
 
 	// A plan = kernel + persistent grid + LDS split.  Grid: as many blocks as stay resident, never more
 	// than there is work for.  LDS: each block stages a prefix of the node stream; the CU's 160 KB are
@@ -634,20 +454,23 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, blockThreads, 0 ) );
 		blocksPerCU = ( blocksPerCU < 1 ) ? 1 : blocksPerCU;
 
-		if( const char* cap = std::getenv( "PBR_BLOCKS_PER_CU" ) ) {   // experiments: run below the resident maximum
-			const int want = std::atoi( cap );
-			blocksPerCU = ( want >= 1 && want < blocksPerCU ) ? want : blocksPerCU;
+		if( knobs.blocksPerCU >= 1 && knobs.blocksPerCU < blocksPerCU ) {
+			blocksPerCU = knobs.blocksPerCU;
 		}
 
+		// a block's share of the CU's 160 KB, for the staged tree top
 		const size_t ldsPerCU = 160 * 1024;
-		size_t slots = ( ldsPerCU / (size_t) blocksPerCU - 256 ) / 32;
+		const size_t share = ldsPerCU / (size_t) blocksPerCU - 256;
+		size_t slots = share / 32;
 		slots = std::min<size_t>( slots, ctx->numHotAvail );
 
-		if( const char* cap = std::getenv( "PBR_LDS_SLOTS" ) ) {        // experiments: 0 = no LDS staging
-			slots = std::min<size_t>( slots, (size_t) std::max( 0, std::atoi( cap ) ) );
+		if( knobs.ldsSlots >= 0 ) {
+			slots = std::min<size_t>( slots, (size_t) knobs.ldsSlots );
 		}
 
-		HIP_TRY( ctx, hipFuncSetAttribute( (const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ( slots * 32 ) ) );
+		// the limit is a property of the kernel function, shared by every context of the process: always the block's whole
+		// share, so that a context with a small scene never lowers it under another context's cached plan
+		HIP_TRY( ctx, hipFuncSetAttribute( (const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) share ) );
 
 		plan->kernel = kernel;
 		plan->blockThreads = blockThreads;
@@ -658,14 +481,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		plan->shade = shade;
 		plan->parkEighths = ( ctx->numNodes >= kWideMinNodes ) ? 4 : 6;   // see traverse(), pt_kernel.hpp
 
-		if( const char* v = std::getenv( "PBR_PH_PARK" ) ) {    // experiments: phased thresholds
-			plan->park = std::max( 1, std::min( 64, std::atoi( v ) ) );
+		if( knobs.phPark >= 0 ) {
+			plan->park = std::max( 1, std::min( 64, knobs.phPark ) );
 		}
-		if( const char* v = std::getenv( "PBR_PH_SHADE" ) ) {
-			plan->shade = std::max( 1, std::min( 64, std::atoi( v ) ) );
+		if( knobs.phShade >= 0 ) {
+			plan->shade = std::max( 1, std::min( 64, knobs.phShade ) );
 		}
-		if( const char* share = std::getenv( "PBR_PARK_EIGHTHS" ) ) {   // experiments
-			plan->parkEighths = std::max( 0, std::min( 8, std::atoi( share ) ) );
+		if( knobs.parkEighths >= 0 ) {
+			plan->parkEighths = std::min( 8, knobs.parkEighths );
 		}
 
 		plan->name = name;
@@ -683,52 +506,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.numHotBytes = plan.numHot * 32;
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
-		P.poolShaders = plan.poolShaders;
-		P.poolPatience = plan.poolPatience;
 		P.drainMode = ctx->drainMode;   // 1: measured (single-frame 1080p launches): park share scaled, shade threshold as is: Dragon-class 2.99 -> 2.47 ms, hairball 4.26 -> 4.02 ms, Sponza- / Cornell-class unchanged; scaling the shade threshold too helps the first two further (2.26 / 3.56 ms) and costs the others 10 - 20 %
 		P.parkEighths = plan.parkEighths;
 		hipLaunchKernelGGL( plan.kernel, dim3( blocks ), dim3( (unsigned) plan.blockThreads ), plan.ldsBytes, ctx->stream, P );
 		HIP_TRY( ctx, hipGetLastError() );
+
 		return PBR_OK;
 	};
 
-#ifdef PBR_LEGACY_SCHEDULES
-	if( forced( "tile" ) ) {
-		// tile-synchronous schedule: a wave walks whole 8x8 tiles, the running mean stays in registers
-		bool wide = ( ctx->numNodes >= kWideMinNodes );
-
-		if( variant != nullptr ) {
-			wide = ( std::strcmp( variant, "wide" ) == 0 ) ? true : ( std::strcmp( variant, "lean" ) == 0 ) ? false : wide;
-		}
-
-		Plan plan;
-		const int status = makePlan( pickKernel( ctx->cfg.brdf, shadow, lights, false, wide ), wide ? "tile-wide" : "tile-lean", 0, 0, &plan );
-
-		if( status != PBR_OK ) {
-			return status;
-		}
-
-		HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
-
-		const int ran = run( plan, (size_t) ctx->numLocalTiles );
-
-		if( ran != PBR_OK ) {
-			return ran;
-		}
-
-		HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
-		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
-
-		float ms = 0.0f;
-		HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
-		ctx->lastKernelMs = (double) ms;
-		ctx->lastTraceMs = (double) ms;
-		ctx->lastTraceLaunches = 1;
-		std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "%s", plan.name );
-		return PBR_OK;
-	}
-
-#endif   // PBR_LEGACY_SCHEDULES
 
 	// Frame-parallel schedules: every (pixel, frame) is its own unit of work — the frames of a pixel are
 	// independent up to the running mean (pathtracing.cl:28,255,332) — so a launch ends with single
@@ -769,89 +554,29 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			return status;
 		}
 
-#ifdef PT_HAVE_POOLED
-		{
-			// the pooled schedule: 768-thread blocks, all of a block's LDS share is the path pool (no staged nodes)
-			Plan& pool = plans[6];
-			pool.kernel = pickKernelPooled( brdf, shadow, lights );
-			pool.blockThreads = kMidBlockThreads;
-			pool.numHot = 0;
-			pool.ldsBytes = ptk::poolLdsBytes( (unsigned) kMidBlockThreads );
-			pool.park = 32;           // lanes (of 64 that entered) that leave a walker's node phase before it ends
-			pool.shade = 0;
-			pool.poolShaders = 3;     // shader waves of 12
-			pool.poolPatience = 16;   // polls before a shader wave takes a partial batch
-			pool.parkEighths = 4;
-			pool.name = "pooled-mid";
-
-			if( const char* v = std::getenv( "PBR_POOL_SHADERS" ) ) {    // experiments
-				pool.poolShaders = std::max( 1, std::min( kMidBlockThreads / 64 - 1, std::atoi( v ) ) );
-			}
-			if( const char* v = std::getenv( "PBR_POOL_PATIENCE" ) ) {
-				pool.poolPatience = std::max( 0, std::atoi( v ) );
-			}
-			if( const char* v = std::getenv( "PBR_PH_PARK" ) ) {
-				pool.park = std::max( 1, std::min( 64, std::atoi( v ) ) );
-			}
-
-			HIP_TRY( ctx, hipFuncSetAttribute( (const void*) pool.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) pool.ldsBytes ) );
-			int blocksPerCU = 0;
-			HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) pool.kernel, pool.blockThreads, pool.ldsBytes ) );
-			pool.blocks = ctx->numCUs * std::max( 1, blocksPerCU );
-		}
-#endif
 
 		ctx->drainMode = 1;
 
-		if( const char* v = std::getenv( "PBR_DRAIN_MODE" ) ) {   // experiments
-			ctx->drainMode = std::atoi( v );
+		if( knobs.drainMode >= 0 ) {
+			ctx->drainMode = knobs.drainMode;
 		}
 
 		ctx->plansBuilt = true;
 		ctx->phongPlanBuilt = false;
 	}
 
-	Plan plans[kPlans + 1];
+	Plan plans[kPlans];
 
-	for( int k = 0; k <= kPlans; k++ ) {
+	for( int k = 0; k < kPlans; k++ ) {
 		plans[k] = ctx->plans[k];
 	}
 
 	auto screened = [&]( int plan ) { return ctx->tuneFrames[plan] >= kTuneFrames || ctx->tuneLaunches[plan] >= 2u; };
 
 	int forcedPlan = -1;
-	Plan batchedPlan;
-
-	if( force != nullptr || variant != nullptr ) {
-		bool wide = ( ctx->numNodes >= kWideMinNodes );
-
-		if( variant != nullptr ) {
-			wide = ( std::strcmp( variant, "wide" ) == 0 ) ? true : ( std::strcmp( variant, "lean" ) == 0 ) ? false : wide;
-		}
-
-		forcedPlan = forced( "phased" ) ? ( wide ? 3 : 2 ) : ( wide ? 1 : 0 );
-
-#ifdef PBR_LEGACY_SCHEDULES
-		if( forced( "batched" ) ) {
-			const int made = makePlan( pickKernelBatched( ctx->cfg.brdf, shadow, lights ), "batched", 0, 0, &batchedPlan );
-
-			if( made != PBR_OK ) {
-				return made;
-			}
-		}
-#endif
-	}
 
 	if( ctx->pinnedPlan >= 0 ) {
 		forcedPlan = std::min( kPlans - 1, ctx->pinnedPlan );
-	}
-
-	if( const char* plan = std::getenv( "PBR_PLAN" ) ) {   // experiments: 0..5 = the candidates above, 6 = the pooled schedule; no tuning
-		forcedPlan = std::max( 0, std::min( kPlans, std::atoi( plan ) ) );
-	}
-
-	if( forcedPlan == kPlans && ( plans[kPlans].kernel == nullptr || dof || phong || ctx->cfg.samples > 255u || ctx->cfg.max_depth + ctx->cfg.max_added_depth > 255u ) ) {
-		return fail( ctx, PBR_EINVAL, "the pooled schedule is not available for this build / configuration (depth of field, Phong tessellation, samples or depth above 255)" );
 	}
 
 	if( phong ) {
@@ -877,8 +602,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// the queue heads count pixel slots x frames of a band in 32 bits
 	chunkCap = std::min<size_t>( chunkCap, std::max<size_t>( 1, 0x7FFFFFFFull / ( pixelSlots + 64 * (size_t) P.queueWidth ) ) );
 
-	if( const char* cap = std::getenv( "PBR_CHUNK_FRAMES" ) ) {    // experiments / tests: force several launch pairs
-		chunkCap = std::min<size_t>( chunkCap, (size_t) std::max( 1, std::atoi( cap ) ) );
+	if( knobs.chunkFrames >= 1 ) {    // tests: force several launch pairs
+		chunkCap = std::min<size_t>( chunkCap, (size_t) knobs.chunkFrames );
 	}
 
 	if( ctx->frameBufFrames < chunkCap ) {
@@ -927,7 +652,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 			const double cost = ( a + b * frames ) / frames;
 
-			if( std::getenv( "PBR_TUNE_LOG" ) != nullptr ) {
+			if( knobs.tuneLog > 0 ) {
 				std::fprintf( stderr, "[pbr tune] fit %-12s a %.3f ms  b %.3f ms/frame  -> %.4f ms/frame at %u frames\n", plans[ctx->refinePlan[k]].name, a, b, cost, (unsigned) frames );
 			}
 
@@ -991,7 +716,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			}
 		}
 
-		const Plan& plan = forced( "batched" ) ? batchedPlan : plans[choice];
+		const Plan& plan = plans[choice];
 		uint32_t n = std::min<uint32_t>( (uint32_t) chunkCap, nFrames - done );
 
 		if( tuning ) {
@@ -1034,7 +759,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "%s", plan.name );
 		}
 
-		if( ( tuning || refining >= 0 ) && std::getenv( "PBR_TUNE_LOG" ) != nullptr ) {
+		if( ( tuning || refining >= 0 ) && knobs.tuneLog > 0 ) {
 			std::fprintf( stderr, "[pbr tune] %s %-12s %u frame(s) %.3f ms = %.3f ms/frame\n", tuning ? "screen" : "refine", plan.name, n, (double) ms, (double) ms / n );
 		}
 
@@ -1085,6 +810,10 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	ctx->lastKernelMs = (double) ms;
 	ctx->lastTraceMs = traceMs;
 	ctx->lastTraceLaunches = launches;
+
+	if( ( (const volatile unsigned*) ctx->dGuard )[1] != 0u ) {
+		return fail( ctx, PBR_EDEVICE, "a bounded device loop of the path-tracing kernel gave up (PBR_GUARD build; pbr_diag_guard_trips): the image is incomplete" );
+	}
 
 	if( ( (const volatile unsigned*) ctx->dGuard )[3] != 0u ) {
 		return fail( ctx, PBR_EDEVICE, "the staged node prefix does not start at LDS address 0 (pt_kernel.hpp, stageHotNodes): this build of the kernels cannot be trusted" );
@@ -1486,9 +1215,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 
 	// the face normals the shading would recompute on every hit, evaluated once by the shading's own device function
 	{
-		const char* off = std::getenv( "PBR_FACE_NORMALS" );   // experiments: 0 = recompute per hit
-
-		if( s->num_faces > 0 && !( off != nullptr && std::atoi( off ) == 0 ) ) {
+		if( s->num_faces > 0 && ctx->knobs.faceNormals != 0 ) {
 			HIP_TRY( ctx, hipMalloc( (void**) &ctx->dFaceN, sizeof( float4 ) * s->num_faces ) );
 			DevParams P;
 			std::memset( &P, 0, sizeof( P ) );
@@ -1507,15 +1234,8 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	ctx->numMaterials = s->num_materials;
 	ctx->numLights = s->num_lights;
 	ctx->sceneBrdf = s->brdf;
-	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
 	ctx->plansBuilt = false;
-	ctx->tuneRenderFrames = ctx->tunedAtFrames = 0;
-	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
-	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
-	std::memset( ctx->tuneLaunches, 0, sizeof( ctx->tuneLaunches ) );
-	ctx->refineCount = 0;
-	ctx->refineChunks = 0;
-	std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
+	resetTuning( ctx );   // a new scene / configuration is tuned afresh
 	ctx->hasScene = true;
 
 	return PBR_OK;
@@ -1565,15 +1285,8 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	HIP_TRY( ctx, hipMemset( ctx->dImgDbg, 0, fullBytes ) );
 	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * kCounterSlots ) );
 	HIP_TRY( ctx, hipDeviceSynchronize() );   // the memsets ran on the null stream; launches use ctx->stream
-	ctx->tunedPlan = -1;   // a new scene / configuration is tuned afresh
 	ctx->plansBuilt = false;
-	ctx->tuneRenderFrames = ctx->tunedAtFrames = 0;
-	std::memset( ctx->tuneMs, 0, sizeof( ctx->tuneMs ) );
-	std::memset( ctx->tuneFrames, 0, sizeof( ctx->tuneFrames ) );
-	std::memset( ctx->tuneLaunches, 0, sizeof( ctx->tuneLaunches ) );
-	ctx->refineCount = 0;
-	ctx->refineChunks = 0;
-	std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
+	resetTuning( ctx );   // a new scene / configuration is tuned afresh
 	ctx->configured = true;
 
 	return PBR_OK;
@@ -2024,8 +1737,8 @@ int buildClustered( pbr_ctx* ctx, const ptb::BuildArrays& A, uint32_t num_faces,
 
 	int radius = 32;   // 4 .. 64 measured: within 3 % of each other on the Sponza- / Dragon-class scenes, 32 the best on the hairball
 
-	if( const char* e = std::getenv( "PBR_PLOC_RADIUS" ) ) {
-		radius = std::atoi( e );
+	if( ctx->knobs.plocRadius >= 1 ) {
+		radius = ctx->knobs.plocRadius;
 	}
 
 	radius = std::min( std::max( radius, 1 ), PLOC_MAX_RADIUS );
@@ -2098,12 +1811,7 @@ int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertic
 		}
 	}
 
-	const char* which = std::getenv( "PBR_BVH_BUILDER" );
-	const bool radix = which != nullptr && std::strcmp( which, "lbvh" ) == 0;
-
-	if( which != nullptr && !radix && std::strcmp( which, "ploc" ) != 0 ) {
-		return fail( ctx, PBR_EINVAL, "build_bvh: PBR_BVH_BUILDER=%s (ploc or lbvh)", which );
-	}
+	const bool radix = ( ctx->knobs.bvhBuilder == 1 );   // round 1's radix tree; default: locally-ordered clustering
 
 	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
 	const uint32_t capacity = pbr_bvh_node_capacity( num_faces );
@@ -2415,20 +2123,31 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned ) 
 	return PBR_OK;
 }
 
-int pbr_diag_has_pooled_schedule( void ) {
-#ifdef PT_HAVE_POOLED
-	return 1;
-#else
-	return 0;
-#endif
-}
+int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value ) {
+	if( ctx == nullptr || name == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "diag_set_knob: null argument" );
+	}
 
-int pbr_diag_has_legacy_schedules( void ) {
-#ifdef PBR_LEGACY_SCHEDULES
-	return 1;
-#else
-	return 0;
-#endif
+	Knobs& k = ctx->knobs;
+	const struct { const char* name; int* slot; } table[] = {
+		{ "lds_slots", &k.ldsSlots }, { "blocks_per_cu", &k.blocksPerCU }, { "ph_park", &k.phPark }, { "ph_shade", &k.phShade },
+		{ "park_eighths", &k.parkEighths }, { "drain_mode", &k.drainMode },
+		{ "chunk_frames", &k.chunkFrames }, { "face_normals", &k.faceNormals }, { "bvh_builder", &k.bvhBuilder },
+		{ "ploc_radius", &k.plocRadius }, { "tune_log", &k.tuneLog },
+	};
+
+	for( const auto& entry : table ) {
+		if( std::strcmp( entry.name, name ) == 0 ) {
+			*entry.slot = value;
+			// plans carry the knobs' values: rebuild them, and let the tuner start over
+			ctx->plansBuilt = false;
+			ctx->phongPlanBuilt = false;
+			resetTuning( ctx );
+			return PBR_OK;
+		}
+	}
+
+	return fail( ctx, PBR_EINVAL, "diag_set_knob: unknown knob '%s'", name );
 }
 
 int pbr_diag_pin_plan( pbr_ctx* ctx, int plan ) {

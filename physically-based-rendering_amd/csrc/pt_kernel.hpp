@@ -25,9 +25,33 @@
 #include "pt_math.hpp"
 
 #ifdef PBR_GUARD
-#define PBR_GUARD_TILES 1
 #define PBR_GUARD_PATH 1
 #define PBR_GUARD_TRAV 1
+#endif
+
+// Measurement hooks.  The product build defines them empty; a lab build (-DPBR_LAB_HOOKS -I lab/src, scripts/lab.sh)
+// takes them from lab/src/pt_lab_hooks.hpp, where they record wave-level statistics into the spare counter slots
+// (lanes per node iteration, time per phase, when a wave first finds the queue empty ...).  They never change results.
+#ifdef PBR_LAB_HOOKS
+#include "pt_lab_hooks.hpp"
+#else
+#define PT_LAB_TRAVERSE_BEGIN
+#define PT_LAB_NODE_ITERATION
+#define PT_LAB_LEAF_PHASE
+#define PT_LAB_TRAVERSE_END( P, anyhit )
+#define PT_LAB_WAVE_BEGIN
+#define PT_LAB_WAVE_DRY
+#define PT_LAB_WAVE_END_LOCKSTEP( P )
+#define PT_LAB_WAVE_END_PHASED( P )
+#define PT_LAB_PHASED_BEGIN
+#define PT_LAB_PHASED_STAT( what )
+#define PT_LAB_PHASED_NODE_BEGIN( mode )
+#define PT_LAB_PHASED_NODE_MID
+#define PT_LAB_PHASED_LEAF_END
+#define PT_LAB_PHASED_NODE_END
+#define PT_LAB_PHASED_SHADE_BEGIN
+#define PT_LAB_PHASED_SHADE_END
+#define PT_LAB_PHASED_END( P )
 #endif
 
 namespace ptk {
@@ -101,7 +125,6 @@ struct DevParams {
 	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
 	float phongAlpha;            // PHONGTESS_ALPHA (kernels built with PHONG = true only)
 	int parkEighths;             // traverse(): a node phase ends once this many eighths of the lanes that entered it have left it
-	int poolShaders, poolPatience;   // pooled schedule (pt_pool.hpp, lab builds): shader waves per block; empty-handed polls before a shader wave takes a partial batch
 	int drainMode;               // phased schedule, once lanes are DONE: bit 0 scale phPark, bit 1 scale phShade with the lanes still at work
 	int phPark, phShade;         // phased schedule: lanes that leave a node phase before it ends / lanes that wait before a shade phase runs
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
@@ -780,7 +803,7 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 // loop, into its own lanes of the temporaries (registers are per lane) — whether at once or behind the next
 // iteration's node loads with s_waitcnt vmcnt(3): the 6 scalar + 3 vector + 3 memory instructions it adds to every
 // iteration cost more (Sponza-class -11 %, Dragon-class -8 %, hairball -13 %) than the one latency per leaf phase it hides.
-#if !defined( PBR_GUARD ) && !defined( PBR_EXP_STATS ) && !defined( PBR_NODE_PHASE_CXX )
+#if !defined( PBR_GUARD ) && !defined( PBR_NODE_PHASE_CXX )
 #define PT_NODE_PHASE_ASM 1
 
 template<bool ANYHIT>
@@ -898,9 +921,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 	const int numNodes = P.numNodes;
 	int guardSteps = 0;
 #endif
-#ifdef PBR_EXP_STATS
-	unsigned statIters = 0, statActive = 0, statLeafIters = 0, statLeafActive = 0;
-#endif
+	PT_LAB_TRAVERSE_BEGIN
 
 	if( LIGHTS ) {
 		traverseLights( P, ray, hit );
@@ -946,36 +967,13 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 				}
 #endif
 				visits++;
-#ifdef PBR_EXP_STATS   // lab only: wave-level iteration statistics
-				{
-					const unsigned long long act = __ballot( 1 );
-					if( (int) __lane_id() == __ffsll( (long long) act ) - 1 ) {
-						statIters++;
-						statActive += (unsigned) __popcll( act );
-					}
-				}
-#endif
+				PT_LAB_NODE_ITERATION
 
 				float4 n0, n1;
 				fetchNode<USE_LDS>( P, lds, cur, &n0, &n1 );
 				const int w0 = __float_as_int( n1.z );
 				const int w1 = __float_as_int( n1.w );
 				float tNear, tFar;
-#ifdef PBR_EXP_PAD_VALU   // sensitivity probes (scripts/lab.sh): extra work per node visit
-				{
-					float pad = n0.x;
-					for( int k = 0; k < PBR_EXP_PAD_VALU; k++ ) {
-						asm volatile( "v_add_f32 %0, %0, %0" : "+v"( pad ) );
-					}
-				}
-#endif
-#ifdef PBR_EXP_PAD_VMEM
-				for( int k = 0; k < PBR_EXP_PAD_VMEM; k++ ) {
-					const volatile float4* vg = (const volatile float4*) P.nodes;
-					const float x = vg[( cur.ref >> 4 ) + ( k & 1 )].x;
-					asm volatile( "" :: "v"( x ) );
-				}
-#endif
 
 				// hit container -> w0; miss, or leaf -> w1
 				const bool isHit = boxHit<ANYHIT>( n0, n1, ray, invDir, hit.t, &tNear, &tFar );
@@ -995,15 +993,7 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 
 		// ---- leaf phase: intersectFaces (pt_bvh.cl:10-46) for every parked lane
 		if( parked ) {
-#ifdef PBR_EXP_STATS
-			{
-				const unsigned long long act = __ballot( 1 );
-				if( (int) __lane_id() == __ffsll( (long long) act ) - 1 ) {
-					statLeafIters++;
-					statLeafActive += (unsigned) __popcll( act );
-				}
-			}
-#endif
+			PT_LAB_LEAF_PHASE
 			testLeaf<PHONG, EAGER>( P, leafFace0( leafWord ), leafFace1( leafWord ), ray, leafTNear, leafTFar, hit, faceTests );
 
 			if( ANYHIT && hit.t < tLight ) {
@@ -1019,29 +1009,8 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 	if( !ANYHIT ) {
 		nodeVisits += visits;
 	}
-#ifdef PBR_EXP_STATS
-	if( !ANYHIT ) {
-		atomicAdd( &P.counters[4], (unsigned long long) statIters );
-		atomicAdd( &P.counters[5], (unsigned long long) statActive );
-		atomicAdd( &P.counters[6], (unsigned long long) statLeafIters );
-		atomicAdd( &P.counters[7], (unsigned long long) statLeafActive );
-	}
-#endif
-}
 
-// Every block stages the hot nodes once (32 B x numHot, coalesced) before its waves start.
-PT_DEV void stageHotNodes( const DevParams& P, float4* lds ) {
-	// nodePhaseAsm reads the staged records at LDS address = record reference: the staged prefix must start at LDS address 0
-	// (it does: these kernels have no static __shared__ data).  Should a toolchain ever lay it out otherwise, say so loudly.
-	if( (unsigned) (size_t) lds != 0u && threadIdx.x == 0 && P.guard != nullptr ) {
-		P.guard[3] = 1u;
-	}
-
-	for( int i = (int) threadIdx.x; i < P.numHot * 2; i += (int) blockDim.x ) {
-		lds[i] = P.nodes[i];
-	}
-
-	__syncthreads();
+	PT_LAB_TRAVERSE_END( P, ANYHIT )
 }
 
 // Geometric normal of a face: fast_normalize( cross( edge1, edge2 ) ), pt_intersect.cl:122
@@ -1502,8 +1471,6 @@ PT_DEV unsigned waveSum( unsigned v ) {
 // Everything a lane carries for the pixel it is working on.
 struct PixelState {
 	unsigned slot;           // tile-major pixel slot: tile = slot >> 6, position in tile = slot & 63
-	f3 acc;                  // running mean over the frames done so far (imageIn -> imageOut)
-	float accW;
 	// frame
 	int frame, sample;
 	f3 finalColor;
@@ -1529,9 +1496,8 @@ PT_DEV void flushCounters( const DevParams& P, LaneCounters& c ) {
 	c.nodes = c.tris = c.hits = c.paths = 0;
 }
 
-// Take up pixel `slot`: load the accumulated value and start the first path of frame `frame`.
-// FP (frame-parallel): the unit of work is ONE frame of the pixel; its {finalColor, focus} go to
-// P.frameBuf and the running mean is folded afterwards, in frame order, by foldFrames.
+// Take up a unit of work — ONE frame of the pixel in `slot` — and start its first path.  The unit's {finalColor, focus}
+// go to P.frameBuf; the running mean is folded afterwards, in frame order, by foldFrames.
 // Image coordinates of a pixel slot of this rank: tileAtDealPosition with the divisions by tilesX as multiplications
 // (a 32-bit division is ~20 instructions).  Recomputed where a camera ray starts — once per path — rather than
 // kept in two registers for the whole path.
@@ -1578,19 +1544,8 @@ PT_DEV void focusInputs( const DevParams& P, unsigned slot, float* tFocus, float
 	}
 }
 
-template<bool FP = false>
-PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneCounters& cnt, unsigned frame = 0u ) {
+PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneCounters& cnt, unsigned frame ) {
 	st.slot = slot;
-
-	st.acc = mk3( 0.0f, 0.0f, 0.0f );
-	st.accW = 0.0f;
-
-	if( !FP ) {
-		const float4 prev = P.imgIn[slot];
-		st.acc = mk3( prev.x, prev.y, prev.z );
-		st.accW = prev.w;
-	}
-
 	st.frame = (int) frame;
 	st.sample = 0;
 	st.finalColor = mk3( 0.0f, 0.0f, 0.0f );
@@ -1611,26 +1566,19 @@ PT_DEV void beginPixel( const DevParams& P, PixelState& st, unsigned slot, LaneC
 	cnt.paths++;
 }
 
-// Store the finished pixel (all frames of this launch accumulated); FP: the finished frame went
-// to P.frameBuf in shadeStep, only the debug image is left to write (st.frame was advanced).
-template<bool FP = false>
+// The finished unit's frame went to P.frameBuf in shadeStep; only the debug image is left to write (st.frame was advanced).
 PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
-	if( !FP ) {
-		P.imgOut[st.slot] = make_float4( st.acc.x, st.acc.y, st.acc.z, st.accW );
-	}
-
 	// writeDebugImage, pathtracing.cl:73-78 (counters of the LAST frame of this launch)
-	if( P.imgDbg != nullptr && ( !FP || st.frame == P.nFrames ) ) {
+	if( P.imgDbg != nullptr && st.frame == P.nFrames ) {
 		P.imgDbg[st.slot] = make_float4( (float) st.dbgTris / 1082.0f, (float) st.dbgNodes / 1265.0f, 0.0f, 0.0f );
 	}
 }
 
 // Everything of one bounce that follows the closest-hit traversal (pathtracing.cl:261-333):
-// shade the hit, and — when the path / frame ends — fold it into the running mean and start the
-// next path.  Returns true when the pixel has had all P.nFrames frames; otherwise st.ray is the
-// next ray to trace.
+// shade the hit, and — when the path ends — start the next path of the frame, or store the finished frame.  Returns
+// true when the unit (one frame of one pixel) is finished; otherwise st.ray is the next ray to trace.
 // CALLS: pow as a function call instead of inline (pt_math.hpp, pow1Call) — every kernel but the lean lock-step one
-template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false, bool CALLS = !EAGER, bool FACEN = false>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool PHONG = false, bool EAGER = false, bool CALLS = !EAGER, bool FACEN = false>
 PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt, const Hit hit ) {
 	// references keep the shading code below in the reference's vocabulary
 	Ray& ray = st.ray;
@@ -1785,39 +1733,12 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 			finalColor = mk3( finalColor.x / ns, finalColor.y / ns, finalColor.z / ns );
 		}
 
-		if( FP ) {
-			// the unit ends here; foldFrames applies the running mean in frame order
-			P.frameBuf[frameBufIndex( P, st.slot, (unsigned) st.frame )] = make_float4( finalColor.x, finalColor.y, finalColor.z, st.focus );
-			cnt.nodes += st.dbgNodes;
-			cnt.tris += st.dbgTris;
-			st.frame++;
-			return true;
-		}
-
-		const unsigned n = (unsigned) ( P.firstCount + st.frame );
-		const float w = P.useExplicitWeight ? P.explicitWeight : ( (float) n / (float) ( n + 1u ) );
-		st.acc = mk3(
-			finalColor.x + ( st.acc.x - finalColor.x ) * w,
-			finalColor.y + ( st.acc.y - finalColor.y ) * w,
-			finalColor.z + ( st.acc.z - finalColor.z ) * w
-		);
-		st.accW = st.focus;
-
+		// the unit ends here; foldFrames applies the running mean (setColors) in frame order
+		P.frameBuf[frameBufIndex( P, st.slot, (unsigned) st.frame )] = make_float4( finalColor.x, finalColor.y, finalColor.z, st.focus );
 		cnt.nodes += st.dbgNodes;
 		cnt.tris += st.dbgTris;
 		st.frame++;
-
-		if( st.frame == P.nFrames ) {
-			return true;
-		}
-
-		st.sample = 0;
-		finalColor = mk3( 0.0f, 0.0f, 0.0f );
-		secondaryPaths = 1;
-		st.focus = 0.0f;
-		st.dbgNodes = 0;
-		st.dbgTris = 0;
-		seed = P.seeds[st.frame];
+		return true;
 	}
 
 	color = mk3( 1.0f, 1.0f, 1.0f );
@@ -1835,14 +1756,14 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 
 // One bounce of the lane's current path: traverse (pathtracing.cl:259), then shadeStep.
 // LEAF_EAGER: the closest-hit walk requests a leaf's second face before it tests the first (EAGER also steers the shading)
-template<int BRDF, bool SHADOW, bool LIGHTS, bool FP = false, bool PHONG = false, bool EAGER = false, bool LEAF_EAGER = EAGER>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool PHONG = false, bool EAGER = false, bool LEAF_EAGER = EAGER>
 PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt ) {
 	Hit hit;
 	hit.t = inff();
 	hit.face = 0;
 	hit.normal = mk3( 0.0f, 0.0f, 0.0f );
 	traverse<false, LIGHTS, true, PHONG, LEAF_EAGER>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
-	return shadeStep<BRDF, SHADOW, LIGHTS, FP, PHONG, EAGER, !EAGER, true>( P, lds, st, cnt, hit );
+	return shadeStep<BRDF, SHADOW, LIGHTS, PHONG, EAGER, !EAGER, true>( P, lds, st, cnt, hit );
 }
 
 // ---- the pixel-slot queue ----------------------------------------------------------------
@@ -1915,13 +1836,9 @@ PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, u
 		const unsigned qf = ( frames > 1u ) ? divInvariant( q, P.framesDiv[0], P.framesDiv[1] ) : q;
 		frame = q - qf * frames;
 		const unsigned tq = qf >> 6;
-#ifdef PBR_QUEUE_ROWMAJOR   // lab only: tiles of a band in row-major order
-		const unsigned tile = row0 * width + tq;
-#else
 		const unsigned col = divInvariant( tq, P.bandDiv[band * 2 + 0], P.bandDiv[band * 2 + 1] );
 		const unsigned row = tq - col * rows;
 		const unsigned tile = ( row0 + row ) * width + col;
-#endif
 
 		if( tile < tiles ) {
 			return tile * 64u + ( qf & 63u );
@@ -1931,24 +1848,21 @@ PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, u
 	return PT_NO_WORK;
 }
 
-// Work distribution: nextSlot() above.  EVERY lane draws its units with a plain per-lane atomicAdd( head, 1 );
-// hipcc folds the adds of the lanes that are active at that point into one wave-level add (v_mbcnt +
-// s_bcnt1 + a single global_atomic_add) and hands each lane base + its rank — the ballot / prefix-sum
-// refill, done by the compiler.  Lanes that fetch together get consecutive frames of one pixel (or, in a
-// single-frame launch, the pixels of one tile); correctness does not depend on it.
-//
-//   REFILL = true   frame-parallel: the unit is one frame of one pixel; a lane whose unit is finished takes the
-//                   next one at once while its neighbours keep tracing.  The default for every launch.
-//   REFILL = false  the tile schedule (PBR_SCHEDULE=tile): the lanes of a wave reconverge after each pixel, i.e.
-//                   a wave walks whole 8x8 tiles through all frames like an OpenCL work-group of the reference.
+// Work distribution: nextSlot() above.  EVERY lane draws its units — one frame of one pixel each — with a plain per-lane
+// atomicAdd( head, 1 ); hipcc folds the adds of the lanes that are active at that point into one wave-level add
+// (v_mbcnt + s_bcnt1 + a single global_atomic_add) and hands each lane base + its rank — the ballot / prefix-sum
+// refill, done by the compiler.  A lane whose unit is finished takes the next one at once while its neighbours keep
+// tracing.  Lanes that fetch together get consecutive frames of one pixel (or, in a single-frame launch, the pixels of
+// one tile); correctness does not depend on it.
 //
 // (A lane-0 atomic + readfirstlane + wave-uniform `break` formulation of this loop was
 // miscompiled by ROCm 7.2 hipcc into an endless re-run of tile 0 on gfx950 — DESIGN.md,
 // "Toolchain notes" — hence the deliberately per-lane control flow.)
-// Block = 1024 threads (16 waves): one or two blocks own a CU's 160 KB of LDS for the staged tree
+// Block = 1024 or 768 threads: one or two blocks own a CU's 160 KB of LDS for the staged tree
 // top.  MINW = waves per SIMD the register allocation must admit (__launch_bounds__):
 //   4  "lean"  <= 128 VGPRs, 1 block / CU — no spills; best when the kernel is bound by its own
-//              arithmetic (Cornell-class) and for the lane state machine on the largest scenes;
+//              arithmetic and for the lane state machine on the largest scenes;
+//   6  "mid"   <= 80 VGPRs, two 768-thread blocks / CU;
 //   8  "wide"  <= 64 VGPRs, 2 blocks / CU — the walk stays spill-free, the shading code spills to
 //              scratch; twice the waves to hide the latency of dependent node fetches.
 #ifndef PBR_BLOCK
@@ -1956,135 +1870,6 @@ PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, u
 #endif
 
 extern __shared__ float4 gHotNodes[];
-
-template<int BRDF, bool SHADOW, bool LIGHTS, bool REFILL, int MINW, bool PHONG = false>
-__global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParams P ) {
-	const float4* lds = gHotNodes;
-#ifdef PBR_EXP_TAIL   // lab only: how much of the launch do waves spend finished, waiting for the last one?
-	const unsigned long long tailStart = wall_clock64();
-#endif
-	stageHotNodes( P, gHotNodes );
-
-	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
-	(void) total;
-	LaneCounters cnt;
-	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
-	PixelState st;
-
-	WorkCursor work = beginWork();
-	unsigned frame = 0;
-	unsigned slot = nextSlot( P, work, REFILL ? (unsigned) P.nFrames : 1u, frame );
-
-	if( REFILL ) {
-		// frame-parallel: the unit of work is one frame of one pixel
-		bool have = ( slot != PT_NO_WORK );
-#ifdef PBR_GUARD_PATH
-		long long guardSteps = 0;
-		const long long guardMax = ( (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1 ) * ( (long long) total + 1 );
-#endif
-
-		if( have ) {
-			beginPixel<true>( P, st, slot, cnt, frame );
-		}
-
-		while( have ) {
-#ifdef PBR_GUARD_PATH
-			if( ++guardSteps > guardMax ) {
-				atomicAdd( &P.guard[1], 1u );
-				break;
-			}
-#endif
-			if( stepPixel<BRDF, SHADOW, LIGHTS, true, PHONG, ( MINW <= 4 ), ( MINW <= PT_EAGER_REFILL_UP_TO )>( P, lds, st, cnt ) ) {
-				finishPixel<true>( P, st );
-
-				if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
-					flushCounters( P, cnt );
-				}
-
-				slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
-				have = ( slot != PT_NO_WORK );
-
-				if( have ) {
-					beginPixel<true>( P, st, slot, cnt, frame );
-				}
-			}
-		}
-	}
-	else {
-#ifdef PBR_GUARD_TILES
-		int guardTiles = 0;
-#endif
-
-		while( slot != PT_NO_WORK ) {
-#ifdef PBR_GUARD_TILES
-			if( ++guardTiles > P.numLocalTiles + 1 ) {
-				atomicAdd( &P.guard[0], 1u );
-				break;
-			}
-#endif
-			beginPixel( P, st, slot, cnt );
-#ifdef PBR_GUARD_PATH
-			long long guardSteps = 0;
-			const long long guardMax = (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1;
-#endif
-
-			while( !stepPixel<BRDF, SHADOW, LIGHTS, false, PHONG, ( MINW <= 4 )>( P, lds, st, cnt ) ) {
-#ifdef PBR_GUARD_PATH
-				if( ++guardSteps > guardMax ) {
-					atomicAdd( &P.guard[1], 1u );
-					break;
-				}
-#endif
-			}
-
-			finishPixel( P, st );
-
-			if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
-				flushCounters( P, cnt );
-			}
-
-			slot = nextSlot( P, work, 1u, frame );
-		}
-	}
-
-	flushCounters( P, cnt );
-#ifdef PBR_EXP_TAIL
-	if( ( threadIdx.x & 63u ) == 0u ) {
-		const unsigned long long tailEnd = wall_clock64();
-		atomicAdd( &P.counters[12], tailEnd - tailStart );
-		atomicMax( &P.counters[13], tailEnd );
-		atomicMax( &P.counters[14], ~tailStart );
-		atomicAdd( &P.counters[15], 1ull );
-	}
-#endif
-}
-
-
-// ---------------------------------------------------------------------------------------
-// Batched schedule: the wave64 ballot scheme
-// ---------------------------------------------------------------------------------------
-// The schedules above keep the 64 lanes of a wave in lock step per bounce: every traversal lasts
-// as long as the wave's longest ray, and a leaf's triangle tests run while the lanes that stand
-// on container nodes idle (measured on the Sponza-class scene: ~28 % of the issued lane slots do
-// useful work).  Here every lane is a small state machine and ONE wave iteration advances each
-// lane by one node:
-//
-//   NODE   fetch the node, slab test, follow the hit / miss link (pt_bvh.cl:88-117)
-//   LEAF   the lane stands on a hit leaf; its (long) triangle tests are deferred ...
-//   SHADE  the lane's ray has left the tree; its (very long) shading step is deferred ...
-//   DONE   no pixel left
-//
-// ... until a ballot shows at least PBR_LEAF_BATCH (PBR_SHADE_BATCH) lanes waiting in that state,
-// or no lane of the wave can make progress otherwise.  Lanes that are shaded start their next ray —
-// or, when their pixel has had all its frames, take the next pixel slot — in the same iteration.
-// Per lane the sequence of node visits, face tests and random draws is exactly the reference's, so
-// the image stays bit-identical; only the interleaving across lanes changes.
-#ifndef PBR_LEAF_BATCH
-#define PBR_LEAF_BATCH 24
-#endif
-#ifndef PBR_SHADE_BATCH
-#define PBR_SHADE_BATCH 24
-#endif
 
 enum { MODE_NODE = 0, MODE_LEAF = 1, MODE_SHADE = 2, MODE_DONE = 3 };
 
@@ -2096,6 +1881,102 @@ struct WalkState {
 	float leafTNear;
 };
 
+// Every block stages the hot nodes once (32 B x numHot, coalesced) before its waves start.
+PT_DEV void stageHotNodes( const DevParams& P, float4* lds ) {
+	// nodePhaseAsm reads the staged records at LDS address = record reference: the staged prefix must start at LDS address 0
+	// (it does: these kernels have no static __shared__ data).  Should a toolchain ever lay it out otherwise, say so loudly.
+	if( (unsigned) (size_t) lds != 0u && threadIdx.x == 0 && P.guard != nullptr ) {
+		P.guard[3] = 1u;
+	}
+
+	for( int i = (int) threadIdx.x; i < P.numHot * 2; i += (int) blockDim.x ) {
+		lds[i] = P.nodes[i];
+	}
+
+	__syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// Lock-step schedule ("refill"): all lanes walk, then all shade
+// ---------------------------------------------------------------------------------------
+template<int BRDF, bool SHADOW, bool LIGHTS, int MINW, bool PHONG = false>
+__global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParams P ) {
+	const float4* lds = gHotNodes;
+	PT_LAB_WAVE_BEGIN
+	stageHotNodes( P, gHotNodes );
+
+	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
+	(void) total;
+	LaneCounters cnt;
+	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
+	PixelState st;
+
+	WorkCursor work = beginWork();
+	unsigned frame = 0;
+	unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
+	bool have = ( slot != PT_NO_WORK );
+#ifdef PBR_GUARD_PATH
+	long long guardSteps = 0;
+	const long long guardMax = ( (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1 ) * ( (long long) total + 1 );
+#endif
+
+	if( have ) {
+		beginPixel( P, st, slot, cnt, frame );
+	}
+
+	while( have ) {
+#ifdef PBR_GUARD_PATH
+		if( ++guardSteps > guardMax ) {
+			atomicAdd( &P.guard[1], 1u );
+			break;
+		}
+#endif
+		if( stepPixel<BRDF, SHADOW, LIGHTS, PHONG, ( MINW <= 4 ), ( MINW <= PT_EAGER_REFILL_UP_TO )>( P, lds, st, cnt ) ) {
+			finishPixel( P, st );
+
+			if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
+				flushCounters( P, cnt );
+			}
+
+			slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
+			have = ( slot != PT_NO_WORK );
+
+			if( have ) {
+				beginPixel( P, st, slot, cnt, frame );
+			}
+		}
+	}
+
+	flushCounters( P, cnt );
+	PT_LAB_WAVE_END_LOCKSTEP( P )
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Phased schedule: a lane state machine, run as nested phase loops
+// ---------------------------------------------------------------------------------------
+// The lock-step schedule keeps the 64 lanes of a wave in step per bounce: every traversal lasts
+// as long as the wave's longest ray, and a leaf's triangle tests run while the lanes that stand
+// on container nodes idle (measured on the Sponza-class scene: ~28 % of the issued lane slots do
+// useful work).  Here every lane is a small state machine
+//
+//   NODE   fetch the node, slab test, follow the hit / miss link (pt_bvh.cl:88-117)
+//   LEAF   the lane stands on a hit leaf; its (long) triangle tests are deferred ...
+//   SHADE  the lane's ray has left the tree; its (very long) shading step is deferred ...
+//   DONE   no unit of work left
+//
+// and the wave alternates between PHASES:
+//
+//   node phase   a tight loop over the lanes that are walking; a lane leaves it when it hits a
+//                leaf (-> LEAF) or its ray has left the tree (-> SHADE); the loop itself ends once
+//                P.phPark lanes have left it (or nobody is left)
+//   leaf phase   the triangle tests of every lane parked on a leaf, in one go
+//   shade phase  once P.phShade lanes wait for shading (or nothing else can run): shade them,
+//                start their next rays / take their next units
+//
+// The node loop carries only the walk state; the path state is untouched between shade phases.  Per lane the sequence
+// of node visits, face tests and random draws is exactly the reference's, so the image stays bit-identical; only the
+// interleaving across lanes changes.
 template<bool LIGHTS>
 PT_DEV int startWalk( const DevParams& P, const Ray& ray, WalkState& w ) {
 	w.invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
@@ -2114,166 +1995,30 @@ PT_DEV int startWalk( const DevParams& P, const Ray& ray, WalkState& w ) {
 }
 
 template<int BRDF, bool SHADOW, bool LIGHTS, int MINW>
-__global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingBatched( const DevParams P ) {
-	const float4* lds = gHotNodes;
-	stageHotNodes( P, gHotNodes );
-
-	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
-	(void) total;
-	const int numNodes = P.numNodes;
-	LaneCounters cnt;
-	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
-	PixelState st;
-	WalkState w;
-	int mode = MODE_DONE;
-
-	WorkCursor work = beginWork();
-	unsigned frame = 0;
-
-	{
-		const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
-
-		if( slot != PT_NO_WORK ) {
-			beginPixel<true>( P, st, slot, cnt, frame );
-			mode = startWalk<LIGHTS>( P, st.ray, w );
-		}
-	}
-
-#ifdef PBR_GUARD_PATH
-	long long guardSteps = 0;
-	const long long guardMax = ( (long long) P.nFrames * P.samples * ( P.maxDepth + P.maxAddedDepth + 1 ) + 1 ) * ( (long long) numNodes + 4 ) * ( (long long) total + 1 );
-#endif
-
-	while( mode != MODE_DONE ) {
-#ifdef PBR_GUARD_PATH
-		if( ++guardSteps > guardMax ) {
-			atomicAdd( &P.guard[1], 1u );
-			break;
-		}
-#endif
-		// ---- one node -------------------------------------------------------------------
-		if( mode == MODE_NODE ) {
-			st.dbgNodes++;
-
-			float4 n0, n1;
-			fetchNode<true>( P, lds, w.cur, &n0, &n1 );
-			const NodeLinks node = decodeNode( n1 );
-			float tNear;
-
-			if( boxHit<false>( n0, n1, st.ray, w.invDir, w.hit.t, &tNear ) ) {
-				w.cur = node.onHit;
-
-				if( node.leaf ) {
-					w.leafFace0 = node.face0;
-					w.leafFace1 = node.face1;
-					w.leafTNear = tNear;
-					mode = MODE_LEAF;
-				}
-			}
-			else {
-				w.cur = node.onMiss;
-			}
-
-			if( mode == MODE_NODE && !alive( w.cur ) ) {
-				mode = MODE_SHADE;
-			}
-		}
-
-		// ---- deferred triangle tests ------------------------------------------------------
-		{
-			const int nLeaf = __popcll( __ballot( mode == MODE_LEAF ) );
-			const int nNode = __popcll( __ballot( mode == MODE_NODE ) );
-
-			if( mode == MODE_LEAF && ( nLeaf >= PBR_LEAF_BATCH || nNode == 0 ) ) {
-				testLeaf( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
-				mode = alive( w.cur ) ? MODE_NODE : MODE_SHADE;
-			}
-		}
-
-		// ---- deferred shading ---------------------------------------------------------------
-		{
-			const int nShade = __popcll( __ballot( mode == MODE_SHADE ) );
-			const int nWalking = __popcll( __ballot( mode == MODE_NODE || mode == MODE_LEAF ) );
-
-			if( mode == MODE_SHADE && ( nShade >= PBR_SHADE_BATCH || nWalking == 0 ) ) {
-				if( shadeStep<BRDF, SHADOW, LIGHTS, true>( P, lds, st, cnt, w.hit ) ) {
-					finishPixel<true>( P, st );
-
-					if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
-						flushCounters( P, cnt );
-					}
-
-					const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
-
-					if( slot != PT_NO_WORK ) {
-						beginPixel<true>( P, st, slot, cnt, frame );
-						mode = startWalk<LIGHTS>( P, st.ray, w );
-					}
-					else {
-						mode = MODE_DONE;
-					}
-				}
-				else {
-					mode = startWalk<LIGHTS>( P, st.ray, w );
-				}
-			}
-		}
-	}
-
-	flushCounters( P, cnt );
-}
-
-
-// ---------------------------------------------------------------------------------------
-// Phased schedule: the batched idea as nested phase loops
-// ---------------------------------------------------------------------------------------
-// Same lane state machine as pathTracingBatched, but the wave alternates between PHASES instead of
-// re-evaluating every state in one flat loop:
-//
-//   node phase   a tight loop over the lanes that are walking; a lane leaves it when it hits a
-//                leaf (-> LEAF) or its ray has left the tree (-> SHADE); the loop itself ends once
-//                P.phPark lanes have left it (or nobody is left)
-//   leaf phase   the triangle tests of every lane parked on a leaf, in one go
-//   shade phase  once P.phShade lanes wait for shading (or nothing else can run): shade them,
-//                start their next rays / take their next pixels
-//
-// The node loop carries only the walk state; the path state is untouched between shade phases.
-template<int BRDF, bool SHADOW, bool LIGHTS, int MINW>
 __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const DevParams P ) {
 	const float4* lds = gHotNodes;
-#ifdef PBR_EXP_TAIL   // lab only: when does a wave start, when does it first find the queue empty, when does it end?
-	const unsigned long long tailStart = wall_clock64();
-	unsigned long long tailDry = 0ull;
-#endif
+	PT_LAB_WAVE_BEGIN
 	stageHotNodes( P, gHotNodes );
 
 	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
 	(void) total;
 	const int numNodes = P.numNodes;
+	(void) numNodes;
 	LaneCounters cnt;
 	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
 	PixelState st;
 	WalkState w;
 	int mode = MODE_DONE;
-#ifdef PBR_EXP_STATS
-	unsigned sNodeIt = 0, sNodeAct = 0, sLeafIt = 0, sLeafAct = 0, sShadeIt = 0, sShadeAct = 0, sOuter = 0, sNodePh = 0;
-#define PH_STAT( it, act ) { const unsigned long long m_ = __ballot( 1 ); if( (int) __lane_id() == __ffsll( (long long) m_ ) - 1 ) { it++; act += (unsigned) __popcll( m_ ); } }
-#else
-#define PH_STAT( it, act )
-#endif
+	PT_LAB_PHASED_BEGIN
 
 	WorkCursor work = beginWork();
 	unsigned frame = 0;
-#ifdef PBR_EXP_PHASE_TIME
-	unsigned long long phaseTime[3] = { 0ull, 0ull, 0ull };
-	const long long phaseStart = clock64();
-#endif
 
 	{
 		const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
 
 		if( slot != PT_NO_WORK ) {
-			beginPixel<true>( P, st, slot, cnt, frame );
+			beginPixel( P, st, slot, cnt, frame );
 			mode = startWalk<LIGHTS>( P, st.ray, w );
 		}
 	}
@@ -2292,29 +2037,29 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 #endif
 		// Once the queue has run dry the wave shrinks: lanes whose last unit is finished are DONE for good.  The two
 		// thresholds are meant as shares of the wave (16 and 40 of 64 lanes); held at their absolute values, a wave of 30
-		// surviving lanes ends a node phase only when 16 of them have left it.  Measured with -DPBR_EXP_TAIL
-		// (scripts/tail_profile.py): a wave needs 0.47 ms (Sponza-class) to 1.4 ms (Dragon-class, hairball) from its first
-		// empty queue to its end, against 0.2 ms for a whole path in the steady state.  P.drainMode chooses which of the
-		// two scale with the lanes still at work (bit 0: the park count, bit 1: the shade threshold).
+		// surviving lanes ends a node phase only when 16 of them have left it.  P.drainMode chooses which of the two scale
+		// with the lanes still at work (bit 0: the park count, bit 1: the shade threshold).
+		// How a launch ends, measured in round 3 (lab hook -DPBR_EXP_TIMELINE, profiles/r03/experiments/timeline.txt;
+		// Sponza-class scene, one 1080p frame): the queue is empty after ~1.0 ms with all 393 k lanes holding a path; 250 us
+		// later half of them are done, after another 250 us 93 % — and the launch runs ~0.7 ms more with 2 - 7 % of its lanes,
+		// one to four paths per wave: the paths with eight bounces and long walks, each bound by the latency of its own
+		// dependent node fetches.  Two ways of gathering those stragglers were built, tested bit-identical and measured
+		// slower (a ring in LDS between the waves of a block; a pool in global memory and a second kernel that walks each
+		// ray with a group of lanes: lab/src/pt_drain.hpp) — and any code behind this loop that touches the path
+		// state costs the loop itself registers: the 6-waves kernel lost 4 - 6 % of its steady state to both.
 		const int lanesAtWork = __popcll( __ballot( mode != MODE_DONE ) );
 		const int parkScaled = ( ( P.phPark * lanesAtWork ) >> 6 ) < 1 ? 1 : ( ( P.phPark * lanesAtWork ) >> 6 );
 		const int shadeScaled = ( ( P.phShade * lanesAtWork ) >> 6 ) < 1 ? 1 : ( ( P.phShade * lanesAtWork ) >> 6 );
 		const int parkNow = ( lanesAtWork >= 64 || !( P.drainMode & 1 ) ) ? P.phPark : parkScaled;
 		const int shadeNow = ( lanesAtWork >= 64 || !( P.drainMode & 2 ) ) ? P.phShade : shadeScaled;
 
-#ifdef PBR_EXP_PHASE_TIME   // lab only: where does a wave's time go?  (clock64 = the shader clock; taken where the wave is converged)
-		const unsigned long long maskNode = __ballot( mode == MODE_NODE );
-		const long long tNode0 = clock64();
-		long long leafDelta = 0;
-#endif
+		PT_LAB_PHASED_NODE_BEGIN( mode )
 		// ---- node phase ---------------------------------------------------------------------
 		if( mode == MODE_NODE ) {
 			const int keep = __popcll( __ballot( 1 ) ) - parkNow;
 			unsigned visits = 0;
+			PT_LAB_PHASED_STAT( 3 )
 
-#ifdef PBR_EXP_STATS
-			{ unsigned dummy = 0; PH_STAT( sNodePh, dummy ) }
-#endif
 #ifdef PT_NODE_PHASE_ASM
 			{
 				// the same hand-scheduled node phase as traverse()
@@ -2327,18 +2072,14 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );   // through the leaf phase below
 				nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
 				st.dbgNodes += visits;
-#ifdef PBR_EXP_PHASE_TIME
-				const long long tPhase1 = clock64();
-#endif
+				PT_LAB_PHASED_NODE_MID
 
 				// ---- leaf phase: only lanes that have just come out of the node phase can stand on a leaf
 				if( parkedFlag != 0 ) {
 					testLeaf<false, ( MINW <= PT_EAGER_UP_TO )>( P, leafFace0( leafWord ), leafFace1( leafWord ), st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
 				}
 				__builtin_amdgcn_s_setprio( 0 );
-#ifdef PBR_EXP_PHASE_TIME
-				leafDelta = clock64() - tPhase1;
-#endif
+				PT_LAB_PHASED_LEAF_END
 
 				if( !alive( w.cur ) ) {
 					mode = MODE_SHADE;
@@ -2347,7 +2088,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 #else
 			do {
 				visits++;
-				PH_STAT( sNodeIt, sNodeAct )
+				PT_LAB_PHASED_STAT( 0 )
 
 				float4 n0, n1;
 				fetchNode<true>( P, lds, w.cur, &n0, &n1 );
@@ -2377,19 +2118,11 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 #endif
 		}
 
-#ifdef PBR_EXP_PHASE_TIME
-		if( maskNode != 0ull ) {
-			const long long both = clock64() - tNode0;
-			const int src = __ffsll( (long long) maskNode ) - 1;
-			const long long leafU = ( (long long) __shfl( (int) ( leafDelta >> 32 ), src, 64 ) << 32 ) | (long long) (unsigned) __shfl( (int) leafDelta, src, 64 );
-			phaseTime[1] += (unsigned long long) leafU;
-			phaseTime[0] += (unsigned long long) ( both - leafU );
-		}
-#endif
+		PT_LAB_PHASED_NODE_END
 #ifndef PT_NODE_PHASE_ASM
 		// ---- leaf phase ---------------------------------------------------------------------
 		if( mode == MODE_LEAF ) {
-			PH_STAT( sLeafIt, sLeafAct )
+			PT_LAB_PHASED_STAT( 1 )
 			testLeaf<false, ( MINW <= 4 )>( P, w.leafFace0, w.leafFace1, st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
 			mode = alive( w.cur ) ? MODE_NODE : MODE_SHADE;
 		}
@@ -2405,13 +2138,11 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 			const int nShade = __popcll( __ballot( mode == MODE_SHADE ) );
 			const int nNode = __popcll( __ballot( mode == MODE_NODE ) );
 
-#ifdef PBR_EXP_PHASE_TIME
-			const long long tShade0 = clock64();
-#endif
+			PT_LAB_PHASED_SHADE_BEGIN
 			if( mode == MODE_SHADE && ( nShade >= shadeNow || nNode == 0 ) ) {
-				PH_STAT( sShadeIt, sShadeAct )
-				if( shadeStep<BRDF, SHADOW, LIGHTS, true, false, ( MINW <= 4 ), true>( P, lds, st, cnt, w.hit ) ) {
-					finishPixel<true>( P, st );
+				PT_LAB_PHASED_STAT( 2 )
+				if( shadeStep<BRDF, SHADOW, LIGHTS, false, ( MINW <= 4 ), true>( P, lds, st, cnt, w.hit ) ) {
+					finishPixel( P, st );
 
 					if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
 						flushCounters( P, cnt );
@@ -2420,69 +2151,25 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 					const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
 
 					if( slot != PT_NO_WORK ) {
-						beginPixel<true>( P, st, slot, cnt, frame );
+						beginPixel( P, st, slot, cnt, frame );
 						mode = startWalk<LIGHTS>( P, st.ray, w );
 					}
 					else {
 						mode = MODE_DONE;
-#ifdef PBR_EXP_TAIL
-						if( tailDry == 0ull ) {
-							tailDry = wall_clock64();
-						}
-#endif
+						PT_LAB_WAVE_DRY
 					}
 				}
 				else {
 					mode = startWalk<LIGHTS>( P, st.ray, w );
 				}
 			}
-#ifdef PBR_EXP_PHASE_TIME
-			phaseTime[2] += (unsigned long long) ( clock64() - tShade0 );
-#endif
+			PT_LAB_PHASED_SHADE_END
 		}
 	}
 
 	flushCounters( P, cnt );
-#ifdef PBR_EXP_PHASE_TIME
-	if( ( threadIdx.x & 63u ) == 0u ) {
-		atomicAdd( &P.counters[4], phaseTime[0] );                                    // node phases
-		atomicAdd( &P.counters[5], phaseTime[1] );                                    // leaf phases
-		atomicAdd( &P.counters[6], phaseTime[2] );                                    // shade checks + shading
-		atomicAdd( &P.counters[7], (unsigned long long) ( clock64() - phaseStart ) );  // the wave's whole life
-	}
-#endif
-#ifdef PBR_EXP_TAIL
-	{
-		// the first lane's view of the wave: start, first empty queue seen by any lane, end
-		unsigned long long dry = tailDry;
-
-		for( int off = 32; off > 0; off >>= 1 ) {
-			const unsigned long long other = ( (unsigned long long) __shfl_xor( (unsigned) ( dry >> 32 ), off, 64 ) << 32 ) | (unsigned long long) __shfl_xor( (unsigned) dry, off, 64 );
-			dry = ( dry == 0ull ) ? other : ( ( other != 0ull && other < dry ) ? other : dry );
-		}
-
-		if( ( threadIdx.x & 63u ) == 0u ) {
-			const unsigned long long tailEnd = wall_clock64();
-			atomicAdd( &P.counters[12], tailEnd - tailStart );
-			atomicMax( &P.counters[13], tailEnd );
-			atomicMax( &P.counters[14], ~tailStart );
-			atomicAdd( &P.counters[15], 1ull );
-			atomicAdd( &P.counters[4], ( dry != 0ull ) ? tailEnd - dry : 0ull );      // time spent draining, summed over the waves
-			atomicMax( &P.counters[5], ( dry != 0ull ) ? tailEnd - dry : 0ull );      // the longest drain
-			atomicMax( &P.counters[6], ~( ( dry != 0ull ) ? dry : tailEnd ) );        // the earliest "queue empty" of the launch
-			atomicMax( &P.counters[7], tailStart );                                    // the latest wave start
-		}
-	}
-#endif
-#ifdef PBR_EXP_STATS
-	atomicAdd( &P.counters[8], (unsigned long long) sNodeIt );
-	atomicAdd( &P.counters[9], (unsigned long long) sNodeAct );
-	atomicAdd( &P.counters[10], (unsigned long long) sLeafIt );
-	atomicAdd( &P.counters[11], (unsigned long long) sLeafAct );
-	atomicAdd( &P.counters[12], (unsigned long long) sShadeIt );
-	atomicAdd( &P.counters[13], (unsigned long long) sShadeAct );
-	atomicAdd( &P.counters[14], (unsigned long long) sNodePh );
-#endif
+	PT_LAB_PHASED_END( P )
+	PT_LAB_WAVE_END_PHASED( P )
 }
 
 
