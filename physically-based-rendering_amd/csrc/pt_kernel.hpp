@@ -178,9 +178,16 @@ struct Ray {
 	f3 origin, dir;
 };
 
+// The scalar half of a material.  Its two colours are read where the BRDF factor is formed (materialColours): held from
+// the start of the shading pass they were six registers live across both pow calls, and the 6-waves state machine
+// spilled three of them around every pass (round 2: 12 B of scratch per lane, one colour stored and reloaded per pass).
 struct Material {
 	float d, Ni, p2, p3;  // p2 = p | nu, p3 = rough | nv
 	float Rs, Rd;
+	const float4* colours;   // {Kd, Ks} of this material in P.mats
+};
+
+struct MaterialColours {
 	f3 Kd, Ks;
 };
 
@@ -238,14 +245,20 @@ PT_DEV f3 jitter( f3 nl, float phi, float sina, float cosa ) {
 PT_DEV Material loadMaterial( const DevParams& P, int index ) {
 	const float4 a = P.mats[index * 4 + 0];
 	const float4 b = P.mats[index * 4 + 1];
-	const float4 kd = P.mats[index * 4 + 2];
-	const float4 ks = P.mats[index * 4 + 3];
 	Material m;
 	m.d = a.x; m.Ni = a.y; m.p2 = a.z; m.p3 = a.w;
 	m.Rs = b.x; m.Rd = b.y;
-	m.Kd = mk3( kd.x, kd.y, kd.z );
-	m.Ks = mk3( ks.x, ks.y, ks.z );
+	m.colours = P.mats + index * 4 + 2;
 	return m;
+}
+
+PT_DEV MaterialColours materialColours( const Material& m ) {
+	const float4 kd = m.colours[0];
+	const float4 ks = m.colours[1];
+	MaterialColours c;
+	c.Kd = mk3( kd.x, kd.y, kd.z );
+	c.Ks = mk3( ks.x, ks.y, ks.z );
+	return c;
 }
 
 
@@ -1375,9 +1388,10 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const
 		brdf *= fmax1( dot( normal, inDir ), 0.0f );
 		brdf = brdf / pdf;
 
-		const f3 f4 = mk3( fresnel( u, mtl.Ks.x ), fresnel( u, mtl.Ks.y ), fresnel( u, mtl.Ks.z ) );
+		const MaterialColours mc = materialColours( mtl );
+		const f3 f4 = mk3( fresnel( u, mc.Ks.x ), fresnel( u, mc.Ks.y ), fresnel( u, mc.Ks.z ) );
 		const f3 k = mk3( f4.x * brdf * d + ( 1.0f - d ), f4.y * brdf * d + ( 1.0f - d ), f4.z * brdf * d + ( 1.0f - d ) );
-		return mtl.Kd * k;
+		return mc.Kd * k;
 	}
 
 	float spec, diff, dotHK1, pdf;
@@ -1386,8 +1400,9 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const
 	diff = diff / pdf;
 
 	const float fr = fresnel( dotHK1, mtl.Rs );
-	const f3 brdf_s = ( mtl.Ks * spec ) * fr;
-	const f3 brdf_d = ( mtl.Kd * diff ) * ( 1.0f - mtl.Rs );
+	const MaterialColours mc = materialColours( mtl );
+	const f3 brdf_s = ( mc.Ks * spec ) * fr;
+	const f3 brdf_d = ( mc.Kd * diff ) * ( 1.0f - mtl.Rs );
 	f3 bc = brdf_s + brdf_d;
 	bc = mk3( bc.x * d + ( 1.0f - d ), bc.y * d + ( 1.0f - d ), bc.z * d + ( 1.0f - d ) );
 	const float maxRGB = max_cl( 1.0f, max_cl( bc.x, max_cl( bc.y, bc.z ) ) );
@@ -1415,9 +1430,10 @@ PT_DEV bool shadowContribution(
 		brdf *= fmax1( dot( normal, lightDir ), 0.0f );
 		brdf = brdf / pdf;
 
-		const f3 f4 = mk3( fresnel( u, mtl.Ks.x ), fresnel( u, mtl.Ks.y ), fresnel( u, mtl.Ks.z ) );
+		const MaterialColours mc = materialColours( mtl );
+		const f3 f4 = mk3( fresnel( u, mc.Ks.x ), fresnel( u, mc.Ks.y ), fresnel( u, mc.Ks.z ) );
 		const f3 k = mk3( f4.x * brdf * d + ( 1.0f - d ), f4.y * brdf * d + ( 1.0f - d ), f4.z * brdf * d + ( 1.0f - d ) );
-		*add = ( ( color * lightRgb ) * mtl.Kd ) * k;
+		*add = ( ( color * lightRgb ) * mc.Kd ) * k;
 		return true;
 	}
 
@@ -1432,8 +1448,9 @@ PT_DEV bool shadowContribution(
 	diff = diff / pdf;
 
 	const float fr = fresnel( dotHK1, mtl.Rs );
-	const f3 brdf_s = ( mtl.Ks * spec ) * fr;
-	const f3 brdf_d = ( mtl.Kd * diff ) * ( 1.0f - mtl.Rs );
+	const MaterialColours mc = materialColours( mtl );
+	const f3 brdf_s = ( mc.Ks * spec ) * fr;
+	const f3 brdf_d = ( mc.Kd * diff ) * ( 1.0f - mtl.Rs );
 	f3 bc = brdf_s + brdf_d;
 	bc = mk3( bc.x * d + ( 1.0f - d ), bc.y * d + ( 1.0f - d ), bc.z * d + ( 1.0f - d ) );
 	const float maxRGB = max_cl( 1.0f, max_cl( bc.x, max_cl( bc.y, bc.z ) ) );
