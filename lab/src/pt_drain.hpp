@@ -280,3 +280,163 @@ __global__ __launch_bounds__( PT_DRAIN_BLOCK, 4 ) void pathDrain( const DevParam
 }
 
 
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Third attempt (round 3): the same cooperative walk INSIDE the wave — no pool, no second kernel, nothing waits.
+// Bit-identical (tests at the commit that removed it), steady state untouched (64-frame launch 64.39 ms either way), and
+// no faster where it was meant to help: single 1080p frame, Sponza-class 1.557 ms without, 1.60 / 1.61 ms with it from 8 /
+// 16 remaining paths per wave on; Dragon-class 2.41 -> 2.47 / 2.54 ms; an 8-way shard of 20 frames 3.08 -> 3.11 / 3.13 ms
+// (profiles/r03/experiments/cooperative_walk.txt).  The stragglers' visits are mostly to the ranked records at the head of
+// the stream, whose successors are explicit and not adjacent: nothing to fetch ahead, and six shuffles more per visit.
+//
+// ---- the cooperative node phase: the end of a launch ---------------------------------------------
+// How a launch ends, measured (lab hook -DPBR_EXP_TIMELINE, profiles/r03/experiments/timeline.txt; Sponza-class scene,
+// one 1080p frame): the queue is empty after ~1.0 ms with all 393 k lanes holding a path; 250 us later half of them are
+// done, after another 250 us 93 % — and the launch runs ~0.7 ms more with 2 - 7 % of its lanes, one to four paths per
+// wave: the paths with eight bounces and long walks, each bound by the latency of its own dependent node fetches, while
+// 60 lanes of its wave have nothing to do.  Moving such paths elsewhere does not shorten them (two ways were built,
+// bit-identical, and measured slower: lab/src/pt_drain.hpp).  Using the idle lanes does: once at most P.coopLanes lanes
+// of a wave still hold a path, every path gets a GROUP of PT_COOP_GROUP lanes for its node phases.  Lane j of the group
+// fetches and slab-tests the record 32 * j bytes behind the path's cursor — in the DFS-ordered part of the node stream a
+// hit container's successor is the adjacent record (58 % of all successors; the records of a group share a 128-byte
+// line) — and the group then follows the walk of pt_bvh.cl:88-117 through them for as long as each record is a hit
+// container whose hit successor is the next lane's record; the record at which that chain ends decides where the walk
+// goes on (its miss link, a far hit successor, a hit leaf to park on).  The closest hit so far cannot change between two
+// leaf tests, so each of those slab tests is the test the sequential walk would have made: node visits, face tests and
+// hits are the reference's; one round trip to memory covers up to PT_COOP_GROUP visits; records fetched ahead in vain
+// are not counted.  The path's state never leaves its lane (the owner): the group's lanes get the ray by shuffles.
+#ifndef PT_COOP_GROUP
+#define PT_COOP_GROUP 4
+#endif
+
+// liveMask: the lanes that hold a path (at most 64 / PT_COOP_GROUP of them); walkMask: those of them that are walking.
+// For an owner lane (a bit of walkMask): ref, visits, parked, leafWord, leafTNear are updated as by nodePhaseAsm.
+PT_DEV void coopNodePhase(
+	const DevParams& P, const float4* lds, unsigned long long liveMask, unsigned long long walkMask, const Ray& ownRay, const f3 ownInvDir,
+	float ownRayT, int keepGroups, int& ref, unsigned& visits, int& parked, int& leafWord, float& leafTNear
+) {
+	const int lane = (int) __lane_id();
+	const int sub = lane & ( PT_COOP_GROUP - 1 );
+	const int group = lane / PT_COOP_GROUP;
+	const int leader = lane & ~( PT_COOP_GROUP - 1 );
+
+	// the owner of group g: the g-th lane that holds a path
+	unsigned long long rest = liveMask;
+
+	for( int k = 0; k < group; k++ ) {
+		rest &= rest - 1ull;
+	}
+
+	const int owner = ( rest != 0ull ) ? __ffsll( (long long) rest ) - 1 : 0;
+	bool walking = ( rest != 0ull ) && ( ( walkMask >> owner ) & 1ull ) != 0ull;
+
+	Ray ray;
+	ray.origin = mk3( __shfl( ownRay.origin.x, owner, 64 ), __shfl( ownRay.origin.y, owner, 64 ), __shfl( ownRay.origin.z, owner, 64 ) );
+	ray.dir = mk3( 0.0f, 0.0f, 0.0f );   // the slab test reads 1 / direction only
+	const f3 invDir = mk3( __shfl( ownInvDir.x, owner, 64 ), __shfl( ownInvDir.y, owner, 64 ), __shfl( ownInvDir.z, owner, 64 ) );
+	const float rayT = __shfl( ownRayT, owner, 64 );
+	int gRef = __shfl( ref, owner, 64 );
+	unsigned gVisits = 0;
+	int gParked = 0, gWord = 0;
+	float gTNear = 0.0f;
+
+	for( ;; ) {
+		if( walking ) {
+			const int myRef = gRef + 32 * sub;
+			const bool fetchable = ( (unsigned) myRef < (unsigned) P.streamBytes );
+			int w0 = 0, w1 = -1;
+			float tNear = 0.0f;
+			bool isHit = false;
+
+			if( fetchable ) {
+				float4 n0, n1;
+				Cursor c;
+				c.ref = myRef;
+				fetchNode<true>( P, lds, c, &n0, &n1 );
+				w0 = __float_as_int( n1.z );
+				w1 = __float_as_int( n1.w );
+				isHit = boxHit<false>( n0, n1, ray, invDir, rayT, &tNear );
+			}
+
+			const bool isLeaf = ( w0 < 0 );
+			// does the walk go from this lane's record to the next lane's?
+			const bool link = fetchable && isHit && !isLeaf && ( w0 == myRef + 32 );
+			const unsigned links = (unsigned) ( __ballot( link ) >> leader ) & ( ( 1u << PT_COOP_GROUP ) - 1u );
+			int consumed = __builtin_ctz( ~links ) + 1;   // 1 + the links that hold from the first record on
+			consumed = ( consumed > PT_COOP_GROUP ) ? PT_COOP_GROUP : consumed;
+			const int last = leader + consumed - 1;       // the record at which the chain ends decides
+			const int nextRef = ( isHit && !isLeaf ) ? w0 : w1;
+			const int lastParks = __shfl( ( isHit && isLeaf ) ? 1 : 0, last, 64 );
+			const int lastWord = __shfl( w0, last, 64 );
+			const float lastTNear = __shfl( tNear, last, 64 );
+			gRef = __shfl( nextRef, last, 64 );
+			gVisits += (unsigned) consumed;
+
+			if( lastParks != 0 ) {
+				gParked = 1;
+				gWord = lastWord;
+				gTNear = lastTNear;
+			}
+
+			walking = ( gRef >= 0 ) && ( gParked == 0 );
+		}
+
+		if( __popcll( __ballot( walking && sub == 0 ) ) <= keepGroups ) {
+			break;
+		}
+	}
+
+	// back to the owners: owner lane o is served by the group of its rank among the lanes that hold a path
+	const int myGroup = __popcll( liveMask & ( ( 1ull << lane ) - 1ull ) );
+	const int from = myGroup * PT_COOP_GROUP;
+	const int backRef = __shfl( gRef, from, 64 );
+	const unsigned backVisits = (unsigned) __shfl( (int) gVisits, from, 64 );
+	const int backParked = __shfl( gParked, from, 64 );
+	const int backWord = __shfl( gWord, from, 64 );
+	const float backTNear = __shfl( gTNear, from, 64 );
+
+	if( ( ( walkMask >> lane ) & 1ull ) != 0ull ) {
+		ref = backRef;
+		visits += backVisits;
+		parked = backParked;
+		leafWord = backWord;
+		leafTNear = backTNear;
+	}
+}
+
+
+// ... and its place in pathTracingPhased, in front of the node phase:
+#if 0
+#ifdef PT_NODE_PHASE_ASM
+		// ---- the end of the launch: few paths left in this wave — its idle lanes help them walk (coopNodePhase)
+		if( __builtin_expect( lanesAtWork <= P.coopLanes, 0 ) ) {
+			const unsigned long long liveMask = __ballot( mode != MODE_DONE );
+			const unsigned long long walkMask = __ballot( mode == MODE_NODE );
+
+			if( walkMask != 0ull ) {
+				const int walkers = __popcll( walkMask );
+				const int leave = ( walkers * P.coopParkEighths ) >> 3;
+				unsigned visits = 0;
+				int leafWord = 0, parkedFlag = 0;
+				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );
+				coopNodePhase( P, lds, liveMask, walkMask, st.ray, w.invDir, w.hit.t, walkers - ( ( leave < 1 ) ? 1 : leave ), w.cur.ref, visits, parkedFlag, leafWord, w.leafTNear );
+
+				if( mode == MODE_NODE ) {
+					st.dbgNodes += visits;
+
+					if( parkedFlag != 0 ) {
+						testLeaf<false, ( MINW <= PT_EAGER_UP_TO )>( P, leafFace0( leafWord ), leafFace1( leafWord ), st.ray, w.leafTNear, 0.0f, w.hit, st.dbgTris );
+					}
+
+					if( !alive( w.cur ) ) {
+						mode = MODE_SHADE;
+					}
+				}
+
+				__builtin_amdgcn_s_setprio( 0 );
+			}
+		}
+		else
+#endif
+#endif

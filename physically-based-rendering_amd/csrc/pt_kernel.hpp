@@ -181,10 +181,12 @@ struct Ray {
 // The scalar half of a material.  Its two colours are read where the BRDF factor is formed (materialColours): held from
 // the start of the shading pass they were six registers live across both pow calls, and the 6-waves state machine
 // spilled three of them around every pass (round 2: 12 B of scratch per lane, one colour stored and reloaded per pass).
+// LATE = false (the lock-step kernels with 80 registers and more, which never spilled them): both at the start.
 struct Material {
 	float d, Ni, p2, p3;  // p2 = p | nu, p3 = rough | nv
 	float Rs, Rd;
-	const float4* colours;   // {Kd, Ks} of this material in P.mats
+	const float4* colours;   // {Kd, Ks} of this material in P.mats (LATE)
+	f3 Kd, Ks;               // (!LATE)
 };
 
 struct MaterialColours {
@@ -242,6 +244,7 @@ PT_DEV f3 jitter( f3 nl, float phi, float sina, float cosa ) {
 	return jitterUV( nl, u, v, phi, sina, cosa );
 }
 
+template<bool LATE = true>
 PT_DEV Material loadMaterial( const DevParams& P, int index ) {
 	const float4 a = P.mats[index * 4 + 0];
 	const float4 b = P.mats[index * 4 + 1];
@@ -249,15 +252,33 @@ PT_DEV Material loadMaterial( const DevParams& P, int index ) {
 	m.d = a.x; m.Ni = a.y; m.p2 = a.z; m.p3 = a.w;
 	m.Rs = b.x; m.Rd = b.y;
 	m.colours = P.mats + index * 4 + 2;
+	m.Kd = m.Ks = mk3( 0.0f, 0.0f, 0.0f );
+
+	if( !LATE ) {
+		const float4 kd = m.colours[0];
+		const float4 ks = m.colours[1];
+		m.Kd = mk3( kd.x, kd.y, kd.z );
+		m.Ks = mk3( ks.x, ks.y, ks.z );
+	}
+
 	return m;
 }
 
+template<bool LATE = true>
 PT_DEV MaterialColours materialColours( const Material& m ) {
-	const float4 kd = m.colours[0];
-	const float4 ks = m.colours[1];
 	MaterialColours c;
-	c.Kd = mk3( kd.x, kd.y, kd.z );
-	c.Ks = mk3( ks.x, ks.y, ks.z );
+
+	if( LATE ) {
+		const float4 kd = m.colours[0];
+		const float4 ks = m.colours[1];
+		c.Kd = mk3( kd.x, kd.y, kd.z );
+		c.Ks = mk3( ks.x, ks.y, ks.z );
+	}
+	else {
+		c.Kd = m.Kd;
+		c.Ks = m.Ks;
+	}
+
 	return c;
 }
 
@@ -1378,7 +1399,7 @@ PT_DEV f3 newRayDir( f3 dir, f3 normal, const Material& mtl, float& seed, bool& 
 }
 
 // The factor updateColor multiplies `color` by (pathtracing.cl:98-124 Schlick, :127-177 S-A).
-template<int BRDF, bool CALLS = false>
+template<int BRDF, bool CALLS = false, bool LATE = true>
 PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const TangentFrame* frame = nullptr ) {
 	const float d = mtl.d;
 
@@ -1388,7 +1409,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const
 		brdf *= fmax1( dot( normal, inDir ), 0.0f );
 		brdf = brdf / pdf;
 
-		const MaterialColours mc = materialColours( mtl );
+		const MaterialColours mc = materialColours<LATE>( mtl );
 		const f3 f4 = mk3( fresnel( u, mc.Ks.x ), fresnel( u, mc.Ks.y ), fresnel( u, mc.Ks.z ) );
 		const f3 k = mk3( f4.x * brdf * d + ( 1.0f - d ), f4.y * brdf * d + ( 1.0f - d ), f4.z * brdf * d + ( 1.0f - d ) );
 		return mc.Kd * k;
@@ -1400,7 +1421,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const
 	diff = diff / pdf;
 
 	const float fr = fresnel( dotHK1, mtl.Rs );
-	const MaterialColours mc = materialColours( mtl );
+	const MaterialColours mc = materialColours<LATE>( mtl );
 	const f3 brdf_s = ( mc.Ks * spec ) * fr;
 	const f3 brdf_d = ( mc.Kd * diff ) * ( 1.0f - mtl.Rs );
 	f3 bc = brdf_s + brdf_d;
@@ -1413,7 +1434,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const
 
 // The shadow-ray contribution to finalColor (pathtracing.cl:102-115 Schlick, :133-154 S-A).
 // Returns false when |pdf| <= 1e-5 (no contribution, secondaryPaths unchanged).
-template<int BRDF, bool CALLS = false>
+template<int BRDF, bool CALLS = false, bool LATE = true>
 PT_DEV bool shadowContribution(
 	const Material& mtl, f3 outDir, f3 lightDir, f3 normal, f3 color, f3 lightRgb, f3* add, const TangentFrame* frame = nullptr
 ) {
@@ -1430,7 +1451,7 @@ PT_DEV bool shadowContribution(
 		brdf *= fmax1( dot( normal, lightDir ), 0.0f );
 		brdf = brdf / pdf;
 
-		const MaterialColours mc = materialColours( mtl );
+		const MaterialColours mc = materialColours<LATE>( mtl );
 		const f3 f4 = mk3( fresnel( u, mc.Ks.x ), fresnel( u, mc.Ks.y ), fresnel( u, mc.Ks.z ) );
 		const f3 k = mk3( f4.x * brdf * d + ( 1.0f - d ), f4.y * brdf * d + ( 1.0f - d ), f4.z * brdf * d + ( 1.0f - d ) );
 		*add = ( ( color * lightRgb ) * mc.Kd ) * k;
@@ -1448,7 +1469,7 @@ PT_DEV bool shadowContribution(
 	diff = diff / pdf;
 
 	const float fr = fresnel( dotHK1, mtl.Rs );
-	const MaterialColours mc = materialColours( mtl );
+	const MaterialColours mc = materialColours<LATE>( mtl );
 	const f3 brdf_s = ( mc.Ks * spec ) * fr;
 	const f3 brdf_d = ( mc.Kd * diff ) * ( 1.0f - mtl.Rs );
 	f3 bc = brdf_s + brdf_d;
@@ -1595,7 +1616,8 @@ PT_DEV void finishPixel( const DevParams& P, const PixelState& st ) {
 // shade the hit, and — when the path ends — start the next path of the frame, or store the finished frame.  Returns
 // true when the unit (one frame of one pixel) is finished; otherwise st.ray is the next ray to trace.
 // CALLS: pow as a function call instead of inline (pt_math.hpp, pow1Call) — every kernel but the lean lock-step one
-template<int BRDF, bool SHADOW, bool LIGHTS, bool PHONG = false, bool EAGER = false, bool CALLS = !EAGER, bool FACEN = false>
+// LATE: the material's colours are read where they are used (Material, above)
+template<int BRDF, bool SHADOW, bool LIGHTS, bool PHONG = false, bool EAGER = false, bool CALLS = !EAGER, bool FACEN = false, bool LATE = true>
 PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt, const Hit hit ) {
 	// references keep the shading code below in the reference's vocabulary
 	Ray& ray = st.ray;
@@ -1632,7 +1654,7 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 			if( PHONG ) {
 				normal = hit.normal;   // ray.normal as intersectFace stored it (pt_bvh.cl:18): the Phong normal on curved faces
 			}
-			const Material mtl = loadMaterial( P, mtlIndex );
+			const Material mtl = loadMaterial<LATE>( P, mtlIndex );
 			totHits++;
 
 			// extendDepth, pt_utils.cl:89-96
@@ -1697,14 +1719,14 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 					if( lit ) {
 						f3 add;
 
-						if( shadowContribution<BRDF, CALLS>( mtl, ray.dir, lightDir, normal, color, lightRgb, &add, &frame ) ) {
+						if( shadowContribution<BRDF, CALLS, LATE>( mtl, ray.dir, lightDir, normal, color, lightRgb, &add, &frame ) ) {
 							finalColor = finalColor + add;
 							secondaryPaths += 1;
 						}
 					}
 				}
 
-				color = color * throughput<BRDF, CALLS>( mtl, ray.dir, newDir, normal, &frame );
+				color = color * throughput<BRDF, CALLS, LATE>( mtl, ray.dir, newDir, normal, &frame );
 
 				depthAdded += ( addDepth && depthAdded < P.maxAddedDepth ) ? 1 : 0;
 
@@ -1773,14 +1795,14 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 
 // One bounce of the lane's current path: traverse (pathtracing.cl:259), then shadeStep.
 // LEAF_EAGER: the closest-hit walk requests a leaf's second face before it tests the first (EAGER also steers the shading)
-template<int BRDF, bool SHADOW, bool LIGHTS, bool PHONG = false, bool EAGER = false, bool LEAF_EAGER = EAGER>
+template<int BRDF, bool SHADOW, bool LIGHTS, bool PHONG = false, bool EAGER = false, bool LEAF_EAGER = EAGER, bool LATE = true>
 PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, LaneCounters& cnt ) {
 	Hit hit;
 	hit.t = inff();
 	hit.face = 0;
 	hit.normal = mk3( 0.0f, 0.0f, 0.0f );
 	traverse<false, LIGHTS, true, PHONG, LEAF_EAGER>( P, lds, st.ray, hit, st.dbgNodes, st.dbgTris );
-	return shadeStep<BRDF, SHADOW, LIGHTS, PHONG, EAGER, !EAGER, true>( P, lds, st, cnt, hit );
+	return shadeStep<BRDF, SHADOW, LIGHTS, PHONG, EAGER, !EAGER, true, LATE>( P, lds, st, cnt, hit );
 }
 
 // ---- the pixel-slot queue ----------------------------------------------------------------
@@ -1948,7 +1970,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 			break;
 		}
 #endif
-		if( stepPixel<BRDF, SHADOW, LIGHTS, PHONG, ( MINW <= 4 ), ( MINW <= PT_EAGER_REFILL_UP_TO )>( P, lds, st, cnt ) ) {
+		if( stepPixel<BRDF, SHADOW, LIGHTS, PHONG, ( MINW <= 4 ), ( MINW <= PT_EAGER_REFILL_UP_TO ), ( MINW > 6 )>( P, lds, st, cnt ) ) {
 			finishPixel( P, st );
 
 			if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
@@ -2060,10 +2082,10 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 		// Sponza-class scene, one 1080p frame): the queue is empty after ~1.0 ms with all 393 k lanes holding a path; 250 us
 		// later half of them are done, after another 250 us 93 % — and the launch runs ~0.7 ms more with 2 - 7 % of its lanes,
 		// one to four paths per wave: the paths with eight bounces and long walks, each bound by the latency of its own
-		// dependent node fetches.  Two ways of gathering those stragglers were built, tested bit-identical and measured
-		// slower (a ring in LDS between the waves of a block; a pool in global memory and a second kernel that walks each
-		// ray with a group of lanes: lab/src/pt_drain.hpp) — and any code behind this loop that touches the path
-		// state costs the loop itself registers: the 6-waves kernel lost 4 - 6 % of its steady state to both.
+		// dependent node fetches (a record's successors are in the record).  Three ways of helping those stragglers were
+		// built, tested bit-identical and measured no faster (lab/src/pt_drain.hpp, DESIGN.md "How a launch ends"): a ring
+		// in LDS that repacks them into fewer waves, a pool in global memory with a second kernel, and the wave's own
+		// idle lanes fetching and testing the adjacent records of the stream ahead of the walk.
 		const int lanesAtWork = __popcll( __ballot( mode != MODE_DONE ) );
 		const int parkScaled = ( ( P.phPark * lanesAtWork ) >> 6 ) < 1 ? 1 : ( ( P.phPark * lanesAtWork ) >> 6 );
 		const int shadeScaled = ( ( P.phShade * lanesAtWork ) >> 6 ) < 1 ? 1 : ( ( P.phShade * lanesAtWork ) >> 6 );
@@ -2158,6 +2180,8 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 			PT_LAB_PHASED_SHADE_BEGIN
 			if( mode == MODE_SHADE && ( nShade >= shadeNow || nNode == 0 ) ) {
 				PT_LAB_PHASED_STAT( 2 )
+				// (stored face normals, FACEN, re-measured in round 3 with the registers the late colours freed: the 6-waves
+				// kernel spills again, Sponza-class -2.7 %, Dragon-class -1.9 % — profiles/r03/experiments/facen_state_machine.txt)
 				if( shadeStep<BRDF, SHADOW, LIGHTS, false, ( MINW <= 4 ), true>( P, lds, st, cnt, w.hit ) ) {
 					finishPixel( P, st );
 

@@ -46,7 +46,7 @@ def collect(out, loads):
             if per:
                 timed = per[max(per)]          # the last pathTracing dispatch is the timed launch
                 for k, v in timed.items():
-                    pmc[k if k != "_ns" else "duration_ns(" + "+".join(c for c in timed if c != "_ns")[:40] + ")"] = v
+                    pmc[k if k != "_ns" else "duration_ns(" + "+".join(sorted(c for c in timed if c != "_ns"))[:40] + ")"] = v
                 rec["dispatch_metadata_as_rocprofv3_reports_it"] = meta[max(per)]
         rec["pmc_timed_launch"] = pmc
         if "TCC_EA0_RDREQ_128B_sum" in pmc:
@@ -96,7 +96,7 @@ def assemble(src, round_name):
         calls = int(ks[0]["Calls"]) if ks else 0
         r["timed_launch_agreement"] = {"rocprof_timed_launch_ms": dur, "bench_launch_ms_same_run": u["roofline"]["launch_ms"], "kernel": last["Kernel_Name"][:60],
                                        "rocprof_stats_average_ms": avg, "rocprof_stats_calls": calls}
-        ns = [v for k, v in p.items() if k.startswith("duration_ns(SQ_WAVE")][0]
+        ns = [v for k, v in p.items() if k.startswith("duration_ns(") and "SQ_INSTS_VALU" in "".join(c for c in p if not c.startswith("duration")) and k.startswith("duration_ns(SQ_ACTIVE_INST_VALU")][0]
         busy = p["SQ_INSTS_VALU"] / (1024 * 1e9 * ns * 1e-9)          # wave-instructions x 2.4 cycles over 1024 SIMDs at 2.4 GHz
         r["issue"] = {"valu_busy": busy, "salu_busy": p["SQ_INSTS_SALU"] * 2.0 / (1024 * 1e9 * ns * 1e-9), "lane_utilisation": r["valu_lane_utilisation"],
                       "useful_lane_throughput_frac": busy * r["valu_lane_utilisation"]}
