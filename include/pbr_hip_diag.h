@@ -80,8 +80,8 @@ int pbr_diag_last_trace( pbr_ctx* ctx, double* trace_ms, uint32_t* launches );
  * builds (-DPBR_LAB_HOOKS, lab/src/pt_lab_hooks.hpp) and stay 0 otherwise. */
 int pbr_diag_raw_counters( pbr_ctx* ctx, uint64_t out[16] );
 
-/* Loop-bound trips recorded by a PBR_GUARD build ([0] tile loop, [1] path loop, [2] traversal);
- * all zero in a normal build. */
+/* Loop-bound trips of the LAST render, recorded by a PBR_GUARD build ([0] unused since round 3, [1] path loop,
+ * [2] traversal); all zero in a normal build.  A render in which a bounded loop gave up returns PBR_EDEVICE. */
 int pbr_diag_guard_trips( pbr_ctx* ctx, uint32_t out[3] );
 
 #ifdef __cplusplus

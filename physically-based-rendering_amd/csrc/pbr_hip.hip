@@ -327,6 +327,11 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
 
+	// the kernels' error flags are of THIS render (host-mapped memory; no launch of this context is in flight here)
+	for( int k = 0; k < 4; k++ ) {
+		( (volatile unsigned*) ctx->dGuard )[k] = 0u;
+	}
+
 	if( ctx->seedCapacity < nFrames ) {
 		(void) hipFree( ctx->dSeeds );
 		ctx->dSeeds = nullptr;
@@ -607,12 +612,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	}
 
 	if( ctx->frameBufFrames < chunkCap ) {
-		// sized at most twice: for renders of up to 256 frames, and — the first time a render is longer than that — for the
-		// cap.  A longer render after a shorter one must not pay for a multi-GB reallocation inside the call (measured:
-		// 432 -> 512 frames at 1080p, hipFree + hipMalloc of 16 GiB = 0.4 - 0.7 s when the pages have had other owners;
-		// 288 GB of HBM: 16 GiB is not the constraint)
+		// grown geometrically, never beyond the cap: at least 256 frames, then twice what is asked for.  A longer render
+		// after a shorter one must not pay for a multi-GB reallocation inside every call (measured: 432 -> 512 frames at
+		// 1080p, hipFree + hipMalloc of 16 GiB = 0.4 - 0.7 s when the pages have had other owners), and a small image must
+		// not take 16 GiB because one render was longer than 256 frames (64 x 64 pixels, 300 frames: 39 MB).
 		const size_t capFrames = std::max<size_t>( 1, kFrameBufBytes / frameBytes );
-		const size_t frames = ( chunkCap <= 256 ) ? std::max<size_t>( chunkCap, std::min<size_t>( 256, capFrames ) ) : std::max<size_t>( chunkCap, capFrames );
+		const size_t frames = std::min<size_t>( capFrames, std::max<size_t>( 256, ( chunkCap <= 256 ) ? chunkCap : 2 * chunkCap ) );
 		(void) hipFree( ctx->dFrameBuf );
 		ctx->dFrameBuf = nullptr;
 		ctx->frameBufFrames = 0;

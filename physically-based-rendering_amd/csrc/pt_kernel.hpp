@@ -73,15 +73,16 @@ using namespace ptm;
 // leaf phase, one memory latency less per two-face leaf) in kernels of up to this many waves / SIMD: the state machine /
 // the lock-step kernels
 #ifndef PT_EAGER_UP_TO
+#define PT_EAGER_UP_TO 8
+#endif
 // Wave priority (s_setprio) while a wave walks: a SIMD arbitrates between its waves by it.  A walking wave issues a
 // handful of instructions and then waits on a fetch; a shading wave issues hundreds back to back.  With the walkers
 // ahead of the shaders a node visit's loads go out as soon as its wave can issue, and shading fills the gaps: measured
 // +2.0 % (Sponza-class), +0.6 % (Dragon-class), 0 (hairball) in the lane state machine with the leaf phase included,
 // +3.2 % on Cornell and +2.2 % on the Sponza-class scene in the lock-step kernels (node phase only); the other way
 // round — shading ahead — costs 2.7 %.  Priorities 1, 2 and 3 measure alike (profiles/r02/experiments/prio.txt).
+#ifndef PT_WALK_PRIO
 #define PT_WALK_PRIO 1
-
-#define PT_EAGER_UP_TO 8
 #endif
 #ifndef PT_EAGER_REFILL_UP_TO
 #define PT_EAGER_REFILL_UP_TO 8
