@@ -13,6 +13,7 @@ __global__ __launch_bounds__( 1024 ) void rate( float* out, int iters ) {
 	typedef float f2 __attribute__( ( ext_vector_type( 2 ) ) );
 	f2 p0 = { a0, 1 }, p1 = { 1, 2 }, p2 = { 2, 3 }, p3 = { 3, 4 }, p4 = { 4, 5 }, p5 = { 5, 6 }, p6 = { 6, 7 }, p7 = { 7, 8 };
 	unsigned addr = ( threadIdx.x * 2654435761u ) & 0x7FF0u;
+	double d0 = 1e-3 * threadIdx.x, d1 = 0.1, d2 = 0.2, d3 = 0.3, d4 = 0.4, d5 = 0.5, d6 = 0.6, d7 = 0.7;
 
 	if( MODE == 4 ) {
 		for( int i = threadIdx.x; i < 2048; i += blockDim.x ) {
@@ -24,6 +25,15 @@ __global__ __launch_bounds__( 1024 ) void rate( float* out, int iters ) {
 	for( int i = 0; i < iters; i++ ) {
 		if( MODE == 0 ) {
 			REP8( asm volatile( "v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n v_add_f32 %4, %4, %4\n v_add_f32 %5, %5, %5\n v_add_f32 %6, %6, %6\n v_add_f32 %7, %7, %7"
+				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ), "+v"( a7 ) ); )
+		}
+		else if( MODE == 12 ) {
+			// binary64 FMA: what pow1's chains are made of (round 3: is a double-float pow worth building?)
+			REP8( asm volatile( "v_fma_f64 %0, %0, %0, %0\n v_fma_f64 %1, %1, %1, %1\n v_fma_f64 %2, %2, %2, %2\n v_fma_f64 %3, %3, %3, %3\n v_fma_f64 %4, %4, %4, %4\n v_fma_f64 %5, %5, %5, %5\n v_fma_f64 %6, %6, %6, %6\n v_fma_f64 %7, %7, %7, %7"
+				: "+v"( d0 ), "+v"( d1 ), "+v"( d2 ), "+v"( d3 ), "+v"( d4 ), "+v"( d5 ), "+v"( d6 ), "+v"( d7 ) ); )
+		}
+		else if( MODE == 13 ) {
+			REP8( asm volatile( "v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7"
 				: "+v"( a0 ), "+v"( a1 ), "+v"( a2 ), "+v"( a3 ), "+v"( a4 ), "+v"( a5 ), "+v"( a6 ), "+v"( a7 ) ); )
 		}
 		else if( MODE == 9 || MODE == 10 || MODE == 11 ) {
@@ -88,7 +98,7 @@ __global__ __launch_bounds__( 1024 ) void rate( float* out, int iters ) {
 		}
 	}
 
-	out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+	out[blockIdx.x * blockDim.x + threadIdx.x] = (float) ( d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 ) + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
 }
 
 template<int MODE>
@@ -126,6 +136,8 @@ int main() {
 	run<9>( "v_add_f32, EXEC = low 32 lanes", cus, out );
 	run<10>( "v_add_f32, EXEC = low 16 lanes", cus, out );
 	run<11>( "v_add_f32, EXEC = 16 + 16 lanes", cus, out );
+	run<13>( "v_fma_f32", cus, out );
+	run<12>( "v_fma_f64", cus, out );
 	run<1>( "v_pk_add_f32", cus, out );
 	run<2>( "v_min3_f32", cus, out );
 	run<3>( "v_cndmask/v_mov", cus, out );
