@@ -832,7 +832,9 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 // the staged prefix sits at LDS address 0 (the kernels have no other __shared__ data; checked in stageHotNodes),
 // so the reference itself is the address operand of both the LDS read and the global load.
 // The hit condition (pt_bvh.cl:107-110) is a chain of v_cmpx: each compare narrows EXEC to the lanes that still
-// qualify, so no scalar instruction merges the three masks — 8 scalar + 24 vector instructions per visit.
+// qualify, so no scalar instruction merges the three masks — 8 scalar + 22 vector instructions per visit (round 3: 24 → 22,
+// see the note at PT_NODE_PHASE_TAIL; bit-identical and NOT faster — 64.4 ms either way on the Sponza-class scene: the node
+// phase waits for its slowest lane's fetch, it is not bound by vector issue).
 //
 // Rejected after measurement (bit-identical, slower): requesting a parked lane's first face record from inside this
 // loop, into its own lanes of the temporaries (registers are per lane) — whether at once or behind the next
@@ -854,14 +856,15 @@ PT_DEV void nodePhaseAsm(
 #define PT_NODE_PHASE_HEAD \
 		"s_mov_b64 %[saved], exec\n" \
 		"s_mov_b64 %[parkMask], 0\n" \
+		"v_mov_b32 v53, %[ref]\n" \
 	"1:\n" \
-		"v_cmp_gt_i32 vcc, %[numHotBytes], %[ref]\n" \
+		"v_cmp_gt_i32 vcc, %[numHotBytes], v53\n" \
 		"s_and_saveexec_b64 %[active], vcc\n" \
-		"ds_read_b128 v[46:49], %[ref]\n" \
-		"ds_read_b128 v[50:53], %[ref] offset:16\n" \
+		"ds_read_b128 v[46:49], v53\n" \
+		"ds_read_b128 v[50:53], v53 offset:16\n" \
 		"s_xor_b64 exec, exec, %[active]\n" \
-		"global_load_dwordx4 v[46:49], %[ref], %[nodes]\n" \
-		"global_load_dwordx4 v[50:53], %[ref], %[nodes] offset:16\n" \
+		"global_load_dwordx4 v[46:49], v53, %[nodes]\n" \
+		"global_load_dwordx4 v[50:53], v53, %[nodes] offset:16\n" \
 		"s_mov_b64 exec, %[active]\n" \
 		"v_add_u32 %[visits], 1, %[visits]\n" \
 		"s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
@@ -878,24 +881,29 @@ PT_DEV void nodePhaseAsm(
 		"v_max_f32 v61, v54, v56\n" \
 		"v_max_f32 v63, v58, v59\n" \
 		"v_max_f32 v62, v55, v57\n" \
-		"v_min_f32 v63, 0x7f800000, v63\n" \
 		"v_min3_f32 v61, v61, v62, v63\n" \
-		"v_mov_b32 %[ref], v53\n" \
 		"v_cmpx_lt_f32 %[eps], v61\n"
 
-	// EXEC = the lanes whose box is hit.  A hit container continues at w0, everything else at w1 (set above);
-	// the lanes on a hit leaf park; then the lanes that go on: alive and not parked
+	// EXEC = the lanes whose box is hit.  A hit container continues at w0, everything else at w1;
+	// the lanes on a hit leaf park; then the lanes that go on: alive and not parked.
+	// Round 3: the cursor lives in v53 for the whole phase — the record's last word IS the reference to continue at
+	// unless the box is a hit container, so the load that fetches a record also advances the cursor (a load may
+	// overwrite its own address register), and the per-visit copy of w1 is gone; and tFar is min3 of the three slab
+	// exits as they stand: pt_intersect.cl's fmin( ., INFINITY ) on the third only matters when all three are NaN, and
+	// then tNear is NaN too and the box is missed either way (the C++ statement below keeps the reference's form).
+	// 22 vector + 8 scalar instructions per visit.
 #define PT_NODE_PHASE_TAIL \
 		"v_cmp_gt_i32 vcc, 0, v52\n" \
-		"v_cndmask_b32 %[ref], v52, v53, vcc\n" \
+		"v_cndmask_b32 v53, v52, v53, vcc\n" \
 		"s_or_b64 %[parkMask], %[parkMask], vcc\n" \
 		"s_mov_b64 exec, %[active]\n" \
-		"v_cmp_le_i32 %[mA], 0, %[ref]\n" \
+		"v_cmp_le_i32 %[mA], 0, v53\n" \
 		"s_andn2_b64 exec, %[mA], vcc\n" \
 		"s_bcnt1_i32_b64 %[count], exec\n" \
 		"s_cmp_gt_i32 %[count], %[keep]\n" \
 		"s_cbranch_scc1 1b\n" \
 		"s_mov_b64 exec, %[saved]\n" \
+		"v_mov_b32 %[ref], v53\n" \
 		"v_cndmask_b32 %[parked], 0, 1, %[parkMask]\n" \
 		"v_mov_b32 %[leafWord], v52\n" \
 		"v_mov_b32 %[leafTNear], v60\n" \
