@@ -15,6 +15,12 @@ HOW = ("rocprofv3 --pmc, separate passes of `python3 bench.py --scene S --steps 
        "writes = WRITE_SIZE KB; Infinity-Cache hits are included; the timed path-tracing launch only")
 
 
+def newest(pattern):
+    """rocprofv3 names its files by process id; a directory that has been merged twice holds two runs: take the later one."""
+    found = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return found[-1:] 
+
+
 def last_line_json(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
@@ -29,12 +35,12 @@ def collect(out, loads):
             rec["bench_error"] = str(e)
         try:
             rec["bench_under_rocprof"] = last_line_json("%s/stats_%s.json" % (out, key))
-            rows = list(csv.DictReader(open(glob.glob("%s/stats_%s/*/*_kernel_stats.csv" % (out, key))[0])))
+            rows = list(csv.DictReader(open(newest("%s/stats_%s/*/*_kernel_stats.csv" % (out, key))[0])))
             rec["kernel_stats"] = [r for r in rows if "ptk::" in r["Name"]]
         except Exception as e:
             rec["stats_error"] = str(e)
         pmc = collections.OrderedDict()
-        for f in sorted(glob.glob("%s/pmc*_%s/*/*_counter_collection.csv" % (out, key))):
+        for f in sorted(sum((newest(d + "/*/*_counter_collection.csv") for d in sorted(glob.glob("%s/pmc*_%s" % (out, key)))), [])):
             per = collections.defaultdict(lambda: collections.defaultdict(float))
             meta = {}
             for r in csv.DictReader(open(f)):
@@ -75,7 +81,7 @@ def assemble(src, round_name):
         json.dump(b, open(dst + "/" + key + "/bench_line.json", "w"), indent=1)
         json.dump(r["bench_under_rocprof"], open(dst + "/" + key + "/bench_line_under_rocprof.json", "w"), indent=1)
         for name in ("kernel_stats", "domain_stats", "kernel_trace"):
-            f = glob.glob("%s/stats_%s/*/*_%s.csv" % (src, key, name))
+            f = newest("%s/stats_%s/*/*_%s.csv" % (src, key, name))
             if f:
                 shutil.copy(f[0], "%s/%s/%s.csv" % (dst, key, name))
         samples = cfg["width"] * cfg["height"] * b["steps"]
@@ -86,7 +92,7 @@ def assemble(src, round_name):
                         "schedule": b.get("schedule"), "fabric_read_bytes_per_launch": rd, "fabric_write_bytes_per_launch": wr,
                         "bytes_per_sample": (rd + wr) / samples, "l2_requests_per_launch": p.get("TCC_REQ_sum"), "l2_hit_rate": r.get("l2_hit_rate"),
                         "sq": {k: p[k] for k in sq_keys if k in p}, "how": HOW}
-        f = glob.glob("%s/stats_%s/*/*_kernel_trace.csv" % (src, key))[0]
+        f = newest("%s/stats_%s/*/*_kernel_trace.csv" % (src, key))[0]
         kr = [x for x in csv.DictReader(open(f)) if "pathTracing" in x["Kernel_Name"]]
         kr.sort(key=lambda x: int(x["Start_Timestamp"]))
         last = kr[-1]; dur = (int(last["End_Timestamp"]) - int(last["Start_Timestamp"])) / 1e6

@@ -1,8 +1,12 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03d
-R=$PWD
-cd /tmp
-for s in sponza hairball; do
-bash $R/scripts/pmc.sh $R/gpurun_out/r03d/pmc_tcp_$s pathTracing -- python3 $R/bench.py --scene $s --steps 32 --plan 4 --cpu-seconds 0 > $R/gpurun_out/r03d/pmc_tcp_$s.txt 2>&1
-done
-cat $R/gpurun_out/r03d/pmc_tcp_sponza.txt $R/gpurun_out/r03d/pmc_tcp_hairball.txt
+mkdir -p gpurun_out/r03e
+( time timeout 3000 python -m pytest tests -x -q -m gpu ) > gpurun_out/r03e/pytest_full.txt 2>&1
+tail -5 gpurun_out/r03e/pytest_full.txt
+rm -rf gpurun_out/round3
+timeout 2400 bash scripts/profile_round.sh gpurun_out/round3 cornell sponza dragon hairball hairball_4k > gpurun_out/r03e/profile_round.log 2>&1
+tail -6 gpurun_out/r03e/profile_round.log
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r03e/bench_driver_command.json 2> gpurun_out/r03e/bench_driver_command.err
+cat gpurun_out/r03e/bench_driver_command.json
+timeout 600 python bench.py --gpus 2 --backend gloo --one-device --steps 20 --warmup 5 --cpu-seconds 0 > gpurun_out/r03e/bench_two_ranks_one_device.json 2> gpurun_out/r03e/bench_two_ranks.err
+cat gpurun_out/r03e/bench_two_ranks_one_device.json; tail -3 gpurun_out/r03e/bench_two_ranks.err
+python -c "import __graft_entry__ as g; g.smoke()"
