@@ -1080,14 +1080,19 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 		return ( weight[a] != weight[b] ) ? ( weight[a] > weight[b] ) : ( a < b );
 	} );
 
-	// ---- the node stream (pt_kernel.hpp decodeNode): hot nodes by rank, then the rest in DFS order ----
+	// ---- the node stream (pt_kernel.hpp decodeNode): hot nodes by rank, then the rest ----
 	std::vector<int> recordOf( (size_t) N, -1 );   // node index -> record; the root has none
 
 	for( uint32_t r = 0; r < numHot; r++ ) {
 		recordOf[ranked[r]] = (int) r;
 	}
 
+	const size_t numRecords = N;   // records the stream holds (the last one is padding)
+
 	{
+		// the rest in DFS order: a cold node's hit successor is the adjacent 32 B.  (Any order is legal — every record names
+		// its successors.  Treelets, a connected piece of the tree per 128-byte line, were built and measured in round 3:
+		// -13 ... -19 % distinct lines per ray offline, +0.0 / +0.2 / +0.7 % on the GPU; lab/src/node_stream_treelets.txt.)
 		int next = (int) numHot;
 
 		for( uint32_t i = 1; i < N; i++ ) {
@@ -1103,7 +1108,11 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 		return ( node > 0 && node < (long long) N ) ? recordOf[(size_t) node] * 32 : -1;
 	};
 
-	std::vector<float4> nodes( (size_t) N * 2, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );
+	if( numRecords * 32 >= ( (size_t) 1 << 31 ) ) {
+		return fail( ctx, PBR_EINVAL, "upload_scene: the node stream would exceed 2 GiB (record references are 31-bit byte offsets)" );
+	}
+
+	std::vector<float4> nodes( numRecords * 2, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );
 
 	for( uint32_t i = 1; i < N; i++ ) {
 		const pbr_bvh_node& n = s->bvh[i];

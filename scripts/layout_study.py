@@ -80,3 +80,46 @@ for hot in (2552, 5112):
     isb = np.zeros(N, bool); isb[best] = True
     evaluate("DFS, hot set by measured visits", positions(np.concatenate([best, np.array([i for i in range(1, N) if not isb[i]])])), hot)
 
+
+    # ---- round 3: treelets — the cold records packed so that a 128-B line holds a CONNECTED piece of the tree ----
+    # (a node is visited iff its parent's box was hit: the visited set is prefix-closed, so lines that hold a parent with
+    # its most-visited descendants are used by more visits than lines that hold four consecutive DFS indices)
+    parent = np.full(N, -1, np.int64); stack2 = []
+    for i in range(N):
+        while stack2 and i >= stack2[-1][0]: stack2.pop()
+        parent[i] = stack2[-1][1] if stack2 else -1
+        if not leaf[i]:
+            esc = link[i] if link[i] > i else N
+            stack2.append((esc, i))
+    children = [[] for _ in range(N)]
+    for i in range(1, N):
+        if parent[i] >= 0: children[parent[i]].append(i)
+    for per_line in (4,):
+        order_cold = []; holes = 0
+        roots = [i for i in range(1, N) if not ishot[i] and (parent[i] < 0 or ishot[parent[i]] or parent[i] == 0)]
+        import heapq
+        todo = list(roots)[::-1]        # DFS-ish order of treelet roots
+        line_fill = 0
+        while todo:
+            r = todo.pop()
+            treelet = [r]; frontier = [(-weight[c], c) for c in children[r] if not ishot[c]]
+            heapq.heapify(frontier)
+            while frontier and len(treelet) < per_line:
+                w_, c = heapq.heappop(frontier)
+                treelet.append(c)
+                for g in children[c]:
+                    if not ishot[g]: heapq.heappush(frontier, (-weight[g], g))
+            rest = sorted([c for _, c in frontier], reverse=True)
+            todo.extend(rest)           # their subtrees next, first child first
+            if line_fill + len(treelet) > per_line:      # does not fit the open line: pad it
+                pad = per_line - line_fill
+                order_cold.extend([-1] * pad); holes += pad; line_fill = 0
+            order_cold.extend(treelet); line_fill = (line_fill + len(treelet)) % per_line
+        # hot nodes' cold children that were never reached (none expected) and positions
+        pos = np.full(N, -1, np.int64); pos[hotset] = np.arange(hot)
+        # the cold part starts on a line boundary
+        base = (hot + 3) // 4 * 4
+        oc = np.array(order_cold, np.int64)
+        pos[oc[oc >= 0]] = base + np.flatnonzero(oc >= 0)
+        assert (pos[1:] >= 0).all(), int((pos[1:] < 0).sum())
+        evaluate("treelets of %d by parent area (%d holes)" % (per_line, holes), pos, hot)
