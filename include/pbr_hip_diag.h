@@ -52,6 +52,8 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
  *   "blocks_per_cu" run below the resident maximum
  *   "ph_park" / "ph_shade"  lane state machine thresholds; "park_eighths": the lock-step walk's park share
  *   "drain_mode"    bit 0 / 1: scale ph_park / ph_shade with the lanes still at work once the queue is empty
+ *   "refill_batch"  lock-step kernels: lanes of a wave that wait with a finished unit before they take their next units
+ *                   together (1 = every lane at once, as up to round 2)
  *   "chunk_frames"  cap of the frames per launch pair of pbr_render (tests: several launch pairs)
  *   "face_normals"  0 = recompute the face normal on every hit (takes effect at the next pbr_upload_scene)
  *   "bvh_builder"   pbr_build_bvh: 0 clustering (default), 1 round 1's radix tree; "ploc_radius": its search radius

@@ -298,7 +298,7 @@ class HostScene:
 # pbr_diag_set_knob) — this harness maps them onto knobs when a context is created.
 _ENV_KNOBS = {
     "PBR_LDS_SLOTS": "lds_slots", "PBR_BLOCKS_PER_CU": "blocks_per_cu", "PBR_PH_PARK": "ph_park", "PBR_PH_SHADE": "ph_shade",
-    "PBR_PARK_EIGHTHS": "park_eighths", "PBR_DRAIN_MODE": "drain_mode",
+    "PBR_PARK_EIGHTHS": "park_eighths", "PBR_DRAIN_MODE": "drain_mode", "PBR_REFILL_BATCH": "refill_batch",
     "PBR_CHUNK_FRAMES": "chunk_frames", "PBR_FACE_NORMALS": "face_normals", "PBR_PLOC_RADIUS": "ploc_radius", "PBR_TUNE_LOG": "tune_log",
 }
 

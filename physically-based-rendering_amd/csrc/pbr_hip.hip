@@ -42,6 +42,7 @@ struct Knobs {
 	int phPark = -1, phShade = -1;   // lane state machine: lanes that leave a node phase before it ends / that wait before a shade phase
 	int parkEighths = -1;   // lock-step walk: share of the lanes (in eighths) that leave a node phase before it ends
 	int drainMode = -1;     // lane state machine once lanes are DONE: bit 0 scale phPark, bit 1 scale phShade
+	int refillBatch = -1;   // lock-step kernels: lanes that wait with a finished unit before the wave refills them together
 	int chunkFrames = -1;   // cap of the frames per launch pair (tests: force several launch pairs)
 	int faceNormals = -1;   // 0 = recompute the face normal on every hit instead of reading the stored one
 	int bvhBuilder = -1;    // pbr_build_bvh: 1 = round 1's radix tree instead of the clustering builder
@@ -266,6 +267,12 @@ KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights );
 // Register budget when a schedule is forced (PBR_SCHEDULE) without PBR_VARIANT: scenes whose tree does
 // not fit the staged LDS prefix get "wide" (pt_kernel.hpp), small scenes "lean".  Unforced renders are auto-tuned.
 const uint32_t kWideMinNodes = 2048;
+
+// lock-step kernels: lanes of a wave that wait with a finished unit before they take their next units together.  Measured
+// (profiles/r03/experiments/sweep_refill.txt, 1080p): Cornell refill-mid 4791 / 4837 / 4865 / 4765 / 4570 Msamples/s at
+// 1 / 8 / 16 / 24 / 32 lanes (a single frame: 2197 -> 2437), Sponza-class refill-wide 1618 / 1664 / 1751 / 1776 / 1791:
+// 16 where the tree fits LDS and shading is most of a bounce, 32 where the walk is.
+const int kRefillBatchSmall = 16, kRefillBatchLarge = 32;
 
 
 KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights ) {
@@ -511,6 +518,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.numHotBytes = plan.numHot * 32;
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
+		P.refillBatch = ( knobs.refillBatch >= 1 ) ? std::min( 64, knobs.refillBatch ) : ( ( ctx->numNodes >= kWideMinNodes ) ? kRefillBatchLarge : kRefillBatchSmall );
 		P.drainMode = ctx->drainMode;   // 1: measured (single-frame 1080p launches): park share scaled, shade threshold as is: Dragon-class 2.99 -> 2.47 ms, hairball 4.26 -> 4.02 ms, Sponza- / Cornell-class unchanged; scaling the shade threshold too helps the first two further (2.26 / 3.56 ms) and costs the others 10 - 20 %
 		P.parkEighths = plan.parkEighths;
 		hipLaunchKernelGGL( plan.kernel, dim3( blocks ), dim3( (unsigned) plan.blockThreads ), plan.ldsBytes, ctx->stream, P );
@@ -2145,7 +2153,7 @@ int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value ) {
 	Knobs& k = ctx->knobs;
 	const struct { const char* name; int* slot; } table[] = {
 		{ "lds_slots", &k.ldsSlots }, { "blocks_per_cu", &k.blocksPerCU }, { "ph_park", &k.phPark }, { "ph_shade", &k.phShade },
-		{ "park_eighths", &k.parkEighths }, { "drain_mode", &k.drainMode },
+		{ "park_eighths", &k.parkEighths }, { "drain_mode", &k.drainMode }, { "refill_batch", &k.refillBatch },
 		{ "chunk_frames", &k.chunkFrames }, { "face_normals", &k.faceNormals }, { "bvh_builder", &k.bvhBuilder },
 		{ "ploc_radius", &k.plocRadius }, { "tune_log", &k.tuneLog },
 	};

@@ -127,6 +127,7 @@ struct DevParams {
 	float phongAlpha;            // PHONGTESS_ALPHA (kernels built with PHONG = true only)
 	int parkEighths;             // traverse(): a node phase ends once this many eighths of the lanes that entered it have left it
 	int drainMode;               // phased schedule, once lanes are DONE: bit 0 scale phPark, bit 1 scale phShade with the lanes still at work
+	int refillBatch;             // lock-step schedule: lanes of a wave that wait with a finished unit before they take their next units together
 	int phPark, phShade;         // phased schedule: lanes that leave a node phase before it ends / lanes that wait before a shade phase runs
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
 	int numHot;             // records [0, numHot) of the node stream are resident in LDS
@@ -1972,26 +1973,45 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 		beginPixel( P, st, slot, cnt, frame );
 	}
 
-	while( have ) {
+	// Refill in batches (round 3).  A lane whose unit is finished does not take the next one at once: it waits until
+	// P.refillBatch lanes of the wave wait with it (or nobody has a unit left), and they take their units — queue fetch,
+	// pixel decode, camera ray: ~450 instructions — together.  In a lock-step wave an idle lane costs nothing (the wave
+	// issues the same walk and the same shading for 40 lanes as for 64), but code that runs for three lanes costs what
+	// it costs for 64: with immediate refill nearly every bounce of a wave ended with a refill for the few lanes whose
+	// path had just ended.
+	bool pending = false;
+
+	while( __ballot( have || pending ) != 0ull ) {
 #ifdef PBR_GUARD_PATH
 		if( ++guardSteps > guardMax ) {
 			atomicAdd( &P.guard[1], 1u );
 			break;
 		}
 #endif
-		if( stepPixel<BRDF, SHADOW, LIGHTS, PHONG, ( MINW <= 4 ), ( MINW <= PT_EAGER_REFILL_UP_TO ), ( MINW > 6 )>( P, lds, st, cnt ) ) {
+		{
+			const int nPending = __popcll( __ballot( pending ) );
+			const int nHave = __popcll( __ballot( have ) );
+
+			if( pending && ( nPending >= P.refillBatch || nHave == 0 ) ) {
+				slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
+				have = ( slot != PT_NO_WORK );
+				pending = false;
+
+				if( have ) {
+					beginPixel( P, st, slot, cnt, frame );
+				}
+			}
+		}
+
+		if( have && stepPixel<BRDF, SHADOW, LIGHTS, PHONG, ( MINW <= 4 ), ( MINW <= PT_EAGER_REFILL_UP_TO ), ( MINW > 6 )>( P, lds, st, cnt ) ) {
 			finishPixel( P, st );
 
 			if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
 				flushCounters( P, cnt );
 			}
 
-			slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
-			have = ( slot != PT_NO_WORK );
-
-			if( have ) {
-				beginPixel( P, st, slot, cnt, frame );
-			}
+			have = false;
+			pending = true;
 		}
 	}
 

@@ -264,6 +264,22 @@ def test_banded_queue_covers_every_pixel_once(pbr, oracle, device, schedule, w, 
     assert device.counters() == ref.counter_dict()
 
 
+@pytest.mark.parametrize("batch", [1, 3, 16, 64])
+@pytest.mark.parametrize("schedule", ["refill-lean", "refill-mid", "refill-wide"])
+def test_batched_refill_does_not_change_results(pbr, oracle, device, schedule, batch):
+    """Lock-step kernels (round 3): a lane whose unit is finished waits until `refill_batch` lanes of its wave wait with
+    it before they take their next units together (1 = at once; 64 = only when the whole wave has finished).  When a lane
+    takes its next unit changes nothing about the unit."""
+    force_schedule(device, schedule)
+    device.set_knob("refill_batch", batch)
+    sc = make_scene(pbr, "sponza", 5, 9000, **{"render.max_depth": 4, "render.samples": 2})
+    got, want, ref = both_render(pbr, oracle, device, sc, 104, 72, 5)
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert same_values(device.read_debug(), ref.debug)
+    assert device.counters() == ref.counter_dict()
+    assert device.guard_trips() == [0, 0, 0]
+
+
 @pytest.mark.parametrize("slots", [0, 7, 300])
 def test_lds_staging_size_does_not_change_results(pbr, oracle, device, slots):
     """Any prefix of the hot-node ranking may be staged (knob lds_slots caps it; 0 = none)."""
@@ -667,6 +683,8 @@ def test_random_configurations_bit_exact(pbr, oracle, device, seed):
         device.set_knob("chunk_frames", int(rng.integers(1, 4)))
     if rng.integers(3) == 0:
         device.set_knob("drain_mode", int(rng.integers(0, 4)))
+    if rng.integers(3) == 0:
+        device.set_knob("refill_batch", int(rng.choice([1, 5, 40, 64])))
     w, h = 8 * int(rng.integers(1, 12)), 8 * int(rng.integers(1, 9))
     frames = int(rng.integers(1, 6))
     first = int(rng.integers(0, 3))
