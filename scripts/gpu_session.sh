@@ -1,5 +1,11 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03g
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cornell_image or larger_scenes or every_tuner or phong or guard_build or random_configurations or chunks or banded" 2>&1 | tail -4
-timeout 900 python scripts/sweep_refill.py > gpurun_out/r03g/sweep_refill.txt 2>&1
-cat gpurun_out/r03g/sweep_refill.txt
+mkdir -p gpurun_out/r03h
+( time timeout 3000 python -m pytest tests -x -q -m gpu ) > gpurun_out/r03h/pytest_full.txt 2>&1
+tail -5 gpurun_out/r03h/pytest_full.txt
+rm -rf gpurun_out/round3c
+timeout 1200 bash scripts/profile_round.sh gpurun_out/round3c cornell > gpurun_out/r03h/profile_cornell.log 2>&1
+tail -3 gpurun_out/r03h/profile_cornell.log
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r03h/bench_driver_command.json 2> gpurun_out/r03h/bench_driver_command.err
+cut -c1-300 gpurun_out/r03h/bench_driver_command.json
+timeout 600 python bench.py --scene cornell --steps 256 --cpu-seconds 0 > gpurun_out/r03h/bench_cornell.json 2>/dev/null
+cut -c1-200 gpurun_out/r03h/bench_cornell.json
