@@ -63,8 +63,10 @@ def algorithmic_bytes(counters, pixel_frames, samples_per_frame=1):
 GATHER_CEILING_LINES = 56e9   # random dependent 32-B gathers from a table beyond L2, 128-B lines per second (scripts/micro/gather_rate.hip: 55-57 G/s)
 
 # what the counters say binds the kernel on each workload; "hbm" is the contract's ceiling for this path
-MEASURED_BOUND = {"cornell": "valu-issue", "sponza": "dependent-gather latency", "dragon": "dependent-gather latency",
-                  "hairball": "dependent-gather latency"}
+MEASURED_BOUND = {"cornell": "vector issue (77 % busy at 47 % of the lanes)",
+                  "sponza": "slowest lane's fetch per node phase (cache-resident: L2 hit 84 %, 62 % of wave-cycles waiting)",
+                  "dragon": "fabric bandwidth (5.0 TB/s of reads = 63 % of the HBM peak, 80 % of a streaming copy's rate)",
+                  "hairball": "L2 request rate (21 TB/s of 128-B lines, above the guide's L2-resident gather rate)"}
 
 
 def recorded_traffic(scene, w, h, depth, brdf):
@@ -82,6 +84,51 @@ def recorded_traffic(scene, w, h, depth, brdf):
             if rec.get("scene", key.split("_")[0]) == scene and (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) == (w, h, depth, brdf):
                 return dict(rec, source=os.path.relpath(path, ROOT))
     return None
+
+
+def roofline_block(scene, plan, traffic, algo_launch, per_launch_samples, kernel_s):
+    """The roofline of the dominant kernel, physical: `achieved` = bytes the memory system moved behind L2 for one launch
+    (fabric reads + writes from the committed PMC passes of this workload — `traffic`, a record of
+    profiles/rNN/pmc_traffic.json — Infinity-Cache hits included, scaled to this run's samples) / the launch's duration
+    measured live (HIP events on the context's stream); `frac` = that / the HBM peak, <= 1 by construction.  The contract's
+    algorithmic figure (every node visit priced at 32 B whether or not it left the CU) is `algorithmic_GBs`: it exceeds
+    the peak on cache-resident scenes and ranks nothing.  `issue` and `l2` say what binds a scene whose working set
+    lives in L2 / Infinity Cache."""
+    roofline = {
+        "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+        "kernel": "ptk::pathTracingPhased" if plan.startswith("phased") else "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
+        "algorithmic_bytes_per_launch": algo_launch, "algorithmic_GBs": algo_launch / kernel_s / 1e9,
+        "bound_measured": MEASURED_BOUND.get(scene),
+    }
+    if traffic is None:
+        return roofline
+    scale = per_launch_samples / (traffic["width"] * traffic["height"] * traffic["steps"])      # this launch's samples / the profiled launch's
+    per_launch = traffic["bytes_per_sample"] * per_launch_samples
+    lines = traffic["fabric_read_bytes_per_launch"] / 128.0 * scale
+    roofline.update({
+        "achieved": per_launch / kernel_s / 1e9, "frac": per_launch / kernel_s / 1e9 / HBM_PEAK_GBS,
+        "traffic": per_launch,
+        "traffic_source": traffic["source"] + " (separate rocprofv3 --pmc passes of this workload with schedule %s, scaled to this run's samples)" % traffic["schedule"],
+        "achievable_frac": per_launch / kernel_s / 1e9 / HBM_ACHIEVABLE_GBS,
+        "gather_ceiling": lines / kernel_s / GATHER_CEILING_LINES,
+        "gather_ceiling_note": "128-B lines fetched per second / 56 G/s, this chip's rate of dependent random 32-B gathers beyond L2 (scripts/micro/gather_rate.hip)",
+    })
+    sq = traffic.get("sq")
+    if sq:
+        # vector issue: wave-instructions x 2.4 cycles each (scripts/micro/valu_rate.hip) over the chip's 1024 SIMDs
+        # at 2.4 GHz = instructions / (1024 x 1e9 x t); useful lanes = thread-cycles / (64 x instructions)
+        insts, threads = sq["SQ_INSTS_VALU"] * scale, sq["SQ_THREAD_CYCLES_VALU"] * scale
+        busy = insts / (NUM_SIMDS * 1e9 * kernel_s)
+        roofline["issue"] = {
+            "valu_busy": busy, "lane_utilisation": threads / (64.0 * insts), "frac": busy * threads / (64.0 * insts),
+            "wave_wait_fraction": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+            "note": "frac = share of the chip's vector lane-throughput doing useful work = SQ_THREAD_CYCLES_VALU x 2.4 cycles / (64 lanes x SIMD-cycles)",
+        }
+    if traffic.get("l2_requests_per_launch"):
+        req = traffic["l2_requests_per_launch"] * scale
+        roofline["l2"] = {"request_GBs": req * 128.0 / kernel_s / 1e9, "peak": L2_PEAK_GBS, "frac": req * 128.0 / kernel_s / 1e9 / L2_PEAK_GBS,
+                          "hit_rate": traffic.get("l2_hit_rate"), "note": "TCC_REQ x 128 B against the 17-19 TB/s the guide measures for L2-resident gathers"}
+    return roofline
 
 
 def diff(a, b):
@@ -341,46 +388,7 @@ def main():
         # trace_launches of them per render; the slowest rank's average launch duration
         algo_launch = algo / world / trace_launches          # SURVEY 8(d)'s per-sample figure x the samples one launch processes
         traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf))
-        # The roofline of the dominant kernel, physical: `achieved` = bytes the memory system moved behind L2 for one
-        # launch (fabric reads + writes from the committed PMC passes of this workload, Infinity-Cache hits included,
-        # scaled to this run's samples) / the launch's duration measured live (HIP events on the context's stream);
-        # `frac` = that / the HBM peak, <= 1 by construction.  The contract's algorithmic figure (every node visit priced
-        # at 32 B whether or not it left the CU) is `algorithmic_GBs`: it exceeds the peak on cache-resident scenes and
-        # ranks nothing.  `issue` and `l2` say what binds a scene whose working set lives in L2 / Infinity Cache.
-        roofline = {
-            "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-            "kernel": "ptk::pathTracingPhased" if plan.startswith("phased") else "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
-            "algorithmic_bytes_per_launch": algo_launch, "algorithmic_GBs": algo_launch / kernel_s / 1e9,
-            "bound_measured": MEASURED_BOUND.get(args.scene),
-        }
-        if traffic is not None:
-            per_launch_samples = samples / world / trace_launches
-            per_launch = traffic["bytes_per_sample"] * per_launch_samples
-            lines = traffic["fabric_read_bytes_per_launch"] / 128.0 * per_launch_samples / (traffic["width"] * traffic["height"] * traffic["steps"])
-            roofline.update({
-                "achieved": per_launch / kernel_s / 1e9, "frac": per_launch / kernel_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": per_launch,
-                "traffic_source": traffic["source"] + " (separate rocprofv3 --pmc passes of this workload with schedule %s, scaled to this run's samples)" % traffic["schedule"],
-                "achievable_frac": per_launch / kernel_s / 1e9 / HBM_ACHIEVABLE_GBS,
-                "gather_ceiling": lines / kernel_s / GATHER_CEILING_LINES,
-                "gather_ceiling_note": "128-B lines fetched per second / 56 G/s, this chip's rate of dependent random 32-B gathers beyond L2 (scripts/micro/gather_rate.hip)",
-            })
-            sq = traffic.get("sq")
-            if sq:
-                # vector issue: wave-instructions x 2.4 cycles each (scripts/micro/valu_rate.hip) over the chip's 1024 SIMDs
-                # at 2.4 GHz = instructions / (1024 x 1e9 x t); useful lanes = thread-cycles / (64 x instructions)
-                scale = per_launch_samples / (traffic["width"] * traffic["height"] * traffic["steps"])
-                insts, threads = sq["SQ_INSTS_VALU"] * scale, sq["SQ_THREAD_CYCLES_VALU"] * scale
-                busy = insts / (NUM_SIMDS * 1e9 * kernel_s)
-                roofline["issue"] = {
-                    "valu_busy": busy, "lane_utilisation": threads / (64.0 * insts), "frac": busy * threads / (64.0 * insts),
-                    "wave_wait_fraction": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
-                    "note": "frac = share of the chip's vector lane-throughput doing useful work = SQ_THREAD_CYCLES_VALU x 2.4 cycles / (64 lanes x SIMD-cycles)",
-                }
-            if traffic.get("l2_requests_per_launch"):
-                req = traffic["l2_requests_per_launch"] * per_launch_samples / (traffic["width"] * traffic["height"] * traffic["steps"])
-                roofline["l2"] = {"request_GBs": req * 128.0 / kernel_s / 1e9, "peak": L2_PEAK_GBS, "frac": req * 128.0 / kernel_s / 1e9 / L2_PEAK_GBS,
-                                  "hit_rate": traffic.get("l2_hit_rate"), "note": "TCC_REQ x 128 B against the 17-19 TB/s the guide measures for L2-resident gathers"}
+        roofline = roofline_block(args.scene, plan, traffic, algo_launch, samples / world / trace_launches, kernel_s)
         out = {
             "metric": "Msamples/s (paths/s) @1080p fixed seed; 1/2/4/8 MI355X scaling",
             "value": samples / elapsed / 1e6,

@@ -176,3 +176,31 @@ def test_bench_gpus_8_without_a_launcher_spawns_instead_of_refusing():
     assert "torch.distributed.run launch" not in run.stderr
     # the ranks were started and refused to run without a device (torch.cuda.set_device or pbr_create, whichever comes first)
     assert run.returncode != 0 and ("No HIP GPUs" in run.stderr or "PbrError" in run.stderr)
+
+
+def test_bench_roofline_is_physical_for_every_profiled_workload():
+    """bench.py's roofline block from the committed PMC passes (profiles/r03/pmc_traffic.json) at each workload's own
+    launch time (profiles/r03/summary.json): `frac` is fabric traffic / time / 8 TB/s — between 0 and 1 —, the issue-side
+    and L2 fractions are below 1 as well, and the contract's algorithmic figure is reported beside them, not as `frac`."""
+    import json
+    bench = _bench_module()
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r03", "summary.json")))
+    seen = 0
+    for key, rec in summary.items():
+        line = rec["bench"]
+        cfg = line["config"]
+        traffic = bench.recorded_traffic(cfg["scene"], cfg["width"], cfg["height"], cfg["max_depth"], cfg["brdf"])
+        assert traffic is not None and traffic["source"].startswith(os.path.join("profiles", "r03")), key
+        samples = cfg["width"] * cfg["height"] * line["steps"]
+        seconds = line["roofline"]["launch_ms"] / 1e3
+        block = bench.roofline_block(cfg["scene"], line["schedule"], traffic, line["per_sample"]["algorithmic_bytes"] * samples, samples, seconds)
+        want = (traffic["fabric_read_bytes_per_launch"] + traffic["fabric_write_bytes_per_launch"]) / seconds / 8e12
+        assert abs(block["frac"] - want) < 1e-9 and 0.0 < block["frac"] <= 1.0, (key, block["frac"])
+        assert block["achieved"] <= block["peak"] and block["bound"] == "hbm" and block["unit"] == "GB/s"
+        assert 0.0 < block["issue"]["frac"] < 1.0 and 0.0 < block["issue"]["lane_utilisation"] < 1.0
+        assert block["algorithmic_GBs"] > 0 and "algorithmic_bytes_per_launch" in block
+        seen += 1
+    assert seen == 5                                   # cornell, sponza, dragon, hairball, hairball at 3840 x 2160
+    # a workload nobody profiled: no invented number
+    none = bench.roofline_block("sponza", "phased-mid", None, 1e9, 1e6, 1e-3)
+    assert none["frac"] is None and none["traffic"] is None and none["algorithmic_GBs"] == 1e9 / 1e-3 / 1e9
