@@ -837,6 +837,10 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 // see the note at PT_NODE_PHASE_TAIL; bit-identical and NOT faster — 64.4 ms either way on the Sponza-class scene: the node
 // phase waits for its slowest lane's fetch, it is not bound by vector issue).
 //
+// Cache policy of the two loads, measured in round 3 (profiles/r03/experiments/node_load_cache_policy.txt): default as
+// it stands; `nt` 0.60 / 0.41 / 0.34x (Sponza- / Dragon-class / hairball), `sc0` the same within noise, `sc1` and
+// `sc0 sc1` 0.92 / 0.78 / 0.63x.
+//
 // Rejected after measurement (bit-identical, slower): requesting a parked lane's first face record from inside this
 // loop, into its own lanes of the temporaries (registers are per lane) — whether at once or behind the next
 // iteration's node loads with s_waitcnt vmcnt(3): the 6 scalar + 3 vector + 3 memory instructions it adds to every
