@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03i
-rm -f gpurun_out/r03i/policy.txt
-for lib in "" lab/libpbrhip_nt.so lab/libpbrhip_sc0.so lab/libpbrhip_sc1.so lab/libpbrhip_sc01.so ""; do
-  PBR_HIP_LIB=$lib PBR_PLAN=4 timeout 300 python scripts/ab.py sponza:32 dragon:32 hairball:16 >> gpurun_out/r03i/policy.txt 2>&1
-done
-cat gpurun_out/r03i/policy.txt
+mkdir -p gpurun_out/r03j
+( time timeout 3000 python -m pytest tests -x -q -m gpu ) > gpurun_out/r03j/pytest_full.txt 2>&1
+tail -4 gpurun_out/r03j/pytest_full.txt
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r03j/bench_driver_command.json 2> gpurun_out/r03j/bench.err
+cut -c1-260 gpurun_out/r03j/bench_driver_command.json
+python -c "import __graft_entry__ as g; g.smoke()"
