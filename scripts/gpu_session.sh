@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03j
-( time timeout 3000 python -m pytest tests -x -q -m gpu ) > gpurun_out/r03j/pytest_full.txt 2>&1
-tail -4 gpurun_out/r03j/pytest_full.txt
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r03j/bench_driver_command.json 2> gpurun_out/r03j/bench.err
-cut -c1-260 gpurun_out/r03j/bench_driver_command.json
-python -c "import __graft_entry__ as g; g.smoke()"
+mkdir -p gpurun_out/r03k
+( time PBR_EXHAUSTIVE=1 timeout 1500 python -m pytest tests/test_gpu_math_exhaustive.py -x -q -m gpu ) > gpurun_out/r03k/math_exhaustive.txt 2>&1
+tail -6 gpurun_out/r03k/math_exhaustive.txt
+( time PBR_SOAK_SEEDS=6000 timeout 2400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k random_configurations ) > gpurun_out/r03k/soak.txt 2>&1
+tail -6 gpurun_out/r03k/soak.txt
