@@ -264,8 +264,8 @@ KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
 
 KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights );
 
-// Register budget when a schedule is forced (PBR_SCHEDULE) without PBR_VARIANT: scenes whose tree does
-// not fit the staged LDS prefix get "wide" (pt_kernel.hpp), small scenes "lean".  Unforced renders are auto-tuned.
+// Scenes whose tree does not fit the staged LDS prefix ("large": the walk is most of a bounce) and those whose tree
+// does ("small": shading is): the lock-step walk's park share and refill batch differ between the two.
 const uint32_t kWideMinNodes = 2048;
 
 // lock-step kernels: lanes of a wave that wait with a finished unit before they take their next units together.  Measured
@@ -507,9 +507,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		return PBR_OK;
 	};
 
-	// waveUnits: how many wave-sized pieces of work the launch has — tiles for the tile schedule, tiles x frames for
-	// the frame-parallel ones (a rank of an 8-GPU run has 4050 tiles at 1080p: fewer than the 6144 - 8192 resident
-	// waves, but 256 frames of them)
+	// waveUnits: how many wave-sized pieces of work the launch has — tiles x frames (a rank of an 8-GPU run has 4050
+	// tiles at 1080p: fewer than the 6144 - 8192 resident waves, but 256 frames of them)
 	auto run = [&]( const Plan& plan, size_t waveUnits ) -> int {
 		const size_t wavesPerBlock = (size_t) plan.blockThreads / 64;
 		const size_t needed = std::max<size_t>( 1, ( waveUnits + wavesPerBlock - 1 ) / wavesPerBlock );

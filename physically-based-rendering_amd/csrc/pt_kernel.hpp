@@ -4,11 +4,11 @@
 // per frame, accumulation through the host).  Here:
 //   * persistent waves (the grid is sized to the chip, not to the image) draw units of work — one
 //     frame of one pixel — from an XCD-banded queue (nextSlot); a lane whose path ends starts its next
-//     path, and a lane whose unit ends takes the next unit, in the same wave iteration;
+//     path, and a lane whose unit ends takes the next unit (the state machine at once, the lock-step
+//     kernels in batches);
 //   * a multi-frame render is ONE launch over all (pixel, frame) units; each writes {finalColor, focus}
-//     to a frame buffer and foldFrames applies the running mean (pt_rgb.cl:9-21) in frame order.  (The
-//     tile schedule, REFILL = false, keeps the older form: a wave walks a tile through all frames with
-//     the mean in registers.)  The framebuffer is tile-major (64 px x RGBA32F = 1 KiB per tile);
+//     to a frame buffer and foldFrames applies the running mean (pt_rgb.cl:9-21) in frame order.
+//     The framebuffer is tile-major (64 px x RGBA32F = 1 KiB per tile);
 //   * the BVH is a node stream of 32-B records with explicit successors, the most-visited records first
 //     and staged in LDS (decodeNode); the walk alternates a hand-scheduled node phase with a leaf phase
 //     for the lanes parked on hit leaves (traverse, nodePhaseAsm);
