@@ -717,6 +717,9 @@ PT_DEV void testLeaf( const DevParams& P, int face0, int face1, const Ray& ray, 
 	const TriRecord first = loadTri( P, face0 );
 	TriRecord second;
 
+	// (requested whether or not the leaf has a second face — the array is padded by one record.  Requesting it only for
+	// two-face leaves, 70 % of them, saves a third of the leaf phase's loads on the others: hairball +0.8 %, Dragon- and
+	// Sponza-class +-0, Cornell -0.9 % for the divergent branch — profiles/r03/experiments/eager_only_two_face_leaves.txt)
 	if( EAGER ) {
 		second = loadTri( P, face0 + 1 );
 	}
