@@ -79,9 +79,10 @@ def _load(path, builder):
 
 
 try:
-    if os.environ.get("PBR_HIP_LIB"):          # debugging aid: an alternative build of the same source
+    _lab = os.environ.get("PBR_LAB_ENV") == "1"   # lab runs only: no PBR_* variable steers a product process
+    if _lab and os.environ.get("PBR_HIP_LIB"):          # an alternative build of the same source (scripts/lab.sh)
         hip = ctypes.CDLL(os.environ["PBR_HIP_LIB"], mode=ctypes.RTLD_GLOBAL)
-    elif os.environ.get("PBR_GUARD") == "1":   # debugging aid: every device loop bounded (build.py)
+    elif _lab and os.environ.get("PBR_GUARD") == "1":   # every device loop bounded (build.py)
         hip = _load(_build.HIP_GUARD_LIB, lambda force=False: _build.build_hip(force, guard=True))
     else:
         hip = _load(_build.HIP_LIB, _build.build_hip)
@@ -295,8 +296,11 @@ class HostScene:
 # ----------------------------------------------------------------------------------------------
 
 # Lab scripts and A/B runs steer the library through environment variables; the LIBRARY reads none (include/pbr_hip_diag.h,
-# pbr_diag_set_knob) — this harness maps them onto knobs when a context is created.
+# pbr_diag_set_knob) — this harness maps them onto knobs when a context is created, and ONLY when PBR_LAB_ENV=1 says that
+# the process is a lab run (round 4: a stray PBR_* variable in a user's environment must not change the schedule of a
+# product render; scripts/*.py and scripts/*.sh set PBR_LAB_ENV themselves).
 _ENV_KNOBS = {
+    "PBR_ASYNC_EIGHTHS": "async_eighths",
     "PBR_LDS_SLOTS": "lds_slots", "PBR_BLOCKS_PER_CU": "blocks_per_cu", "PBR_PH_PARK": "ph_park", "PBR_PH_SHADE": "ph_shade",
     "PBR_PARK_EIGHTHS": "park_eighths", "PBR_DRAIN_MODE": "drain_mode", "PBR_REFILL_BATCH": "refill_batch",
     "PBR_CHUNK_FRAMES": "chunk_frames", "PBR_FACE_NORMALS": "face_normals", "PBR_PLOC_RADIUS": "ploc_radius", "PBR_TUNE_LOG": "tune_log",
@@ -314,11 +318,21 @@ class Device:
                 self._ctx = None
             raise PbrError(msg)
         self.width = self.height = 0
+        if os.environ.get("PBR_LAB_ENV") == "1":
+            self._apply_lab_environment()
+
+    def _apply_lab_environment(self):
+        """PBR_* variables -> knobs / pinned plan, for lab scripts (opt-in: PBR_LAB_ENV=1)."""
+        if not hasattr(hip, "pbr_diag_set_knob"):
+            raise PbrError("PBR_LAB_ENV=1, but this libpbrhip has no pbr_diag_set_knob")
         for var, knob in _ENV_KNOBS.items():
-            if os.environ.get(var) and hasattr(hip, "pbr_diag_set_knob"):
+            if os.environ.get(var):
                 self.set_knob(knob, int(os.environ[var]))
-        if os.environ.get("PBR_BVH_BUILDER"):
-            self.set_knob("bvh_builder", {"ploc": 0, "lbvh": 1}[os.environ["PBR_BVH_BUILDER"]])
+        builder = os.environ.get("PBR_BVH_BUILDER")
+        if builder:
+            if builder not in ("ploc", "lbvh"):
+                raise PbrError("PBR_BVH_BUILDER must be 'ploc' or 'lbvh', not %r" % builder)
+            self.set_knob("bvh_builder", {"ploc": 0, "lbvh": 1}[builder])
         if os.environ.get("PBR_PLAN"):
             self.pin_plan(int(os.environ["PBR_PLAN"]))
 

@@ -30,6 +30,7 @@ typedef void ( *KernelFn )( const ptk::DevParams );
 struct Plan {
 	KernelFn kernel = nullptr;
 	int blocks = 0, blockThreads = 0, numHot = 0, park = 0, shade = 0, parkEighths = 4;
+	bool async = false;     // the node phase polls per-lane LDS slots filled by LDS-DMA (pt_kernel.hpp, nodePhaseAsync)
 	size_t ldsBytes = 0;
 	const char* name = "";
 };
@@ -48,6 +49,7 @@ struct Knobs {
 	int bvhBuilder = -1;    // pbr_build_bvh: 1 = round 1's radix tree instead of the clustering builder
 	int plocRadius = -1;    // pbr_build_bvh: search radius of the clustering builder
 	int tuneLog = -1;       // 1 = the schedule tuner logs its launches to stderr
+	int asyncEighths = -1;  // asynchronous node phase: eighths of the walking lanes that must be ready before an iteration starts
 };
 
 struct pbr_ctx {
@@ -223,28 +225,40 @@ KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 #define PBR_WIDE_MINW 8
 #endif
 
-template<int MINW>
+template<int MINW, bool ASYNC = false>
 KernelFn pickKernelPhasedMode( uint32_t brdf, bool shadow, bool lights ) {
 #ifdef PBR_LAB
 	(void) brdf; (void) shadow; (void) lights;
-	return ptk::pathTracingPhased<1, false, false, MINW>;
+	return ptk::pathTracingPhased<1, false, false, MINW, ASYNC>;
 #else
 	if( brdf == 0 ) {
 		if( lights ) {
-			return shadow ? ptk::pathTracingPhased<0, true, true, MINW> : ptk::pathTracingPhased<0, false, true, MINW>;
+			return shadow ? ptk::pathTracingPhased<0, true, true, MINW, ASYNC> : ptk::pathTracingPhased<0, false, true, MINW, ASYNC>;
 		}
-		return ptk::pathTracingPhased<0, false, false, MINW>;
+		return ptk::pathTracingPhased<0, false, false, MINW, ASYNC>;
 	}
 
 	if( lights ) {
-		return shadow ? ptk::pathTracingPhased<1, true, true, MINW> : ptk::pathTracingPhased<1, false, true, MINW>;
+		return shadow ? ptk::pathTracingPhased<1, true, true, MINW, ASYNC> : ptk::pathTracingPhased<1, false, true, MINW, ASYNC>;
 	}
-	return ptk::pathTracingPhased<1, false, false, MINW>;
+	return ptk::pathTracingPhased<1, false, false, MINW, ASYNC>;
 #endif
 }
 
+// lab builds: -DPBR_ASYNC_LEAN / -DPBR_ASYNC_MID put the asynchronous node phase in the place of phased-lean / phased-mid
+#ifdef PBR_ASYNC_LEAN
+const bool kAsyncLean = true;
+#else
+const bool kAsyncLean = false;
+#endif
+#ifdef PBR_ASYNC_MID
+const bool kAsyncMid = true;
+#else
+const bool kAsyncMid = false;
+#endif
+
 KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) {
-	return wide ? pickKernelPhasedMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelPhasedMode<PBR_LEAN_MINW>( brdf, shadow, lights );
+	return wide ? pickKernelPhasedMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelPhasedMode<PBR_LEAN_MINW, kAsyncLean>( brdf, shadow, lights );
 }
 
 // the "mid" budget: <= 80 VGPRs, launched as two 768-thread blocks per CU = 6 waves / SIMD
@@ -259,7 +273,7 @@ const int kMidBlockThreads = PBR_MID_THREADS;
 
 
 KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
-	return pickKernelPhasedMode<kMidMinWaves>( brdf, shadow, lights );
+	return pickKernelPhasedMode<kMidMinWaves, kAsyncMid>( brdf, shadow, lights );
 }
 
 KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights );
@@ -461,7 +475,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// split between the blocks the register budget admits.  The experiment knobs (PBR_BLOCKS_PER_CU, PBR_LDS_SLOTS,
 	// PBR_PH_PARK, PBR_PH_SHADE, PBR_PARK_EIGHTHS, PBR_DRAIN_MODE) are read when the plans are built — once per
 	// scene + configuration — not per launch.
-	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK ) -> int {
+	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK, bool async = false ) -> int {
 		int blocksPerCU = 0;
 		HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, blockThreads, 0 ) );
 		blocksPerCU = ( blocksPerCU < 1 ) ? 1 : blocksPerCU;
@@ -473,7 +487,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		// a block's share of the CU's 160 KB, for the staged tree top
 		const size_t ldsPerCU = 160 * 1024;
 		const size_t share = ldsPerCU / (size_t) blocksPerCU - 256;
-		size_t slots = share / 32;
+		// asynchronous node phase: 32 B of the share per lane are the lanes' record slots (two planes of 1024 x 16 B)
+		const size_t slotBytes = async ? (size_t) 2 * PT_SLOT_PLANE : 0;
+		size_t slots = ( share - slotBytes ) / 32;
 		slots = std::min<size_t>( slots, ctx->numHotAvail );
 
 		if( knobs.ldsSlots >= 0 ) {
@@ -488,7 +504,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		plan->blockThreads = blockThreads;
 		plan->blocks = ctx->numCUs * blocksPerCU;   // all that are resident at once; run() launches fewer when there is less work
 		plan->numHot = (int) slots;
-		plan->ldsBytes = slots * 32;
+		plan->ldsBytes = slots * 32 + slotBytes;
+		plan->async = async;
 		plan->park = park;
 		plan->shade = shade;
 		plan->parkEighths = ( ctx->numNodes >= kWideMinNodes ) ? 4 : 6;   // see traverse(), pt_kernel.hpp
@@ -515,6 +532,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		const unsigned blocks = (unsigned) std::min<size_t>( (size_t) plan.blocks, needed );
 		P.numHot = plan.numHot;
 		P.numHotBytes = plan.numHot * 32;
+		P.slotBase = plan.numHot * 32;
+		// measured (profiles/r04/experiments/async_node_phase.txt): the share of the walking lanes an iteration waits for
+		P.asyncEighths = ( knobs.asyncEighths >= 1 ) ? std::min( 8, knobs.asyncEighths ) : 6;
+
+		if( plan.async && ( plan.numHot < 1 || ctx->firstRef >= plan.numHot * 32 ) ) {
+			return fail( ctx, PBR_ESTATE, "asynchronous node phase: the walk's first record must be staged in LDS" );
+		}
+
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
 		P.refillBatch = ( knobs.refillBatch >= 1 ) ? std::min( 64, knobs.refillBatch ) : ( ( ctx->numNodes >= kWideMinNodes ) ? kRefillBatchLarge : kRefillBatchSmall );
@@ -557,9 +582,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		Plan* plans = ctx->plans;
 		int status = makePlan( pickKernel( brdf, shadow, lights, true, false ), "refill-lean", 0, 0, &plans[0] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernel( brdf, shadow, lights, true, true ), "refill-wide", 0, 0, &plans[1] );
-		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2] );
+		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2], PBR_BLOCK, kAsyncLean );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 48, &plans[3] );
-		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhasedMid( brdf, shadow, lights ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads );
+		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhasedMid( brdf, shadow, lights ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads, kAsyncMid );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelMid( brdf, shadow, lights ), "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
 
 		if( status != PBR_OK ) {
@@ -1134,9 +1159,13 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 			w1 = refOf( (long long) i + 1 );
 		}
 
+		// every NaN of a box is stored as THE quiet NaN 0x7FC00000: the slab test only ever compares (a NaN's payload
+		// changes nothing), and the asynchronous node phase marks an empty record slot with the NaN 0xFFFFFFFF in a
+		// box word (pt_kernel.hpp, nodePhaseAsync) — a record must never look like an empty slot
+		auto boxWord = []( float x ) { return ( x != x ) ? __builtin_bit_cast( float, 0x7FC00000u ) : x; };
 		const size_t r = (size_t) recordOf[i];
-		nodes[r * 2 + 0] = make_float4( n.bbMin.x, n.bbMin.y, n.bbMax.x, n.bbMax.y );
-		nodes[r * 2 + 1] = make_float4( n.bbMin.z, n.bbMax.z, __builtin_bit_cast( float, w0 ), __builtin_bit_cast( float, w1 ) );
+		nodes[r * 2 + 0] = make_float4( boxWord( n.bbMin.x ), boxWord( n.bbMin.y ), boxWord( n.bbMax.x ), boxWord( n.bbMax.y ) );
+		nodes[r * 2 + 1] = make_float4( boxWord( n.bbMin.z ), boxWord( n.bbMax.z ), __builtin_bit_cast( float, w0 ), __builtin_bit_cast( float, w1 ) );
 	}
 
 	// ---- faces: gather the corners; store a, b - a, c - a (what pt_intersect.cl:98-99 computes) ----
@@ -2154,7 +2183,7 @@ int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value ) {
 		{ "lds_slots", &k.ldsSlots }, { "blocks_per_cu", &k.blocksPerCU }, { "ph_park", &k.phPark }, { "ph_shade", &k.phShade },
 		{ "park_eighths", &k.parkEighths }, { "drain_mode", &k.drainMode }, { "refill_batch", &k.refillBatch },
 		{ "chunk_frames", &k.chunkFrames }, { "face_normals", &k.faceNormals }, { "bvh_builder", &k.bvhBuilder },
-		{ "ploc_radius", &k.plocRadius }, { "tune_log", &k.tuneLog },
+		{ "ploc_radius", &k.plocRadius }, { "tune_log", &k.tuneLog }, { "async_eighths", &k.asyncEighths },
 	};
 
 	for( const auto& entry : table ) {

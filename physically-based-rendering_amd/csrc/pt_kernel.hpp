@@ -133,6 +133,8 @@ struct DevParams {
 	int numHot;             // records [0, numHot) of the node stream are resident in LDS
 	int numHotBytes;        // = numHot * 32: a record reference (byte offset) below this is resident
 	int firstRef;           // reference (byte offset) of node 1's record, where every walk starts
+	int slotBase;           // asynchronous node phase: LDS byte address of the lanes' record slots (= numHotBytes), nodePhaseAsync
+	int asyncEighths;       // ... and the share of the walking lanes (in eighths) that must be ready before an iteration starts
 	int nFrames, firstCount;
 	int useExplicitWeight;
 	float explicitWeight;
@@ -946,6 +948,172 @@ PT_DEV void nodePhaseAsm(
 #undef PT_NODE_PHASE_HEAD
 #undef PT_NODE_PHASE_TAIL
 #undef PT_NODE_PHASE_OPERANDS
+}
+
+// ---- the node phase, asynchronous (round 4) --------------------------------------------------------
+// nodePhaseAsm ends every iteration in `s_waitcnt vmcnt(0)`: it lasts as long as its SLOWEST lane's fetch.  Measured in
+// round 3 on the Sponza-class scene: an L1 miss comes back after 194 cycles on average, an iteration lasts ~900 — with
+// ~18 lanes on cold records and an L2 hit rate of 84 %, 96 % of all iterations contain at least one request that goes
+// on to the Infinity Cache or HBM, and 62 % of all wave-cycles are spent waiting.  s_waitcnt cannot wait for "most" of
+// a wave's lanes; a load to registers has no other way of telling that it has arrived.
+//
+// A load to LDS has: the bytes are simply there at some point.  Here every lane owns a 32-byte SLOT in LDS (two 16-byte
+// halves, PT_SLOT_PLANE apart, lane-linear — the only destination shape an LDS-DMA has: M0 + offset + 16 * lane).  A
+// lane whose next record is cold writes a marker into each half of its slot (the record's last word, w1, is a byte
+// offset or negative — never 1; the last word of the first half is a box coordinate — never the NaN 0xFFFFFFFF:
+// pbr_upload_scene stores every NaN of a box as 0x7FC00000, which no comparison can tell apart), requests the record
+// with two `global_load_lds_dwordx4` and goes on polling: every iteration
+// reads, for every walking lane, either the staged record (hot) or the lane's slot (cold), and the lanes whose record
+// is there — hot, or marker overwritten — take their visit; the others keep their state and are asked again in the
+// next iteration.  An iteration starts as soon as P.asyncEighths / 8 of the walking lanes are ready (else the wave
+// sleeps 64 cycles and polls again), so a far miss delays ITS lane, not the wave.  No wait on vmcnt anywhere in the loop.
+// Nothing orders a ds_read behind a pending LDS-DMA (MI355X_MICROARCH.md, item 7: "a read issued earlier returns the OLD
+// LDS bytes, no stall") — which is exactly the behaviour polled for.  Measured with scripts/micro/glds_poll.hip
+// (profiles/r04/experiments/glds_poll.txt, 6e9 records per variant, each checked word by word): a lane's 16 bytes land
+// at once, but the two halves of a record land IN EITHER ORDER (with a marker in the second half only, 0.02 % of the
+// records were consumed torn; with both, none) — hence the two markers.
+// Invariant between phases: a walking lane's cursor is either the reference of a staged record (< P.slotBase) or the
+// LDS address of its own slot, with the request issued (cold cursors are replaced by the slot address when the request
+// goes out; a lane that parks on a leaf has its next record requested before the leaf phase).  Per lane the sequence of
+// visits is the reference's; only which iteration a visit falls into changes.
+// Registers: v46-v63 as nodePhaseAsm; v64 = address of the second half - 16, v65 = this lane's slot + 12, v66 / v67 = the markers.
+// Scalars s84-s99 are the block's own (clobbered): saved exec, walking lanes, ready lanes, parked lanes, a temporary
+// mask, counts, the compiler's M0, the error flag (s83).
+#define PT_SLOT_PLANE 16384     // bytes between the two halves of a lane's slot: 1024 lanes x 16 B
+#if defined( PBR_DBG_NOREARM )
+#define PT_ASYNC_REARM ""
+#elif defined( PBR_DBG_REARM2 )
+#define PT_ASYNC_REARM "ds_write_b32 v65, v67\n" "ds_write_b32 v65, v66 offset:16384\n"
+#else
+#define PT_ASYNC_REARM "ds_write2st64_b32 v65, v67, v66 offset1:64\n"        // both markers back into this lane's slot (+ 12, + PT_SLOT_PLANE + 12)
+#endif
+#if defined( PBR_DBG_NOP )
+#define PT_ASYNC_NOP "s_nop 7\n"
+#else
+#define PT_ASYNC_NOP ""
+#endif
+#define PT_ASYNC_POLL_LIMIT 0x100000
+
+template<int DUMMY = 0>
+PT_DEV void nodePhaseAsync(
+	const DevParams& P, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep, int m0a,
+	int& ref, unsigned& visits, int& leafWord, float& leafTNear, int& parked, int& err
+) {
+	const float eps = EPSILON5;
+	keep = __builtin_amdgcn_readfirstlane( keep );
+	m0a = __builtin_amdgcn_readfirstlane( m0a );         // P.slotBase + 1024 * (wave of the block): + 16 * lane by the hardware
+
+	asm volatile(
+		"s_mov_b64 s[84:85], exec\n"
+		"s_mov_b64 s[86:87], exec\n"
+		"s_mov_b64 s[90:91], 0\n"
+		"s_mov_b32 s98, m0\n"
+		"s_mov_b32 s97, 0\n"
+		"s_mov_b32 s83, 0\n"
+		"s_add_u32 s99, %[m0a], 16368\n"                     // second half: M0 + offset:16 + 16 * lane = slot + PT_SLOT_PLANE
+		"v_mbcnt_lo_u32_b32 v65, -1, 0\n"
+		"v_mbcnt_hi_u32_b32 v65, -1, v65\n"
+		"v_lshl_add_u32 v65, v65, 4, %[m0a]\n"
+		"v_add_u32 v65, 12, v65\n"                           // this lane's slot + 12: its first marker
+		"v_mov_b32 v66, 1\n"
+		"v_mov_b32 v67, -1\n"
+		"v_add_u32 v64, 16356, v65\n"                        // slot + PT_SLOT_PLANE - 16
+		"v_cmp_gt_i32 vcc, %[slotBase], %[ref]\n"            // staged record?  else the cursor is the slot (request issued)
+		"v_cndmask_b32 v64, v64, %[ref], vcc\n"
+		"s_bcnt1_i32_b64 s95, exec\n"
+	"1:\n"
+		"s_mul_i32 s96, s95, %[eighths]\n"                    // lanes that must be ready for an iteration to start
+		"s_lshr_b32 s96, s96, 3\n"
+		"s_max_i32 s96, s96, 1\n"
+	"2:\n"
+		"ds_read_b128 v[46:49], %[ref]\n"
+		"ds_read_b128 v[50:53], v64 offset:16\n"
+		"s_waitcnt lgkmcnt(0)\n"
+		"v_cmp_ne_u32 vcc, 1, v53\n"                          // the record is there: staged, or BOTH markers are gone
+		"v_cmp_ne_u32 s[92:93], -1, v49\n"                   // (the halves land in either order, scripts/micro/glds_poll.hip)
+		"s_and_b64 vcc, vcc, s[92:93]\n"
+		"s_bcnt1_i32_b64 s94, vcc\n"
+		"s_cmp_ge_i32 s94, s96\n"
+		"s_cbranch_scc1 3f\n"
+		"s_add_i32 s97, s97, 1\n"
+		"s_cmp_gt_i32 s97, %[pollLimit]\n"
+		"s_cbranch_scc1 8f\n"
+		"s_sleep 1\n"
+		"s_branch 2b\n"
+	"3:\n"
+		"s_mov_b64 s[88:89], vcc\n"
+		"s_mov_b64 exec, vcc\n"
+		PT_ASYNC_REARM
+		"v_add_u32 %[visits], 1, %[visits]\n"
+		"v_pk_add_f32 v[54:55], v[46:47], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_add_f32 v[56:57], v[48:49], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_add_f32 v[58:59], v[50:51], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_mul_f32 v[54:55], %[ixy], v[54:55]\n"
+		"v_pk_mul_f32 v[56:57], %[ixy], v[56:57]\n"
+		"v_pk_mul_f32 v[58:59], %[izz], v[58:59]\n"
+		"v_min_f32 v60, v54, v56\n"
+		"v_min_f32 v61, v55, v57\n"
+		"v_min_f32 v62, v58, v59\n"
+		"v_max3_f32 v60, v60, v61, v62\n"
+		"v_max_f32 v61, v54, v56\n"
+		"v_max_f32 v63, v58, v59\n"
+		"v_max_f32 v62, v55, v57\n"
+		"v_min3_f32 v61, v61, v62, v63\n"
+		"v_cmpx_lt_f32 %[eps], v61\n"
+		"v_cmpx_gt_f32 %[rayT], v60\n"
+		"v_cmpx_le_f32 v60, v61\n"
+		"v_cmp_le_i32 vcc, 0, v52\n"                          // hit container
+		PT_ASYNC_NOP
+		"s_andn2_b64 s[92:93], exec, vcc\n"                   // hit leaf: parks
+		"s_or_b64 s[90:91], s[90:91], s[92:93]\n"
+		"s_mov_b64 exec, s[88:89]\n"
+		"v_cndmask_b32 %[ref], v53, v52, vcc\n"               // hit container -> w0, everything else -> w1
+		"v_mov_b32 v64, %[ref]\n"
+		"v_cmp_gt_i32 vcc, 0, %[ref]\n"                       // the walk has ended
+		"s_or_b64 s[92:93], s[92:93], vcc\n"
+		"s_andn2_b64 s[86:87], s[86:87], s[92:93]\n"
+		"v_cmp_le_i32 vcc, %[slotBase], %[ref]\n"             // next record cold: request it (parked lanes too)
+		"s_and_b64 exec, exec, vcc\n"
+		"s_cbranch_scc0 4f\n"
+		"s_waitcnt lgkmcnt(0)\n"                              // the marker is in the slot before the request leaves
+		"s_mov_b32 m0, %[m0a]\n"
+		"s_nop 0\n"
+		"global_load_lds_dwordx4 %[ref], %[nodes]\n"
+		"s_mov_b32 m0, s99\n"
+		"s_nop 0\n"
+		"global_load_lds_dwordx4 %[ref], %[nodes] offset:16\n"
+		"v_add_u32 %[ref], -12, v65\n"
+		"v_add_u32 v64, 16356, v65\n"
+	"4:\n"
+		"s_mov_b64 exec, s[86:87]\n"
+		"s_bcnt1_i32_b64 s95, s[86:87]\n"
+		"s_cmp_gt_i32 s95, %[keep]\n"
+		"s_cbranch_scc1 1b\n"
+	"5:\n"
+		"s_mov_b64 exec, s[84:85]\n"
+		"s_mov_b32 m0, s98\n"
+		"v_cndmask_b32 %[parked], 0, 1, s[90:91]\n"
+		"v_mov_b32 %[leafWord], v52\n"
+		"v_mov_b32 %[leafTNear], v60\n"
+		"v_mov_b32 %[err], s83\n"
+		"s_branch 7f\n"
+	"8:\n"                                                    // the poll limit: never hang a GPU
+		"s_waitcnt vmcnt(0)\n"
+		"s_cmp_eq_u32 s83, 0\n"
+		"s_mov_b32 s83, 1\n"
+		"s_mov_b32 s97, 0\n"
+		"s_cbranch_scc1 2b\n"
+		"v_mov_b32 %[ref], -1\n"
+		"s_branch 5b\n"
+	"7:\n"
+		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [parked] "=v"( parked ), [err] "=v"( err )
+		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ),
+		  [slotBase] "s"( P.slotBase ), [nodes] "s"( P.nodes ), [eps] "s"( eps ), [m0a] "s"( m0a ), [eighths] "s"( P.asyncEighths ),
+		  [pollLimit] "n"( PT_ASYNC_POLL_LIMIT )
+		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+		  "v64", "v65", "v66", "v67", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
+		  "vcc", "scc", "memory"
+	);
 }
 #endif
 
@@ -2069,11 +2237,22 @@ PT_DEV int startWalk( const DevParams& P, const Ray& ray, WalkState& w ) {
 	return MODE_NODE;
 }
 
-template<int BRDF, bool SHADOW, bool LIGHTS, int MINW>
+template<int BRDF, bool SHADOW, bool LIGHTS, int MINW, bool ASYNC = false>
 __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const DevParams P ) {
 	const float4* lds = gHotNodes;
 	PT_LAB_WAVE_BEGIN
 	stageHotNodes( P, gHotNodes );
+#ifdef PT_NODE_PHASE_ASM
+	// asynchronous node phase: every lane's slot starts out empty (marker in the last word of its second half);
+	// the slots of a wave are 1 KiB per half, lane-linear (nodePhaseAsync)
+	const int slotM0 = __builtin_amdgcn_readfirstlane( P.slotBase + (int) ( threadIdx.x >> 6 ) * 1024 );
+	int asyncErr = 0;
+
+	if( ASYNC ) {
+		*(volatile unsigned*) ( (char*) gHotNodes + P.slotBase + (int) threadIdx.x * 16 + 12 ) = 0xFFFFFFFFu;
+		*(volatile unsigned*) ( (char*) gHotNodes + P.slotBase + PT_SLOT_PLANE + (int) threadIdx.x * 16 + 12 ) = 1u;
+	}
+#endif
 
 	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
 	(void) total;
@@ -2145,7 +2324,15 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				int leafWord = 0, parkedFlag;
 				float unusedTFar;
 				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );   // through the leaf phase below
-				nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
+				if( ASYNC ) {
+					(void) unusedTFar;
+					int phaseErr;
+					nodePhaseAsync( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, slotM0, w.cur.ref, visits, leafWord, w.leafTNear, parkedFlag, phaseErr );
+					asyncErr |= phaseErr;
+				}
+				else {
+					nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
+				}
 				st.dbgNodes += visits;
 				PT_LAB_PHASED_NODE_MID
 
@@ -2245,6 +2432,16 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 	}
 
 	flushCounters( P, cnt );
+#ifdef PT_NODE_PHASE_ASM
+	if( ASYNC ) {
+		// every request has been consumed by the lane that made it; a block's LDS must not be handed on with a DMA in flight
+		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+
+		if( asyncErr != 0 && P.guard != nullptr ) {
+			atomicAdd( &P.guard[1], 1u );      // a slot never filled: the render is reported as failed (pbr_hip.hip, launch())
+		}
+	}
+#endif
 	PT_LAB_PHASED_END( P )
 	PT_LAB_WAVE_END_PHASED( P )
 }

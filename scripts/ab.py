@@ -3,13 +3,14 @@
 speed AND for bit-identical results.  usage: python scripts/ab.py [scene:frames ...]"""
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import numpy as np
 import pbr_loader
 pbr = pbr_loader.load()
 
 SCENES = {"cornell": ("cornell", 1, 0, 8), "sponza": ("sponza", 2, 260000, 3), "dragon": ("dragon", 1, 870000, 3), "hairball": ("hairball", 3, 2000000, 3)}
 jobs = sys.argv[1:] or ["cornell:64", "sponza:32", "dragon:32", "hairball:16"]
-tag = os.path.basename(os.environ.get("PBR_HIP_LIB", "default")) + "/" + os.environ.get("PBR_SCHEDULE", "auto")
+tag = os.path.basename(os.environ.get("PBR_HIP_LIB", "default")) + "/" + ("plan " + os.environ["PBR_PLAN"] if os.environ.get("PBR_PLAN") else "auto")
 W, H = 1920, 1080
 for job in jobs:
     name, frames = job.split(":"); frames = int(frames)

@@ -1,6 +1,7 @@
 """Known-traffic kernels for interpreting the memory PMC counters (run under rocprofv3 --pmc)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import pbr_loader
 pbr = pbr_loader.load()
 hip = pbr.hip

@@ -5,6 +5,7 @@ the mean gap between the end of one call's last kernel and the start of the next
 import csv, glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 
 if len(sys.argv) > 2 and sys.argv[1] == "--report":
     rows = []

@@ -2,6 +2,7 @@
 node stream does a walk touch, and would a hot set chosen from MEASURED visit counts beat the surface-area ranking?  usage: python scripts/layout_study.py [scene] [rays]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import numpy as np
 import pbr_loader
 pbr = pbr_loader.load()

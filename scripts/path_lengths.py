@@ -3,6 +3,7 @@ face tests (pathtracing.cl:73-78).  The end of a launch lasts as long as the lon
 dry (DESIGN.md "How a launch ends").  usage: python scripts/path_lengths.py [scene ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import numpy as np
 import pbr_loader
 pbr = pbr_loader.load()

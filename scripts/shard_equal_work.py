@@ -2,6 +2,7 @@
 as a unit of the whole frame?  usage: python scripts/shard_equal_work.py [plan]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import pbr_loader
 pbr = pbr_loader.load()
 W, H = 1920, 1080

@@ -3,6 +3,7 @@ the scaling efficiency the kernel side alone would give, T(1) / (N x T(N)) (no g
 usage: python scripts/shard_scaling.py [scene] [frames]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import pbr_loader
 pbr = pbr_loader.load()
 W, H = 1920, 1080

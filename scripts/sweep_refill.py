@@ -2,6 +2,7 @@
 (knob refill_batch; 1 = every lane at once, as up to round 2).  usage: python scripts/sweep_refill.py [scene:frames:plan ...]"""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import numpy as np
 import pbr_loader
 pbr = pbr_loader.load()

@@ -2,6 +2,7 @@
 the 100 MHz wall clock.  usage: PBR_HIP_LIB=lab/libpbrhip_tail.so PBR_PLAN=4 python scripts/tail_profile.py [scene:frames ...]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import numpy as np
 import pbr_loader
 pbr = pbr_loader.load()

@@ -3,6 +3,7 @@ per pixel, summed over a few frames), then max / mean over the ranks for candida
 usage: python scripts/tile_balance.py [scene]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import numpy as np
 import pbr_loader
 pbr = pbr_loader.load()

@@ -1,5 +1,6 @@
 import os, sys
 sys.path.insert(0, os.getcwd())
+os.environ.setdefault("PBR_LAB_ENV", "1")   # lab script: PBR_* variables are mapped onto the library's knobs (package __init__)
 import pbr_loader
 pbr = pbr_loader.load()
 W, H = 1920, 1080

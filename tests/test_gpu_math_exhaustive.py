@@ -1,10 +1,10 @@
 """Every float32 there is through the one-argument functions of the arithmetic layer: the HIP
 implementations (csrc/pt_math.hpp via pbr_diag_math) against the oracle's, bit for bit, for all 2^32 inputs of sin, cos,
 tan, acos, atan and the RNG's hash step; a billion random pairs through pow; 64 random materials x 2^18 directions
-through the BRDF and new-ray stages.  Minutes of CPU on the GPU box's host
-cores, so all of it only runs when asked for: PBR_EXHAUSTIVE=1 python -m pytest tests/test_gpu_math_exhaustive.py -m gpu;
-the default suite runs the 2^32 sweeps of sin and of the RNG's hash step
-(log of the round's run: profiles/r02/math_exhaustive.txt)."""
+through the BRDF and new-ray stages.  Since round 4 ALL of it runs in the default GPU suite (pow, acos,
+atan and tan are the builtins the default BRDF's sampling lives on, pt_brdf.cl:278-330, and a builder-run log is not
+driver-run evidence): nine tests, 87 s on the GPU box with its host cores checking against the oracle
+(profiles/r04/math_exhaustive.txt).  PBR_QUICK=1 skips them for a fast local iteration."""
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -12,10 +12,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-opt_in = pytest.mark.skipif(os.environ.get("PBR_EXHAUSTIVE") != "1", reason="set PBR_EXHAUSTIVE=1 (takes minutes)")
-# sin and the RNG's hash step feed every random number of the path (pt_utils.cl:39-44): all 2^32 inputs of both run in
-# the default suite (~11 s each on the GPU box); the other functions and the pair / stage soaks are opt-in.
-ALWAYS = ("sin", "randhash")
+quick = pytest.mark.skipif(os.environ.get("PBR_QUICK") == "1", reason="PBR_QUICK=1: the exhaustive sweeps are skipped")
 
 CHUNK = 1 << 26          # 256 MB of inputs per device call
 PIECE = 1 << 20          # the oracle is single-threaded per call (ctypes releases the GIL): pieces on a thread pool
@@ -33,7 +30,8 @@ def same_bits(a, b):
     return (ai == bi) | (np.isnan(a) & np.isnan(b))
 
 
-@pytest.mark.parametrize("op", [pytest.param(op, marks=() if op in ALWAYS else opt_in) for op in ["sin", "cos", "tan", "acos", "atan", "randhash"]])
+@quick
+@pytest.mark.parametrize("op", ["sin", "cos", "tan", "acos", "atan", "randhash"])
 def test_every_float32(pbr, oracle, gpu_device, op):
     dev = pbr.Device(gpu_device)
     threads = min(64, os.cpu_count() or 8)
@@ -50,7 +48,7 @@ def test_every_float32(pbr, oracle, gpu_device, op):
     dev.close()
 
 
-@opt_in
+@quick
 def test_a_billion_pow_pairs(pbr, oracle, gpu_device):
     """pow( x, y ) as the BRDFs use it (pt_brdf.cl: bases in [0, 1] and a little above, exponents from 1e-3 to the
     nu = nv = 100000 of suzanne.mtl, negative ones, and raw bit patterns for the special cases)."""
@@ -75,7 +73,7 @@ def test_a_billion_pow_pairs(pbr, oracle, gpu_device):
     dev.close()
 
 
-@opt_in
+@quick
 @pytest.mark.parametrize("brdf", [1, 0])
 def test_brdf_and_new_ray_stage_soak(pbr, oracle, gpu_device, brdf):
     """64 random materials x 2^18 random (arriving, leaving, normal) triples through the BRDF evaluation and the

@@ -732,7 +732,7 @@ def test_guard_build_with_the_cxx_node_phase_gives_the_same_bits(pbr, device, tm
         "    dev.render(0, pbr.frame_seeds(0, 3), pbr.pixel_dimension(%d, %d), sc.camera())\n"
         "    assert dev.guard_trips() == [0, 0, 0], (plan, dev.guard_trips())\n"
         "    assert np.array_equal(dev.read_output(), first, equal_nan=True), plan\n" % (ROOT, w, h, w, h, str(tmp_path / "guarded.npy"), w, h))
-    env = dict(os.environ, PBR_GUARD="1")
+    env = dict(os.environ, PBR_GUARD="1", PBR_LAB_ENV="1")
     done = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0, done.stderr[-2000:]
     got = np.load(tmp_path / "guarded.npy")
