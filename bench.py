@@ -42,7 +42,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4 copy ~6290
 HBM_ACHIEVABLE_GBS = 6300.0
-L2_PEAK_GBS = 18000.0   # rows of an L2-resident table gathered by every workgroup: 16.8-18.8 TB/s (MI355X_MICROARCH.md)
+# The L2's ceiling for THIS access shape, in requests per second: TCC_REQ of scripts/micro/gather_rate.hip's dependent random
+# 32-B gathers from a 2 MiB (L2-resident) table at full occupancy / its duration, rocprofv3 --pmc TCC_REQ_sum
+# (profiles/r04/experiments/l2_request_ceiling.txt).  Round 3 priced every TCC_REQ at 128 B against the guide's 18 TB/s of
+# L2-resident row gathers and reported fractions of 1.07 and 1.19: TCC requests are not all 128 B.
+L2_REQUEST_CEILING = 226e9
 NUM_SIMDS = 1024        # 256 CUs x 4
 
 WORKLOADS = {
@@ -62,18 +66,35 @@ def algorithmic_bytes(counters, pixel_frames, samples_per_frame=1):
 
 GATHER_CEILING_LINES = 56e9   # random dependent 32-B gathers from a table beyond L2, 128-B lines per second (scripts/micro/gather_rate.hip: 55-57 G/s)
 
-# what the counters say binds the kernel on each workload; "hbm" is the contract's ceiling for this path
-MEASURED_BOUND = {"cornell": "vector issue (77 % busy at 47 % of the lanes)",
-                  "sponza": "slowest lane's fetch per node phase (cache-resident: L2 hit 84 %, 62 % of wave-cycles waiting)",
-                  "dragon": "fabric bandwidth (5.0 TB/s of reads = 63 % of the HBM peak, 80 % of a streaming copy's rate)",
-                  "hairball": "L2 request rate (21 TB/s of 128-B lines, above the guide's L2-resident gather rate)"}
+def measured_bound(fabric_frac, l2_frac, valu_busy):
+    """What the counters of the profiled launch say binds the kernel (computed, not a table of
+    strings): `fabric` when the traffic behind L2 reaches half the HBM peak, `l2-requests` when the L2 takes requests at
+    90 % of its measured ceiling, `issue` when the vector ALU is 70 % busy, else `latency` (waves wait for dependent
+    fetches with every one of those resources to spare)."""
+    if fabric_frac is not None and fabric_frac >= 0.5:
+        return "fabric"
+    if l2_frac is not None and l2_frac >= 0.9:
+        return "l2-requests"
+    if valu_busy is not None and valu_busy >= 0.7:
+        return "issue"
+    return "latency"
+
+
+def library_stamp():
+    """Digest of the sources + flags the loaded csrc/libpbrhip.so was built from (build.py keeps it next to the library)."""
+    try:
+        with open(os.path.join(ROOT, "physically-based-rendering_amd", "csrc", "libpbrhip.so.srchash")) as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 def recorded_traffic(scene, w, h, depth, brdf):
     """Fabric-side bytes PER SAMPLE from the committed PMC passes (profiles/rNN/pmc_traffic.json: rocprofv3 --pmc in
     separate runs; read = 128 x TCC_EA0_RDREQ_128B + 64 x _64B + 32 x _32B = 2 x FETCH_SIZE[KB] x 1024 on gfx950,
     write = WRITE_SIZE, calibrated with scripts/calibrate.py) of the newest round that profiled exactly this workload;
-    None otherwise (PMC counters cannot be read from inside this run)."""
+    None otherwise (PMC counters cannot be read from inside this run).  Every record carries the digest of the library
+    it profiled (`srchash`) and the schedule: roofline_block refuses a record of another build or another schedule."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         try:
@@ -86,7 +107,7 @@ def recorded_traffic(scene, w, h, depth, brdf):
     return None
 
 
-def roofline_block(scene, plan, traffic, algo_launch, per_launch_samples, kernel_s):
+def roofline_block(scene, plan, traffic, algo_launch, per_launch_samples, kernel_s, stamp="unchecked"):
     """The roofline of the dominant kernel, physical: `achieved` = bytes the memory system moved behind L2 for one launch
     (fabric reads + writes from the committed PMC passes of this workload — `traffic`, a record of
     profiles/rNN/pmc_traffic.json — Infinity-Cache hits included, scaled to this run's samples) / the launch's duration
@@ -98,10 +119,21 @@ def roofline_block(scene, plan, traffic, algo_launch, per_launch_samples, kernel
         "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
         "kernel": "ptk::pathTracingPhased" if plan.startswith("phased") else "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
         "algorithmic_bytes_per_launch": algo_launch, "algorithmic_GBs": algo_launch / kernel_s / 1e9,
-        "bound_measured": MEASURED_BOUND.get(scene),
+        "bound_measured": None,      # no counters, no claim
     }
     if traffic is None:
         return roofline
+    # counters of ANOTHER build of the kernels, or of another schedule, price nothing: say so instead of printing a
+    # confident fraction (stamp = library_stamp() of the loaded library; "unchecked" only from tests of the arithmetic)
+    stale = []
+    if stamp != "unchecked" and traffic.get("srchash") != stamp:
+        stale.append("profiled library %s, loaded library %s" % (str(traffic.get("srchash"))[:12], str(stamp)[:12]))
+    if traffic.get("schedule") != plan:
+        stale.append("profiled schedule %s, this run %s" % (traffic.get("schedule"), plan))
+    if stale:
+        roofline.update({"traffic_stale": True, "traffic_stale_why": "; ".join(stale), "traffic_source": traffic["source"]})
+        return roofline
+    roofline["traffic_stale"] = False
     scale = per_launch_samples / (traffic["width"] * traffic["height"] * traffic["steps"])      # this launch's samples / the profiled launch's
     per_launch = traffic["bytes_per_sample"] * per_launch_samples
     lines = traffic["fabric_read_bytes_per_launch"] / 128.0 * scale
@@ -126,8 +158,17 @@ def roofline_block(scene, plan, traffic, algo_launch, per_launch_samples, kernel
         }
     if traffic.get("l2_requests_per_launch"):
         req = traffic["l2_requests_per_launch"] * scale
-        roofline["l2"] = {"request_GBs": req * 128.0 / kernel_s / 1e9, "peak": L2_PEAK_GBS, "frac": req * 128.0 / kernel_s / 1e9 / L2_PEAK_GBS,
-                          "hit_rate": traffic.get("l2_hit_rate"), "note": "TCC_REQ x 128 B against the 17-19 TB/s the guide measures for L2-resident gathers"}
+        roofline["l2"] = {"requests_per_s": req / kernel_s, "peak": L2_REQUEST_CEILING, "frac": min(1.0, req / kernel_s / L2_REQUEST_CEILING),
+                          "hit_rate": traffic.get("l2_hit_rate"),
+                          "note": "TCC_REQ per second against the request rate of dependent random 32-B gathers from an L2-resident table (scripts/micro/gather_rate.hip under rocprofv3 --pmc TCC_REQ_sum)"}
+    verdict = measured_bound(roofline["frac"], roofline.get("l2", {}).get("frac"), roofline.get("issue", {}).get("valu_busy"))
+    roofline["bound_measured"] = {
+        "value": verdict, "fabric_frac": roofline["frac"], "l2_frac": roofline.get("l2", {}).get("frac"),
+        "valu_busy": roofline.get("issue", {}).get("valu_busy"), "wave_wait_fraction": roofline.get("issue", {}).get("wave_wait_fraction"),
+        "rule": "fabric if fabric_frac >= 0.5, else l2-requests if l2_frac >= 0.9, else issue if valu_busy >= 0.7, else latency",
+    }
+    # "hbm" only where it is true: the traffic behind L2 is what binds; otherwise the measured bound
+    roofline["bound"] = "hbm" if verdict == "fabric" else verdict
     return roofline
 
 
@@ -140,7 +181,9 @@ def cpu_baseline(pbr, scene, cfg, cam, px, budget_s):
     the same workload: whole frames of the same scene / resolution / depth until ~budget_s."""
     from oracle import oracle
     cores = os.cpu_count() or 1
-    ref = oracle.Renderer(scene.desc, cfg, threads=cores)
+    # the timing build: -O3 -march=native -ffp-contract=off, compiled on this machine (SURVEY 8(d); the portable -O2 -mavx2
+    # library the tests use stays the checker); falls back to the portable one where there is no compiler
+    ref = oracle.Renderer(scene.desc, cfg, threads=cores, native=True)
     frames, t0, elapsed = 0, time.perf_counter(), 0.0
     # a band of rows per call keeps each call short; whole frames are what is reported
     while True:
@@ -154,8 +197,9 @@ def cpu_baseline(pbr, scene, cfg, cam, px, budget_s):
     samples = cfg.width * cfg.height * frames
     return {
         "value": samples / elapsed / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": "%d frame(s) of the same %dx%d workload in %.1f s (oracle/pt_oracle.c, OpenMP, %d threads)" % (
-            frames, cfg.width, cfg.height, elapsed, cores),
+        "sample": "%d frame(s) of the same %dx%d workload in %.1f s (oracle/pt_oracle.c, OpenMP, %d threads, %s)" % (
+            frames, cfg.width, cfg.height, elapsed, cores,
+            "gcc -O3 -march=native -ffp-contract=off, built on this host" if ref.native else "gcc -O2 -mavx2 -mfma -ffp-contract=off"),
     }
 
 
@@ -168,42 +212,97 @@ def elect_plan(votes):
     return max(valid, key=lambda v: (valid.count(v), -valid.index(v)))
 
 
+_PORT_HOLDERS = []     # launch_ranks: the rendezvous port stays reserved while the parent lives
+
+
 def launch_ranks(n, argv, popen=subprocess.Popen, environ=None):
     """`--gpus N` without a launcher: start the N ranks ourselves — N copies of this script with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, the rendezvous on 127.0.0.1 — and return the child processes.  Runs in
     a parent that has not imported torch or the HIP library: a process that has initialised the GPU must neither fork
     nor exec.  Rank 0 inherits stdout (its one JSON line is the run's output); the other ranks' stdout goes to stderr."""
     environ = dict(os.environ if environ is None else environ)
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # The rendezvous port: bound here (SO_REUSEADDR, never listening) and KEPT bound for the parent's lifetime, so that
+    # nothing else on the machine is handed the number; rank 0's store binds and listens on it with SO_REUSEADDR too,
+    # which Linux allows while the other holder does not listen (checked with torch's TCPStore: it binds, accepts and
+    # serves while this socket is open).  Round 3 bound, closed and handed the number on: a window of a process start.
+    holder = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    holder.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    holder.bind(("127.0.0.1", 0))
+    port = holder.getsockname()[1]
+    _PORT_HOLDERS.append(holder)
     procs = []
     for rank in range(n):
         env = dict(environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's only working transport on this pool
+        # dmabuf IPC.  Where this comes from: the build's environment notes for this GPU pool ("the host driver only
+        # supports dmabuf IPC, and without it RCCL / CUDA-tensor sharing across processes fails with
+        # hipIpcGetMemHandle: invalid argument"; the variable is exported on the pool's boxes already).  This build has
+        # never had two devices to exercise it on: it is passed on, not verified.
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # every rank in its own session: the parent can end a rank AND whatever it started (start_new_session)
         procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                           stdout=None if rank == 0 else sys.stderr))
+                           stdout=None if rank == 0 else sys.stderr, start_new_session=True))
     return procs
 
 
-def wait_ranks(procs, poll_s=0.05):
-    """Wait for every rank; the first one that fails ends the others (their exact PIDs), and its code is the run's."""
-    code = 0
-    while any(p.poll() is None for p in procs):
-        failed = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
-        if failed:
-            code = failed[0]
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
-                try:
-                    p.wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(poll_s)
+def end_ranks(procs, grace_s=10.0):
+    """Terminate the ranks that still run (their exact PIDs), wait, then kill what is left."""
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    deadline = time.monotonic() + grace_s
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.0, deadline - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+    for p in procs:
+        if p.poll() is None:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                pass
+
+
+def wait_ranks(procs, poll_s=0.05, limit_s=None):
+    """Wait for every rank; the first one that fails ends the others (their exact PIDs), and its code is the run's.
+    SIGTERM / SIGINT to this parent (a `timeout` around `python bench.py --gpus 8` signals only the parent) end the ranks
+    before the parent exits — no orphans holding the GPUs in a half-finished all-gather —, and so does the wall-clock
+    limit `limit_s`, after which the run fails with code 124."""
+    import signal
+    stop = {"signal": None}
+
+    def on_signal(signum, _frame):
+        stop["signal"] = signum
+
+    previous = {}
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            previous[sig] = signal.signal(sig, on_signal)
+        except ValueError:          # not the main thread (tests): no handlers, the rest works as before
+            pass
+    code, started = 0, time.monotonic()
+    try:
+        while any(p.poll() is None for p in procs):
+            failed = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+            if failed:
+                code = failed[0]
+                end_ranks(procs)
+                break
+            if stop["signal"] is not None:
+                sys.stderr.write("bench.py: signal %d — ending %d rank(s)\n" % (stop["signal"], sum(p.poll() is None for p in procs)))
+                end_ranks(procs)
+                code = 128 + stop["signal"]
+                break
+            if limit_s is not None and time.monotonic() - started > limit_s:
+                sys.stderr.write("bench.py: the ranks did not finish within %.0f s — ending them\n" % limit_s)
+                end_ranks(procs)
+                code = 124
+                break
+            time.sleep(poll_s)
+    finally:
+        for sig, handler in previous.items():
+            signal.signal(sig, handler)
     for p in procs:
         if p.returncode not in (0, None) and code == 0:
             code = p.returncode
@@ -226,9 +325,11 @@ def main():
                     help="gloo + --one-device: rehearse the N > 1 path on a single GPU (tests); the gather then goes through host memory")
     ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
     ap.add_argument("--repeats", type=int, default=0, help="repetitions of the K-step render (0 = until 250 ms have been timed, at most 15); the median is reported")
-    ap.add_argument("--plan", type=int, default=int(os.environ.get("PBR_PLAN", "-1")),
+    ap.add_argument("--plan", type=int, default=-1,
                     help="pin schedule 0..5 (refill-lean, refill-wide, phased-lean, phased-wide, phased-mid, refill-mid) instead of tuning; profiling runs")
     ap.add_argument("--dump", default="", help="rank 0 writes the gathered / rendered frame to this .npy")
+    ap.add_argument("--rank-limit", type=float, default=1500.0, help="self-launched ranks (--gpus N without a launcher): wall-clock seconds after which the parent ends them and fails")
+    ap.add_argument("--hold-seconds", type=float, default=3.0, help="N = 1: keep the GPU rendering (untimed) this long after the timed region, so that an outside utilisation sampler sees the GPU leg at all")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,7 +337,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes the parent of N ranks.  Nothing GPU-related has been imported yet.
-        sys.exit(wait_ranks(launch_ranks(args.gpus, sys.argv[1:])))
+        sys.exit(wait_ranks(launch_ranks(args.gpus, sys.argv[1:]), limit_s=args.rank_limit))
     if world != args.gpus:
         args.gpus = world
 
@@ -268,6 +369,13 @@ def main():
     dev = pbr.Device(local_rank)
     dev.upload_scene(scene.desc)
     dev.configure(cfg)
+
+    # The CPU baseline leg FIRST (rank 0 of a one-GPU run): the GPU leg then ends the process, and an outside utilisation
+    # sampler that looks at the last seconds of the run sees the GPU at work, not 12 s of host cores (BENCH_r03: gpu_busy 0
+    # on all samples — the 0.3 s GPU leg came first).  What a baseline has to time: PathTracer.cpp:43-71, one frame per call.
+    baseline = None
+    if world == 1 and rank == 0 and args.cpu_seconds > 0:
+        baseline = cpu_baseline(pbr, scene, scene.config(w, h), cam, px, args.cpu_seconds)
 
     gather_out = gather_in = None
     if world > 1:
@@ -356,6 +464,16 @@ def main():
     repeats = len(runs)
 
     counters = diff(dev.counters(), before)
+    if rank == 0 and args.dump:
+        np.save(args.dump, dev.read_full() if world > 1 else dev.read_output())
+    # untimed: keep rendering for --hold-seconds, so that a sampler with a period of a second or two sees the GPU leg at all
+    # (the timed region of the driver's command is 0.3 s)
+    held_frames = 0
+    if world == 1 and args.hold_seconds > 0:
+        t_hold = time.perf_counter()
+        while time.perf_counter() - t_hold < args.hold_seconds:
+            dev.render(first + held_frames, pbr.frame_seeds(first + held_frames, args.steps), px, cam)
+            held_frames += args.steps
     # per repetition: max over ranks of the elapsed time and of the average launch duration; then the median repetition
     per_run = [[r["elapsed"], r["trace_ms"] / r["launches"] / 1e3, r["render"], r["elapsed"] - r["render"]] for r in runs]
     totals = [float(counters["nodes"]), float(counters["tris"]), float(counters["hits"]), float(counters["paths"])]
@@ -388,7 +506,7 @@ def main():
         # trace_launches of them per render; the slowest rank's average launch duration
         algo_launch = algo / world / trace_launches          # SURVEY 8(d)'s per-sample figure x the samples one launch processes
         traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf))
-        roofline = roofline_block(args.scene, plan, traffic, algo_launch, samples / world / trace_launches, kernel_s)
+        roofline = roofline_block(args.scene, plan, traffic, algo_launch, samples / world / trace_launches, kernel_s, stamp=library_stamp())
         out = {
             "metric": "Msamples/s (paths/s) @1080p fixed seed; 1/2/4/8 MI355X scaling",
             "value": samples / elapsed / 1e6,
@@ -423,11 +541,9 @@ def main():
             out["per_rank_ms"] = rank_ms
         if plan_votes is not None:
             out["plan_votes"] = plan_votes
-        if world == 1 and args.cpu_seconds > 0:
-            cfg1 = scene.config(w, h)
-            out["cpu_baseline"] = cpu_baseline(pbr, scene, cfg1, cam, px, args.cpu_seconds)
-        if args.dump:
-            np.save(args.dump, dev.read_full() if world > 1 else dev.read_output())
+        if baseline is not None:
+            out["cpu_baseline"] = baseline
+        out["held_frames_untimed"] = held_frames
         print(json.dumps(out), flush=True)
 
     if world > 1:

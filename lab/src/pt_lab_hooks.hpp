@@ -109,6 +109,30 @@
 		for( int k_ = 0; k_ < 8; k_++ ) { atomicAdd( &P.counters[4 + k_], (unsigned long long) tlLanes[k_] ); } \
 		for( int k_ = 0; k_ < 4; k_++ ) { atomicAdd( &P.counters[12 + k_], (unsigned long long) tlRounds[k_] ); } \
 	}
+#elif defined( PBR_EXP_LEAFHIST )
+// round 4: how many lanes stand on a leaf when a node phase ends — a histogram over the leaf phases
+// (slots 4..11: 0, 1-4, 5-8, 9-12, 13-16, 17-24, 25-32, 33+ parked lanes), node phases (12), parked lanes (13), lanes whose
+// walk ended in the phase (14), lanes that entered (15)
+#define PT_LAB_PHASED_BEGIN unsigned lhHist[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, lhPhases = 0, lhParked = 0, lhFinished = 0, lhEntered = 0;
+#define PT_LAB_PHASED_STAT( what )
+#define PT_LAB_PHASED_NODE_BEGIN( mode )
+#define PT_LAB_PHASED_NODE_MID \
+	{ \
+		const int np_ = __popcll( __ballot( parkedFlag != 0 ) ); \
+		const int nf_ = __popcll( __ballot( parkedFlag == 0 && w.cur.ref < 0 ) ); \
+		const int b_ = ( np_ == 0 ) ? 0 : ( np_ <= 16 ) ? ( np_ + 3 ) / 4 : ( np_ <= 32 ) ? 5 + ( np_ - 17 ) / 8 : 7; \
+		lhHist[b_]++; lhPhases++; lhParked += (unsigned) np_; lhFinished += (unsigned) nf_; lhEntered += (unsigned) __popcll( __ballot( 1 ) ); \
+	}
+#define PT_LAB_PHASED_LEAF_END
+#define PT_LAB_PHASED_NODE_END
+#define PT_LAB_PHASED_SHADE_BEGIN
+#define PT_LAB_PHASED_SHADE_END
+#define PT_LAB_PHASED_END( P ) \
+	if( ( threadIdx.x & 63u ) == 0u ) { \
+		for( int k_ = 0; k_ < 8; k_++ ) { atomicAdd( &P.counters[4 + k_], (unsigned long long) lhHist[k_] ); } \
+		atomicAdd( &P.counters[12], (unsigned long long) lhPhases ); atomicAdd( &P.counters[13], (unsigned long long) lhParked ); \
+		atomicAdd( &P.counters[14], (unsigned long long) lhFinished ); atomicAdd( &P.counters[15], (unsigned long long) lhEntered ); \
+	}
 #elif defined( PBR_EXP_PHASE_TIME )
 // clock64 = the shader clock; taken where the wave is converged
 #define PT_LAB_PHASED_BEGIN unsigned long long phaseTime[3] = { 0ull, 0ull, 0ull }; const long long phaseStart = clock64();

@@ -33,6 +33,39 @@ def build(force=False):
     return _LIB
 
 
+def _cpu_tag():
+    """A name for THIS machine's CPU: a library built with -march=native must never be loaded on another one (built
+    libraries travel with the tree to the GPU box)."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            text = f.read()
+        lines = [l for l in text.splitlines() if l.startswith(("model name", "flags"))][:2]
+    except OSError:
+        lines = []
+    import platform
+    return hashlib.sha1(("\n".join(lines) + platform.machine()).encode()).hexdigest()[:10]
+
+
+def build_native():
+    """The baseline leg's build (bench.py, cpu_baseline): -O3 -march=native, as SURVEY 8(d) planned for the CPU timing —
+    compiled ON the machine that times it, under a name that carries that machine's CPU, next to the portable library the
+    tests check everything against.  -ffp-contract=off stays: same bits (tests/test_oracle_kernel.py compares the two)."""
+    target = os.path.join(_HERE, "liboracle_native_%s.so" % _cpu_tag())
+    stale = not os.path.exists(target) or any(os.path.getmtime(s) > os.path.getmtime(target) for s in _SRC)
+    if stale:
+        tmp = "%s.%d.tmp" % (target, os.getpid())
+        try:
+            subprocess.check_call([
+                "gcc", "-O3", "-march=native", "-std=c11", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
+                "-o", tmp, _SRC[0], "-lm"])
+            os.replace(tmp, target)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    return target
+
+
 class OrcConfig(ctypes.Structure):
     _fields_ = [
         ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("brdf", ctypes.c_int32),
@@ -57,6 +90,20 @@ class OrcCounters(ctypes.Structure):
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _lib = None
+_native = None
+
+
+def native_lib():
+    """The -O3 -march=native build (build_native), for timing; None where it cannot be built (no gcc)."""
+    global _native
+    if _native is None:
+        try:
+            _native = ctypes.CDLL(build_native())
+        except (OSError, subprocess.CalledProcessError):
+            return None
+        _native.orc_render_frame.argtypes = lib().orc_render_frame.argtypes
+        _native.orc_render_frame.restype = None
+    return _native
 
 
 def lib():
@@ -121,10 +168,12 @@ def scene_and_config(desc, cfg):
 class Renderer:
     """Frame-by-frame driver with the reference's host ping-pong (PathTracer.cpp:59-71)."""
 
-    def __init__(self, desc, cfg, threads=1):
+    def __init__(self, desc, cfg, threads=1, native=False):
         self.scene, self.cfg = scene_and_config(desc, cfg)
         self._keep = (desc, cfg)
         self.threads = threads
+        self._lib = (native_lib() if native else None) or lib()
+        self.native = self._lib is not lib()
         self.width, self.height = int(cfg.width), int(cfg.height)
         self.image = np.zeros((self.height, self.width, 4), np.float32)
         self.debug = np.zeros_like(self.image)
@@ -133,7 +182,7 @@ class Renderer:
     def render_frame(self, seed, pixel_weight, px_dim, cam, rows=None):
         out = np.zeros_like(self.image)
         y0, y1 = rows if rows is not None else (0, self.height)
-        lib().orc_render_frame(
+        self._lib.orc_render_frame(
             ctypes.byref(self.scene), ctypes.byref(self.cfg), ctypes.addressof(cam),
             seed, pixel_weight, px_dim, _ptr(self.image), _ptr(out), _ptr(self.debug),
             y0, y1, self.threads, ctypes.byref(self.counters))

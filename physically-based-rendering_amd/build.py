@@ -98,14 +98,37 @@ def _run(cmd):
     return proc.stdout
 
 
-def build_hip(force=False, guard=False):
+HIP_FLAGS = [
+    # xnack-: the hand-scheduled node phase lets a record load overwrite its own address register (pt_kernel.hpp,
+    # PT_NODE_PHASE_HEAD), which is only legal when a faulted load is never replayed; a plain gfx950 code object is
+    # "xnack any" and would also load into an XNACK-enabled process, where a replay would read a clobbered address.
+    # With the target feature spelled out the loader enforces the assumption instead.
+    "--offload-arch=gfx950:xnack-", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+    # hipcc's SLP vectoriser packs adjacent scalar f32 operations into v_pk_* instructions, which issue at
+    # half rate on gfx950 and need v_mov shuffles + hazard s_nops around them: same bits, 3-9 % slower kernels
+    "-fno-slp-vectorize",
+]
+
+
+def hip_sources():
     sources = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
-    sources += [os.path.join(INCLUDE, f) for f in ("pbr_hip.h", "pbr_hip_diag.h")]
+    return sources + [os.path.join(INCLUDE, f) for f in ("pbr_hip.h", "pbr_hip_diag.h")]
+
+
+def hip_digest():
+    """What the product library is built from: sources + flags.  libpbrhip.so.srchash holds the digest of the build that is
+    there; bench.py stamps profiles with it and refuses to price a run with counters of another build."""
+    return _digest(hip_sources(), " ".join(HIP_FLAGS))
+
+
+def build_hip(force=False, guard=False):
+    sources = hip_sources()
+    flags = " ".join(HIP_FLAGS)
     target = HIP_GUARD_LIB if guard else HIP_LIB
-    if not force and (not _stale(target, sources) or _keep_prebuilt(target, "hipcc")):
+    if not force and (not _stale(target, sources, flags) or _keep_prebuilt(target, "hipcc")):
         return target
     with _locked(target):
-        if not force and not _stale(target, sources):     # another process built it while this one waited
+        if not force and not _stale(target, sources, flags):     # another process built it while this one waited
             return target
         return _build_hip_locked(target, sources, guard)
 
@@ -113,10 +136,7 @@ def build_hip(force=False, guard=False):
 def _build_hip_locked(target, sources, guard):
     tmp = "%s.%d.tmp" % (target, os.getpid())
     cmd = [
-        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-        # hipcc's SLP vectoriser packs adjacent scalar f32 operations into v_pk_* instructions, which issue at
-        # half rate on gfx950 and need v_mov shuffles + hazard s_nops around them: same bits, 3-9 % slower kernels
-        "-fno-slp-vectorize",
+        _hipcc(), *HIP_FLAGS,
         "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC, *(["-DPBR_GUARD=1"] if guard else []),
         "-o", tmp, os.path.join(CSRC, "pbr_hip.hip"),
     ]
@@ -126,7 +146,7 @@ def _build_hip_locked(target, sources, guard):
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
-    _stamp(target, sources)
+    _stamp(target, sources, " ".join(HIP_FLAGS))
     return target
 
 

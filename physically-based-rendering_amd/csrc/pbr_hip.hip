@@ -31,6 +31,7 @@ struct Plan {
 	KernelFn kernel = nullptr;
 	int blocks = 0, blockThreads = 0, numHot = 0, park = 0, shade = 0, parkEighths = 4;
 	bool async = false;     // the node phase polls per-lane LDS slots filled by LDS-DMA (pt_kernel.hpp, nodePhaseAsync)
+	bool pair = false;      // the node phase fetches the adjacent record along: reads the flagged copy of the stream (nodePhasePair)
 	size_t ldsBytes = 0;
 	const char* name = "";
 };
@@ -64,6 +65,7 @@ struct pbr_ctx {
 	// scene
 	bool hasScene = false;
 	float4* dNodes = nullptr;
+	float4* dNodesPair = nullptr;  // lab: the stream with `hit successor is the adjacent record` flags (nodePhasePair)
 	float4* dTris = nullptr;
 	float4* dTriPN = nullptr;      // exact vertices + vertex normals per face (Phong tessellation); null if the normal indices are unusable
 	float4* dMats = nullptr;
@@ -144,6 +146,8 @@ int fail( pbr_ctx* ctx, int code, const char* fmt, ... ) {
 
 void freeScene( pbr_ctx* ctx ) {
 	(void) hipFree( ctx->dNodes );
+	(void) hipFree( ctx->dNodesPair );
+	ctx->dNodesPair = nullptr;
 	(void) hipFree( ctx->dTris );
 	(void) hipFree( ctx->dTriPN );
 	ctx->dTriPN = nullptr;
@@ -225,7 +229,7 @@ KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
 #define PBR_WIDE_MINW 8
 #endif
 
-template<int MINW, bool ASYNC = false>
+template<int MINW, int ASYNC = 0>
 KernelFn pickKernelPhasedMode( uint32_t brdf, bool shadow, bool lights ) {
 #ifdef PBR_LAB
 	(void) brdf; (void) shadow; (void) lights;
@@ -246,19 +250,23 @@ KernelFn pickKernelPhasedMode( uint32_t brdf, bool shadow, bool lights ) {
 }
 
 // lab builds: -DPBR_ASYNC_LEAN / -DPBR_ASYNC_MID put the asynchronous node phase in the place of phased-lean / phased-mid
-#ifdef PBR_ASYNC_LEAN
-const bool kAsyncLean = true;
+// (-DPBR_PAIR_LEAN: the adjacent-record fetch in the place of phased-lean)
+#if defined( PBR_ASYNC_LEAN )
+const int kWalkLean = ptk::WALK_ASYNC;
+#elif defined( PBR_PAIR_LEAN )
+const int kWalkLean = ptk::WALK_PAIR;
 #else
-const bool kAsyncLean = false;
+const int kWalkLean = ptk::WALK_SYNC;
 #endif
 #ifdef PBR_ASYNC_MID
-const bool kAsyncMid = true;
+const int kWalkMid = ptk::WALK_ASYNC;
 #else
-const bool kAsyncMid = false;
+const int kWalkMid = ptk::WALK_SYNC;
 #endif
+const bool kAsyncLean = ( kWalkLean == ptk::WALK_ASYNC ), kAsyncMid = ( kWalkMid == ptk::WALK_ASYNC );
 
 KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) {
-	return wide ? pickKernelPhasedMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelPhasedMode<PBR_LEAN_MINW, kAsyncLean>( brdf, shadow, lights );
+	return wide ? pickKernelPhasedMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelPhasedMode<PBR_LEAN_MINW, kWalkLean>( brdf, shadow, lights );
 }
 
 // the "mid" budget: <= 80 VGPRs, launched as two 768-thread blocks per CU = 6 waves / SIMD
@@ -273,7 +281,7 @@ const int kMidBlockThreads = PBR_MID_THREADS;
 
 
 KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
-	return pickKernelPhasedMode<kMidMinWaves, kAsyncMid>( brdf, shadow, lights );
+	return pickKernelPhasedMode<kMidMinWaves, kWalkMid>( brdf, shadow, lights );
 }
 
 KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights );
@@ -533,6 +541,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.numHot = plan.numHot;
 		P.numHotBytes = plan.numHot * 32;
 		P.slotBase = plan.numHot * 32;
+		P.nodes = ( plan.pair && ctx->dNodesPair != nullptr ) ? ctx->dNodesPair : ctx->dNodes;
 		// measured (profiles/r04/experiments/async_node_phase.txt): the share of the walking lanes an iteration waits for
 		P.asyncEighths = ( knobs.asyncEighths >= 1 ) ? std::min( 8, knobs.asyncEighths ) : 6;
 
@@ -583,6 +592,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		int status = makePlan( pickKernel( brdf, shadow, lights, true, false ), "refill-lean", 0, 0, &plans[0] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernel( brdf, shadow, lights, true, true ), "refill-wide", 0, 0, &plans[1] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2], PBR_BLOCK, kAsyncLean );
+		plans[2].pair = ( kWalkLean == ptk::WALK_PAIR );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 48, &plans[3] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhasedMid( brdf, shadow, lights ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads, kAsyncMid );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelMid( brdf, shadow, lights ), "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
@@ -848,8 +858,11 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	ctx->lastTraceMs = traceMs;
 	ctx->lastTraceLaunches = launches;
 
-	if( ( (const volatile unsigned*) ctx->dGuard )[1] != 0u ) {
-		return fail( ctx, PBR_EDEVICE, "a bounded device loop of the path-tracing kernel gave up (PBR_GUARD build; pbr_diag_guard_trips): the image is incomplete" );
+	// [1] the path loop (or a record slot of the asynchronous node phase that never filled), [2] a traversal that took more
+	// steps than the tree has nodes (PBR_GUARD builds): either way a walk was cut short and the image is wrong
+	if( ( (const volatile unsigned*) ctx->dGuard )[1] != 0u || ( (const volatile unsigned*) ctx->dGuard )[2] != 0u ) {
+		return fail( ctx, PBR_EDEVICE, "a bounded device loop of the path-tracing kernel gave up (path loop %u, traversal %u trips; pbr_diag_guard_trips): the image is incomplete",
+		             ( (const volatile unsigned*) ctx->dGuard )[1], ( (const volatile unsigned*) ctx->dGuard )[2] );
 	}
 
 	if( ( (const volatile unsigned*) ctx->dGuard )[3] != 0u ) {
@@ -1254,6 +1267,26 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dMats, sizeof( float4 ) * mats.size() ) );
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dLights, sizeof( float4 ) * lights.size() ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dNodes, nodes.data(), sizeof( float4 ) * nodes.size(), hipMemcpyHostToDevice ) );
+
+	if( kWalkLean == ptk::WALK_PAIR ) {
+		// lab (nodePhasePair): bit 0 of a container's w0 = "my hit successor is the adjacent record", only behind the ranked
+		// prefix (every plan fetches those records from memory)
+		std::vector<float4> flagged( nodes );
+		size_t flags = 0;
+
+		for( size_t r = numHot; r + 1 < numRecords; r++ ) {
+			const int w0 = __builtin_bit_cast( int, flagged[r * 2 + 1].z );
+
+			if( w0 >= 0 && (size_t) w0 == ( r + 1 ) * 32 ) {
+				flagged[r * 2 + 1].z = __builtin_bit_cast( float, w0 | 1 );
+				flags++;
+			}
+		}
+
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dNodesPair, sizeof( float4 ) * flagged.size() ) );
+		HIP_TRY( ctx, hipMemcpy( ctx->dNodesPair, flagged.data(), sizeof( float4 ) * flagged.size(), hipMemcpyHostToDevice ) );
+		std::fprintf( stderr, "[pbr pair] %zu of %zu records carry the adjacent-successor flag\n", flags, numRecords );
+	}
 	HIP_TRY( ctx, hipMemcpy( ctx->dTris, tris.data(), sizeof( float4 ) * tris.size(), hipMemcpyHostToDevice ) );
 
 	if( !triPN.empty() ) {

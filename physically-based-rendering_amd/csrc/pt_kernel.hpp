@@ -84,6 +84,8 @@ using namespace ptm;
 #ifndef PT_WALK_PRIO
 #define PT_WALK_PRIO 1
 #endif
+// asynchronous node phase (nodePhaseAsync): bytes between the two halves of a lane's record slot in LDS: 1024 lanes x 16 B
+#define PT_SLOT_PLANE 16384
 #ifndef PT_EAGER_REFILL_UP_TO
 #define PT_EAGER_REFILL_UP_TO 8
 #endif
@@ -839,7 +841,7 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 // so the reference itself is the address operand of both the LDS read and the global load.
 // The hit condition (pt_bvh.cl:107-110) is a chain of v_cmpx: each compare narrows EXEC to the lanes that still
 // qualify, so no scalar instruction merges the three masks — 8 scalar + 22 vector instructions per visit (round 3: 24 → 22,
-// see the note at PT_NODE_PHASE_TAIL; bit-identical and NOT faster — 64.4 ms either way on the Sponza-class scene: the node
+// see the note at PT_NODE_PHASE_TAIL_BEGIN; bit-identical and NOT faster — 64.4 ms either way on the Sponza-class scene: the node
 // phase waits for its slowest lane's fetch, it is not bound by vector issue).
 //
 // Cache policy of the two loads, measured in round 3 (profiles/r03/experiments/node_load_cache_policy.txt): default as
@@ -853,7 +855,9 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 #if !defined( PBR_GUARD ) && !defined( PBR_NODE_PHASE_CXX )
 #define PT_NODE_PHASE_ASM 1
 
-template<bool ANYHIT>
+// PARKED_ONLY (round 4, lab: VERDICT r03 item 6): the phase ends once `keep` lanes have PARKED on a leaf — lanes whose
+// walk has ended leave the loop without counting — or nobody is left walking; the default ends it once `keep` or fewer lanes go on.
+template<bool ANYHIT, bool PARKED_ONLY = false>
 PT_DEV void nodePhaseAsm(
 	const DevParams& P, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep,
 	int& ref, unsigned& visits, int& leafWord, float& leafTNear, float& leafTFar, int& parked
@@ -902,16 +906,24 @@ PT_DEV void nodePhaseAsm(
 	// exits as they stand: pt_intersect.cl's fmin( ., INFINITY ) on the third only matters when all three are NaN, and
 	// then tNear is NaN too and the box is missed either way (the C++ statement below keeps the reference's form).
 	// 22 vector + 8 scalar instructions per visit.
-#define PT_NODE_PHASE_TAIL \
+#define PT_NODE_PHASE_TAIL_BEGIN \
 		"v_cmp_gt_i32 vcc, 0, v52\n" \
 		"v_cndmask_b32 v53, v52, v53, vcc\n" \
 		"s_or_b64 %[parkMask], %[parkMask], vcc\n" \
 		"s_mov_b64 exec, %[active]\n" \
 		"v_cmp_le_i32 %[mA], 0, v53\n" \
-		"s_andn2_b64 exec, %[mA], vcc\n" \
+		"s_andn2_b64 exec, %[mA], vcc\n"
+#define PT_NODE_PHASE_LOOP_DEFAULT \
 		"s_bcnt1_i32_b64 %[count], exec\n" \
 		"s_cmp_gt_i32 %[count], %[keep]\n" \
+		"s_cbranch_scc1 1b\n"
+#define PT_NODE_PHASE_LOOP_PARKED_ONLY \
+		"s_cbranch_execz 3f\n" \
+		"s_bcnt1_i32_b64 %[count], %[parkMask]\n" \
+		"s_cmp_lt_i32 %[count], %[keep]\n" \
 		"s_cbranch_scc1 1b\n" \
+	"3:\n"
+#define PT_NODE_PHASE_TAIL_END \
 		"s_mov_b64 exec, %[saved]\n" \
 		"v_mov_b32 %[ref], v53\n" \
 		"v_cndmask_b32 %[parked], 0, 1, %[parkMask]\n" \
@@ -931,7 +943,20 @@ PT_DEV void nodePhaseAsm(
 		asm volatile(
 			PT_NODE_PHASE_HEAD
 			"v_cmpx_le_f32 v60, v61\n"
-			PT_NODE_PHASE_TAIL
+			PT_NODE_PHASE_TAIL_BEGIN
+			PT_NODE_PHASE_LOOP_DEFAULT
+			PT_NODE_PHASE_TAIL_END
+			PT_NODE_PHASE_OPERANDS
+		);
+	}
+	else if( PARKED_ONLY ) {
+		asm volatile(
+			PT_NODE_PHASE_HEAD
+			"v_cmpx_gt_f32 %[rayT], v60\n"
+			"v_cmpx_le_f32 v60, v61\n"
+			PT_NODE_PHASE_TAIL_BEGIN
+			PT_NODE_PHASE_LOOP_PARKED_ONLY
+			PT_NODE_PHASE_TAIL_END
 			PT_NODE_PHASE_OPERANDS
 		);
 	}
@@ -940,14 +965,125 @@ PT_DEV void nodePhaseAsm(
 			PT_NODE_PHASE_HEAD
 			"v_cmpx_gt_f32 %[rayT], v60\n"
 			"v_cmpx_le_f32 v60, v61\n"
-			PT_NODE_PHASE_TAIL
+			PT_NODE_PHASE_TAIL_BEGIN
+			PT_NODE_PHASE_LOOP_DEFAULT
+			PT_NODE_PHASE_TAIL_END
 			PT_NODE_PHASE_OPERANDS
 		);
 	}
 
 #undef PT_NODE_PHASE_HEAD
-#undef PT_NODE_PHASE_TAIL
+#undef PT_NODE_PHASE_TAIL_BEGIN
+#undef PT_NODE_PHASE_LOOP_DEFAULT
+#undef PT_NODE_PHASE_LOOP_PARKED_ONLY
+#undef PT_NODE_PHASE_TAIL_END
 #undef PT_NODE_PHASE_OPERANDS
+}
+
+// ---- the node phase with the adjacent record fetched along (round 4, lab) ----------------------------------
+// VERDICT r03 item 1.  A cold fetch brings 64 B: the record and the next one of the stream (in DFS order a container's hit
+// successor; the same 128-byte line three times out of four).  pbr_upload_scene keeps a second copy of the stream for
+// this plan in which a container's w0 carries bit 0 when (a) the record lies behind the ranked prefix — so every lane that
+// sees it has fetched from memory, whatever the plan's LDS share — and (b) its hit successor is the adjacent record.  A
+// lane whose box is hit and whose new cursor carries the flag takes its NEXT visit at once, from registers: same
+// visit, same counters, one round trip to memory less.  Per lane the sequence of visits is the reference's
+// (pt_bvh.cl:88-122).  Registers: as nodePhaseAsm + v[64:71] for the adjacent record.
+template<int DUMMY = 0>
+PT_DEV void nodePhasePair(
+	const DevParams& P, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep,
+	int& ref, unsigned& visits, int& leafWord, float& leafTNear, int& parked
+) {
+	const float eps = EPSILON5;
+	keep = __builtin_amdgcn_readfirstlane( keep );
+	unsigned long long saved, active, parkMask, mA;
+	int count;
+
+	asm volatile(
+		"s_mov_b64 %[saved], exec\n"
+		"s_mov_b64 %[parkMask], 0\n"
+		"v_mov_b32 v53, %[ref]\n"
+	"1:\n"
+		"v_cmp_gt_i32 vcc, %[numHotBytes], v53\n"
+		"s_and_saveexec_b64 %[active], vcc\n"
+		"ds_read_b128 v[46:49], v53\n"
+		"ds_read_b128 v[50:53], v53 offset:16\n"
+		"s_xor_b64 exec, exec, %[active]\n"
+		"global_load_dwordx4 v[46:49], v53, %[nodes]\n"
+		"global_load_dwordx4 v[64:67], v53, %[nodes] offset:32\n"
+		"global_load_dwordx4 v[68:71], v53, %[nodes] offset:48\n"
+		"global_load_dwordx4 v[50:53], v53, %[nodes] offset:16\n"
+		"s_mov_b64 exec, %[active]\n"
+		"v_add_u32 %[visits], 1, %[visits]\n"
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+		"v_pk_add_f32 v[54:55], v[46:47], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_add_f32 v[56:57], v[48:49], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_add_f32 v[58:59], v[50:51], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_mul_f32 v[54:55], %[ixy], v[54:55]\n"
+		"v_pk_mul_f32 v[56:57], %[ixy], v[56:57]\n"
+		"v_pk_mul_f32 v[58:59], %[izz], v[58:59]\n"
+		"v_min_f32 v60, v54, v56\n"
+		"v_min_f32 v61, v55, v57\n"
+		"v_min_f32 v62, v58, v59\n"
+		"v_max3_f32 v60, v60, v61, v62\n"
+		"v_max_f32 v61, v54, v56\n"
+		"v_max_f32 v63, v58, v59\n"
+		"v_max_f32 v62, v55, v57\n"
+		"v_min3_f32 v61, v61, v62, v63\n"
+		"v_cmpx_lt_f32 %[eps], v61\n"
+		"v_cmpx_gt_f32 %[rayT], v60\n"
+		"v_cmpx_le_f32 v60, v61\n"
+		"v_cmp_gt_i32 vcc, 0, v52\n"
+		"v_cndmask_b32 v53, v52, v53, vcc\n"
+		"s_or_b64 %[parkMask], %[parkMask], vcc\n"
+		// the lanes whose next record is the adjacent one they have fetched: their next visit, from registers
+		"v_and_b32 v62, 1, v53\n"
+		"v_cmp_ne_u32 vcc, 0, v62\n"
+		"s_and_b64 exec, exec, vcc\n"
+		"s_cbranch_scc0 2f\n"
+		"s_mov_b64 %[mA], exec\n"
+		"v_add_u32 %[visits], 1, %[visits]\n"
+		"v_pk_add_f32 v[54:55], v[64:65], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_add_f32 v[56:57], v[66:67], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_add_f32 v[58:59], v[68:69], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_mul_f32 v[54:55], %[ixy], v[54:55]\n"
+		"v_pk_mul_f32 v[56:57], %[ixy], v[56:57]\n"
+		"v_pk_mul_f32 v[58:59], %[izz], v[58:59]\n"
+		"v_min_f32 v60, v54, v56\n"
+		"v_min_f32 v61, v55, v57\n"
+		"v_min_f32 v62, v58, v59\n"
+		"v_max3_f32 v60, v60, v61, v62\n"
+		"v_max_f32 v61, v54, v56\n"
+		"v_max_f32 v63, v58, v59\n"
+		"v_max_f32 v62, v55, v57\n"
+		"v_min3_f32 v61, v61, v62, v63\n"
+		"v_cmpx_lt_f32 %[eps], v61\n"
+		"v_cmpx_gt_f32 %[rayT], v60\n"
+		"v_cmpx_le_f32 v60, v61\n"
+		"v_cmp_gt_i32 vcc, 0, v70\n"
+		"v_cndmask_b32 v71, v70, v71, vcc\n"
+		"s_or_b64 %[parkMask], %[parkMask], vcc\n"
+		"v_mov_b32 v52, v70\n"                               // a lane that parks here: its leaf word where the epilogue reads it
+		"s_mov_b64 exec, %[mA]\n"
+		"v_and_b32 v53, -2, v71\n"                           // the cursor never carries the flag into an address
+	"2:\n"
+		"s_mov_b64 exec, %[active]\n"
+		"v_cmp_le_i32 %[mA], 0, v53\n"
+		"s_andn2_b64 exec, %[mA], %[parkMask]\n"
+		"s_bcnt1_i32_b64 %[count], exec\n"
+		"s_cmp_gt_i32 %[count], %[keep]\n"
+		"s_cbranch_scc1 1b\n"
+		"s_mov_b64 exec, %[saved]\n"
+		"v_mov_b32 %[ref], v53\n"
+		"v_cndmask_b32 %[parked], 0, 1, %[parkMask]\n"
+		"v_mov_b32 %[leafWord], v52\n"
+		"v_mov_b32 %[leafTNear], v60\n"
+		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [parked] "=v"( parked ),
+		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [count] "=&s"( count )
+		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ),
+		  [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps )
+		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "vcc", "scc"
+	);
 }
 
 // ---- the node phase, asynchronous (round 4) --------------------------------------------------------
@@ -979,7 +1115,6 @@ PT_DEV void nodePhaseAsm(
 // Registers: v46-v63 as nodePhaseAsm; v64 = address of the second half - 16, v65 = this lane's slot + 12, v66 / v67 = the markers.
 // Scalars s84-s99 are the block's own (clobbered): saved exec, walking lanes, ready lanes, parked lanes, a temporary
 // mask, counts, the compiler's M0, the error flag (s83).
-#define PT_SLOT_PLANE 16384     // bytes between the two halves of a lane's slot: 1024 lanes x 16 B
 #if defined( PBR_DBG_NOREARM )
 #define PT_ASYNC_REARM ""
 #elif defined( PBR_DBG_REARM2 )
@@ -2237,8 +2372,12 @@ PT_DEV int startWalk( const DevParams& P, const Ray& ray, WalkState& w ) {
 	return MODE_NODE;
 }
 
-template<int BRDF, bool SHADOW, bool LIGHTS, int MINW, bool ASYNC = false>
+// WALK: which node phase — 0 nodePhaseAsm, 1 nodePhaseAsync (polled LDS-DMA slots), 2 nodePhasePair (adjacent record fetched along)
+enum { WALK_SYNC = 0, WALK_ASYNC = 1, WALK_PAIR = 2 };
+
+template<int BRDF, bool SHADOW, bool LIGHTS, int MINW, int WALK = WALK_SYNC>
 __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const DevParams P ) {
+	constexpr bool ASYNC = ( WALK == WALK_ASYNC );
 	const float4* lds = gHotNodes;
 	PT_LAB_WAVE_BEGIN
 	stageHotNodes( P, gHotNodes );
@@ -2330,8 +2469,19 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 					nodePhaseAsync( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, slotM0, w.cur.ref, visits, leafWord, w.leafTNear, parkedFlag, phaseErr );
 					asyncErr |= phaseErr;
 				}
+				else if( WALK == WALK_PAIR ) {
+					(void) unusedTFar;
+					nodePhasePair( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, parkedFlag );
+				}
 				else {
+#ifdef PBR_EXP_PARKED_ONLY
+					// lab: the phase ends once parkNow lanes (at most half of those that entered) stand on a leaf
+					const int entered = keep + parkNow;
+					const int target = ( parkNow < ( entered + 1 ) / 2 ) ? parkNow : ( entered + 1 ) / 2;
+					nodePhaseAsm<false, true>( P, oxy, ozz, ixy, izz, w.hit.t, ( target < 1 ) ? 1 : target, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
+#else
 					nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
+#endif
 				}
 				st.dbgNodes += visits;
 				PT_LAB_PHASED_NODE_MID

@@ -11,7 +11,7 @@ pbr = pbr_loader.load()
 SCENES = {"cornell": ("cornell", 1, 0, 8), "sponza": ("sponza", 2, 260000, 3), "dragon": ("dragon", 1, 870000, 3), "hairball": ("hairball", 3, 2000000, 3)}
 jobs = sys.argv[1:] or ["cornell:64", "sponza:32", "dragon:32", "hairball:16"]
 tag = os.path.basename(os.environ.get("PBR_HIP_LIB", "default")) + "/" + ("plan " + os.environ["PBR_PLAN"] if os.environ.get("PBR_PLAN") else "auto")
-W, H = 1920, 1080
+W, H = (int(v) for v in os.environ.get("AB_SIZE", "1920x1080").split("x"))
 for job in jobs:
     name, frames = job.split(":"); frames = int(frames)
     kind, seed, tris, depth = SCENES[name]
@@ -45,6 +45,12 @@ for job in jobs:
     if hasattr(pbr.hip, "pbr_diag_raw_counters") and os.environ.get("PBR_STATS"):
         pbr.hip.pbr_diag_raw_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         pbr.hip.pbr_diag_raw_counters(dev._ctx, raw)
+        if os.environ["PBR_STATS"] == "leafhist":       # lab build -DPBR_EXP_LEAFHIST (lab/src/pt_lab_hooks.hpp)
+            hist, phases, parked, finished, entered = [raw[4 + k] for k in range(8)], raw[12], raw[13], raw[14], raw[15]
+            print("    leaf phases by parked lanes  0: %.1f %%  1-4: %.1f %%  5-8: %.1f %%  9-12: %.1f %%  13-16: %.1f %%  17-24: %.1f %%  25-32: %.1f %%  33+: %.1f %%" % tuple(100.0 * h / max(phases, 1) for h in hist))
+            print("    node phases %.3e: %.1f lanes enter, %.2f park, %.2f end their walk per phase" % (phases, entered / max(phases, 1), parked / max(phases, 1), finished / max(phases, 1)), flush=True)
+            dev.close()
+            continue
         it, act, lit, lact = raw[4], raw[5], raw[6], raw[7]
         if it:
             print("    stats: wave-iterations %.3e  active lanes/iteration %.1f  iterations with a leaf %.1f %%  lanes in the leaf branch %.2f" % (

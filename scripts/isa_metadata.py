@@ -24,9 +24,13 @@ def code_object(lib, workdir):
     fat = os.path.join(workdir, "fat.bin")
     dev = os.path.join(workdir, "dev.co")
     subprocess.check_call([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, lib])
-    subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + dev])
-    return dev
+    # the product is built for gfx950:xnack- since round 4 (build.py, HIP_FLAGS); older and lab libraries for plain gfx950
+    for target in ("hipv4-amdgcn-amd-amdhsa--gfx950:xnack-", "hipv4-amdgcn-amd-amdhsa--gfx950"):
+        done = subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=" + target, "--output=" + dev], capture_output=True, text=True)
+        if done.returncode == 0 and os.path.exists(dev) and os.path.getsize(dev) > 0:
+            return dev
+    raise RuntimeError("no gfx950 code object in %s: %s" % (lib, done.stderr))
 
 
 def demangle(names):

@@ -924,6 +924,62 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert j["value"] > 0 and j["scaling"] == "strong"
 
 
+def test_environment_steers_lab_runs_only(pbr, gpu_device, cfg_defaults, monkeypatch):
+    """the C library reads no environment variable, and the Python harness maps PBR_* variables onto knobs only
+    for a process that says it is a lab run (PBR_LAB_ENV=1): a stray PBR_PLAN in a user's environment changes nothing."""
+    sc = pbr.HostScene.generate("cornell", 1, 0)
+    cfg, cam, px = sc.config(64, 48), sc.camera(), pbr.pixel_dimension(64, 48)
+
+    def first_plan():
+        dev = pbr.Device(gpu_device)
+        dev.upload_scene(sc.desc)
+        dev.configure(cfg)
+        dev.render(0, pbr.frame_seeds(0, 1), px, cam)
+        plan = dev.last_plan()
+        dev.close()
+        return plan
+
+    monkeypatch.delenv("PBR_LAB_ENV", raising=False)
+    monkeypatch.setenv("PBR_PLAN", "3")
+    monkeypatch.setenv("PBR_BVH_BUILDER", "no-such-builder")         # would raise if it were looked at
+    assert first_plan()[0] == pbr.Device.PLAN_NAMES[0]               # the tuner's first candidate: nothing was pinned
+    monkeypatch.setenv("PBR_LAB_ENV", "1")
+    with pytest.raises(pbr.PbrError):                                # a lab run: the variables count, and a bad value is an error, not a KeyError
+        first_plan()
+    monkeypatch.setenv("PBR_BVH_BUILDER", "lbvh")
+    assert first_plan() == (pbr.Device.PLAN_NAMES[3], -1)            # pinned by PBR_PLAN
+
+
+def test_bench_full_scale_shape_rehearsed_on_one_device(tmp_path):
+    """the SHAPE of the driver's 8-GPU run on the hardware there is — `python3 bench.py --gpus 8`
+    with no launcher, the driver's --steps 20 --warmup 5, the Sponza-class scene at 1920x1080, eight ranks on ONE device
+    over gloo.  Eight concurrent imports behind the build lock, eight contexts on one device, eight tuners and the
+    vote, the all-gather and the scatter: one line, n_gpus 8, eight per-rank timings, eight votes, and the gathered frame
+    is the one-rank frame bit for bit.  No 8-GPU number is claimed from this: the ranks share one GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--repeats", "1", "--hold-seconds", "0"]
+    eight = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--one-device",
+                            "--dump", str(tmp_path / "eight.npy")] + common, capture_output=True, text=True, timeout=1100, env=env)
+    assert eight.returncode == 0, eight.stderr[-3000:]
+    lines = [ln for ln in eight.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, eight.stdout[-2000:]
+    j8 = json.loads(lines[0])
+    assert j8["n_gpus"] == 8 and j8["steps"] == 20 and j8["warmup"] == 5 and j8["config"]["scene"] == "sponza"
+    assert (j8["config"]["width"], j8["config"]["height"]) == (1920, 1080)
+    assert len(j8["per_rank_ms"]["render"]) == 8 and len(j8["per_rank_ms"]["gather"]) == 8 and all(v > 0 for v in j8["per_rank_ms"]["render"])
+    assert len(j8["plan_votes"]) == 8 and j8["schedule"] in [pbr_plan_name(v) for v in j8["plan_votes"] if v >= 0]
+    assert j8["value"] > 0 and j8["scaling"] == "strong"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dump", str(tmp_path / "one.npy")] + common,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert j1["per_sample"] == j8["per_sample"]                     # the same paths, each counted once, on whichever rank
+    assert same_values(np.load(tmp_path / "one.npy"), np.load(tmp_path / "eight.npy"))
+
+
 # ----------------------------------------------------------------------------------------------
 # the reference's own scenes (resources/models/testing/*.obj|.mtl|.lights) as committed fixtures
 # ----------------------------------------------------------------------------------------------

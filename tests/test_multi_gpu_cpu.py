@@ -130,7 +130,8 @@ def test_bench_launches_one_rank_per_gpu_with_a_local_rendezvous():
     started = []
 
     class Fake:
-        def __init__(self, cmd, env=None, stdout=None):
+        def __init__(self, cmd, env=None, stdout=None, start_new_session=False):
+            assert start_new_session            # every rank in its own session: the parent ends a rank and what it started
             started.append((cmd, env, stdout))
 
     procs = bench.launch_ranks(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], popen=Fake, environ={"PATH": os.environ["PATH"]})
@@ -142,7 +143,19 @@ def test_bench_launches_one_rank_per_gpu_with_a_local_rendezvous():
         assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
         ports.add(env["MASTER_PORT"])
         assert (stdout is None) == (rank == 0)          # only rank 0 writes to the run's stdout
-    assert len(ports) == 1 and 0 < int(ports.pop()) < 65536
+    assert len(ports) == 1
+    port = int(ports.pop())
+    assert 0 < port < 65536
+    # the port stays reserved while the parent lives (round 3 closed it before the ranks started: a window for anybody else) ...
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as other:
+        with pytest.raises(OSError):
+            other.bind(("127.0.0.1", port))
+    # ... and rank 0's store, which sets SO_REUSEADDR like the holder, can still bind and listen on it
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as store:
+        store.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        store.bind(("127.0.0.1", port))
+        store.listen(8)
 
 
 def test_bench_plan_election():
@@ -162,45 +175,113 @@ def test_bench_first_failing_rank_ends_the_run():
     assert all(p.poll() is not None for p in procs)
 
 
+def test_bench_parent_ends_its_ranks_on_sigterm_and_on_the_deadline():
+    """`timeout ... python bench.py --gpus 8` signals only the parent.  The parent's handler ends the ranks
+    (exact PIDs) before it exits, and a wall-clock limit ends a run whose ranks hang."""
+    import signal
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import importlib.util, subprocess, sys
+        spec = importlib.util.spec_from_file_location("bench_under_test", %r)
+        bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+        procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"], start_new_session=True) for _ in range(3)]
+        print(" ".join(str(p.pid) for p in procs), flush=True)
+        sys.exit(bench.wait_ranks(procs, limit_s=float(sys.argv[1])))
+    """ % os.path.join(ROOT, "bench.py"))
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+            with open("/proc/%d/stat" % pid) as f:
+                return f.read().split(")")[-1].split()[0] != "Z"
+        except (OSError, IndexError):
+            return False
+
+    # SIGTERM to the parent
+    parent = subprocess.Popen([sys.executable, "-c", code, "600"], stdout=subprocess.PIPE, text=True)
+    pids = [int(v) for v in parent.stdout.readline().split()]
+    assert len(pids) == 3 and all(alive(p) for p in pids)
+    parent.send_signal(signal.SIGTERM)
+    assert parent.wait(timeout=60) == 128 + signal.SIGTERM
+    assert not any(alive(p) for p in pids)
+    # the deadline
+    parent = subprocess.Popen([sys.executable, "-c", code, "1.0"], stdout=subprocess.PIPE, text=True)
+    pids = [int(v) for v in parent.stdout.readline().split()]
+    assert parent.wait(timeout=60) == 124
+    assert not any(alive(p) for p in pids)
+
+
 def test_bench_gpus_8_without_a_launcher_spawns_instead_of_refusing():
     """`python bench.py --gpus 8` with no WORLD_SIZE must not stop at argument parsing (round 2 did: "needs a
     torch.distributed.run launch").  Here there is no GPU, so the eight ranks it starts fail loudly at their first device call —
     the product has no CPU fallback — and the parent reports that failure."""
     import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run (covered by the gpu suite)")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "1", "--warmup", "0",
                           "--scene", "cornell", "--width", "64", "--height", "48", "--cpu-seconds", "0"],
                          capture_output=True, text=True, timeout=600, env=env)
-    if torch.cuda.is_available():
-        pytest.skip("a GPU is present: the ranks would run (covered by the gpu suite)")
     assert "torch.distributed.run launch" not in run.stderr
     # the ranks were started and refused to run without a device (torch.cuda.set_device or pbr_create, whichever comes first)
     assert run.returncode != 0 and ("No HIP GPUs" in run.stderr or "PbrError" in run.stderr)
 
 
-def test_bench_roofline_is_physical_for_every_profiled_workload():
-    """bench.py's roofline block from the committed PMC passes (profiles/r03/pmc_traffic.json) at each workload's own
-    launch time (profiles/r03/summary.json): `frac` is fabric traffic / time / 8 TB/s — between 0 and 1 —, the issue-side
-    and L2 fractions are below 1 as well, and the contract's algorithmic figure is reported beside them, not as `frac`."""
+def test_bench_roofline_is_physical_and_cannot_go_stale():
+    """bench.py's roofline block from the newest committed PMC passes (profiles/rNN/pmc_traffic.json) at each workload's own
+    launch time (profiles/rNN/summary.json): `frac` is fabric traffic / time / 8 TB/s — between 0 and 1 —, the issue-side
+    and the L2 fractions are in (0, 1] as well (the L2 fraction read 1.07 and 1.19), `bound` / `bound_measured`
+    follow from the counters by the stated rule, and counters of another build or another schedule are refused."""
+    import glob
     import json
     bench = _bench_module()
-    summary = json.load(open(os.path.join(ROOT, "profiles", "r03", "summary.json")))
-    seen = 0
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[-1]
+    round_dir = os.path.dirname(newest)
+    summary = json.load(open(os.path.join(round_dir, "summary.json")))
+    records = json.load(open(newest))
+    seen, bounds = 0, {}
     for key, rec in summary.items():
+        if key not in records:
+            continue
         line = rec["bench"]
         cfg = line["config"]
         traffic = bench.recorded_traffic(cfg["scene"], cfg["width"], cfg["height"], cfg["max_depth"], cfg["brdf"])
-        assert traffic is not None and traffic["source"].startswith(os.path.join("profiles", "r03")), key
+        assert traffic is not None and traffic["source"].startswith(os.path.relpath(round_dir, ROOT)), key
         samples = cfg["width"] * cfg["height"] * line["steps"]
         seconds = line["roofline"]["launch_ms"] / 1e3
-        block = bench.roofline_block(cfg["scene"], line["schedule"], traffic, line["per_sample"]["algorithmic_bytes"] * samples, samples, seconds)
+        block = bench.roofline_block(cfg["scene"], traffic["schedule"], traffic, line["per_sample"]["algorithmic_bytes"] * samples, samples, seconds)
         want = (traffic["fabric_read_bytes_per_launch"] + traffic["fabric_write_bytes_per_launch"]) / seconds / 8e12
+        assert block["traffic_stale"] is False
         assert abs(block["frac"] - want) < 1e-9 and 0.0 < block["frac"] <= 1.0, (key, block["frac"])
-        assert block["achieved"] <= block["peak"] and block["bound"] == "hbm" and block["unit"] == "GB/s"
+        assert block["achieved"] <= block["peak"] and block["unit"] == "GB/s"
         assert 0.0 < block["issue"]["frac"] < 1.0 and 0.0 < block["issue"]["lane_utilisation"] < 1.0
+        if cfg["scene"] != "cornell":                        # its tree lives in LDS: hardly an L2 request
+            assert 0.0 < block["l2"]["frac"] <= 1.0, (key, block["l2"])
         assert block["algorithmic_GBs"] > 0 and "algorithmic_bytes_per_launch" in block
+        bm = block["bound_measured"]
+        assert bm["value"] == bench.measured_bound(bm["fabric_frac"], bm["l2_frac"], bm["valu_busy"])
+        assert block["bound"] == ("hbm" if bm["value"] == "fabric" else bm["value"])
+        bounds[key] = bm["value"]
+        # counters of another build of the kernels: refused, nothing priced
+        other = bench.roofline_block(cfg["scene"], traffic["schedule"], traffic, 1e9, samples, seconds, stamp="0" * 64)
+        assert other["traffic_stale"] is True and other["frac"] is None and other["traffic"] is None and other["bound_measured"] is None
+        assert "loaded library" in other["traffic_stale_why"]
+        # ... of another schedule: refused
+        other = bench.roofline_block(cfg["scene"], "refill-lean" if traffic["schedule"] != "refill-lean" else "phased-mid", traffic, 1e9, samples, seconds)
+        assert other["traffic_stale"] is True and other["frac"] is None and "schedule" in other["traffic_stale_why"]
+        # the library the record was taken with (round 4 on: every record carries its digest): accepted
+        if traffic.get("srchash"):
+            same = bench.roofline_block(cfg["scene"], traffic["schedule"], traffic, 1e9, samples, seconds, stamp=traffic["srchash"])
+            assert same["traffic_stale"] is False and same["frac"] is not None
         seen += 1
     assert seen == 5                                   # cornell, sponza, dragon, hairball, hairball at 3840 x 2160
+    # what binds: the Dragon-class scene streams (the one workload whose `bound` is "hbm"), Cornell issues, nothing else does either
+    assert bounds["dragon"] == "fabric" and bounds["cornell"] == "issue" and bounds["sponza"] == "latency", bounds
+    # the rule itself
+    assert bench.measured_bound(0.6, 0.2, 0.3) == "fabric" and bench.measured_bound(0.2, 0.95, 0.3) == "l2-requests"
+    assert bench.measured_bound(0.1, 0.4, 0.8) == "issue" and bench.measured_bound(0.15, 0.44, 0.6) == "latency"
+    assert bench.measured_bound(None, None, None) == "latency"
     # a workload nobody profiled: no invented number
     none = bench.roofline_block("sponza", "phased-mid", None, 1e9, 1e6, 1e-3)
-    assert none["frac"] is None and none["traffic"] is None and none["algorithmic_GBs"] == 1e9 / 1e-3 / 1e9
+    assert none["frac"] is None and none["traffic"] is None and none["bound_measured"] is None and none["algorithmic_GBs"] == 1e9 / 1e-3 / 1e9

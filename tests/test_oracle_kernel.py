@@ -263,6 +263,24 @@ def test_threads_do_not_change_results(cfg_defaults, oracle):
     assert same_values(a, b)
 
 
+@pytest.mark.parametrize("brdf", [1, 0])
+def test_the_baseline_legs_native_build_gives_the_same_bits(cfg_defaults, oracle, brdf):
+    """bench.py times the oracle built -O3 -march=native on the machine it runs on (oracle.build_native, SURVEY 8(d));
+    the tests check everything against the portable -O2 -mavx2 build.  -ffp-contract=off in both: identical images,
+    debug images and counters — the flags buy time, never bits."""
+    pbr = cfg_defaults
+    pbr.cfg_set(**{"render.brdf": brdf, "render.max_depth": 4})
+    sc = pbr.HostScene.generate("sponza", 2, 3000)
+    cfg, cam, px = sc.config(64, 48), sc.camera(), pbr.pixel_dimension(64, 48)
+    portable = oracle.Renderer(sc.desc, cfg, threads=2)
+    native = oracle.Renderer(sc.desc, cfg, threads=2, native=True)
+    assert native.native and not portable.native and "native" in oracle.build_native()
+    a = portable.render(0, pbr.frame_seeds(0, 3), px, cam)
+    b = native.render(0, pbr.frame_seeds(0, 3), px, cam)
+    assert same_values(a, b) and same_values(portable.debug, native.debug)
+    assert portable.counter_dict() == native.counter_dict()
+
+
 # ----------------------------------------------------------------------------------------------
 # fixtures of the reference's own scenes (tests/golden/ref_*.npz, make_reference_scenes.py)
 # ----------------------------------------------------------------------------------------------
