@@ -46,7 +46,7 @@ HBM_ACHIEVABLE_GBS = 6300.0
 # 32-B gathers from a 2 MiB (L2-resident) table at full occupancy / its duration, rocprofv3 --pmc TCC_REQ_sum
 # (profiles/r04/experiments/l2_request_ceiling.txt).  Round 3 priced every TCC_REQ at 128 B against the guide's 18 TB/s of
 # L2-resident row gathers and reported fractions of 1.07 and 1.19: TCC requests are not all 128 B.
-L2_REQUEST_CEILING = 226e9
+L2_REQUEST_CEILING = 245e9
 NUM_SIMDS = 1024        # 256 CUs x 4
 
 WORKLOADS = {

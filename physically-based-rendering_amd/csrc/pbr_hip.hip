@@ -23,6 +23,7 @@
 using ptk::DevParams;
 
 typedef void ( *KernelFn )( const ptk::DevParams );
+typedef void ( *KernelFn2 )( const ptk::DevParams, const float4*, unsigned, float2* );
 
 // A plan = kernel + persistent grid + LDS split (launch()).  Built once per scene + configuration and kept in the
 // context: six occupancy queries and six function-attribute calls are host time a frame-by-frame caller would pay
@@ -2137,6 +2138,53 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 	*ms_out = best;
 	return PBR_OK;
 }
+
+#if defined( PBR_LAB ) && !defined( PBR_GUARD )
+// lab builds only (scripts/trace_dual.py): the traversal-only probe at `waves` (4 | 8) per SIMD with one or two walks per lane
+extern "C" int pbr_lab_trace_stream_dual( pbr_ctx* ctx, int mode, int waves, int dual, const float* rays8, uint32_t n, int repeats, float* out2, double* ms_out ) {
+	if( ctx == nullptr || !ctx->hasScene || rays8 == nullptr || n == 0 || out2 == nullptr || ms_out == nullptr || ( waves != 4 && waves != 6 && waves != 8 ) || ( waves == 8 && dual ) ) {
+		return fail( ctx, PBR_EINVAL, "lab_trace_stream_dual: bad argument / no scene (waves 4 | 6 | 8; two walks per lane need more than 64 registers: not at 8)" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	DevBuf dRays, dOut;
+	HIP_TRY( ctx, dRays.alloc( sizeof( float ) * 8 * (size_t) n ) );
+	HIP_TRY( ctx, dOut.alloc( sizeof( float ) * 2 * (size_t) n ) );
+	HIP_TRY( ctx, hipMemcpy( dRays.p, rays8, sizeof( float ) * 8 * (size_t) n, hipMemcpyHostToDevice ) );
+	DevParams P = sceneParams( ctx );
+	P.workCounter = ctx->dWork;
+	P.counters = ctx->dCounters;
+	P.parkEighths = 4;
+	ctx->workClean = false;
+	double best = 1e30;
+	// 4: one 1024-thread block per CU; 6: two 768-thread blocks (the 4-waves kernels fit 80 registers); 8: two 1024-thread blocks
+	KernelFn2 kernel = ( waves == 8 ) ? ptk::diagTraceStreamDual<8, false> : ( dual ? ptk::diagTraceStreamDual<4, true> : ptk::diagTraceStreamDual<4, false> );
+	const int blocksPerCU = ( waves == 4 ) ? 1 : 2;
+	const unsigned blockThreads = ( waves == 6 ) ? 768u : (unsigned) PBR_BLOCK;
+	size_t slots = std::min<size_t>( (size_t) mode, ctx->numHotAvail );
+	slots = std::min<size_t>( slots, ( 160 * 1024 / (size_t) blocksPerCU - 256 ) / 32 );
+	slots = std::max<size_t>( slots, 1 );
+	P.numHot = (int) slots;
+	P.numHotBytes = (int) slots * 32;
+	HIP_TRY( ctx, hipFuncSetAttribute( (const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ( 160 * 1024 / blocksPerCU - 256 ) ) );
+
+	for( int r = 0; r < repeats; r++ ) {
+		HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, kWorkBytes, ctx->stream ) );
+		HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
+		hipLaunchKernelGGL( kernel, dim3( (unsigned) ( ctx->numCUs * blocksPerCU ) ), dim3( blockThreads ), slots * 32, ctx->stream, P, (const float4*) dRays.p, n, (float2*) dOut.p );
+		HIP_TRY( ctx, hipGetLastError() );
+		HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
+		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+		float ms = 0.0f;
+		HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
+		best = ( ms < best ) ? ms : best;
+	}
+
+	HIP_TRY( ctx, hipMemcpy( out2, dOut.p, sizeof( float ) * 2 * (size_t) n, hipMemcpyDeviceToHost ) );
+	*ms_out = best;
+	return PBR_OK;
+}
+#endif
 
 // Counter calibration: allocate a zero-filled table of table_bytes, read `reads` elements / records
 // in the given pattern (0 stream, 1 random 16 B, 2 random 32 B); reports the kernel time.  Run it

@@ -1036,8 +1036,8 @@ PT_DEV void nodePhasePair(
 		"v_cndmask_b32 v53, v52, v53, vcc\n"
 		"s_or_b64 %[parkMask], %[parkMask], vcc\n"
 		// the lanes whose next record is the adjacent one they have fetched: their next visit, from registers
-		"v_and_b32 v62, 1, v53\n"
-		"v_cmp_ne_u32 vcc, 0, v62\n"
+		"v_and_b32 v62, 0x80000001, v53\n"                   // (a walk that has ended is all ones: not a flag)
+		"v_cmp_eq_u32 vcc, 1, v62\n"
 		"s_and_b64 exec, exec, vcc\n"
 		"s_cbranch_scc0 2f\n"
 		"s_mov_b64 %[mA], exec\n"
@@ -1085,6 +1085,130 @@ PT_DEV void nodePhasePair(
 		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "vcc", "scc"
 	);
 }
+
+// ---- the node phase with TWO walks per lane (round 4, lab: traversal-only probe) ----------------------------
+// VERDICT r03 item 2 asks what "two rays per lane" buys: memory-level parallelism without more waves.  This is the
+// doubled node phase by itself: every lane carries walk A and walk B (cursors in v53 / v71, records in v[46:53] /
+// v[64:71]); an iteration issues A's fetches, then B's, waits once, runs A's slab test and B's.  44 vector + ~22 scalar
+// instructions per iteration for up to 128 visits.  Used by diagTraceStreamDual only (lab builds): what it is worth at
+// equal occupancy is measured there before any state machine is rebuilt around it.
+#ifdef PBR_LAB
+#define PT_DUAL_SLAB( n0a, n0b, n0c, n0d, n1a, n1b, oxy, ozz, ixy, izz ) \
+		"v_pk_add_f32 v[54:55], v[" n0a ":" n0b "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
+		"v_pk_add_f32 v[56:57], v[" n0c ":" n0d "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
+		"v_pk_add_f32 v[58:59], v[" n1a ":" n1b "], " ozz " neg_lo:[0,1] neg_hi:[0,1]\n" \
+		"v_pk_mul_f32 v[54:55], " ixy ", v[54:55]\n" \
+		"v_pk_mul_f32 v[56:57], " ixy ", v[56:57]\n" \
+		"v_pk_mul_f32 v[58:59], " izz ", v[58:59]\n" \
+		"v_min_f32 v60, v54, v56\n" \
+		"v_min_f32 v61, v55, v57\n" \
+		"v_min_f32 v62, v58, v59\n" \
+		"v_max3_f32 v60, v60, v61, v62\n" \
+		"v_max_f32 v61, v54, v56\n" \
+		"v_max_f32 v63, v58, v59\n" \
+		"v_max_f32 v62, v55, v57\n" \
+		"v_min3_f32 v61, v61, v62, v63\n"
+
+template<int DUMMY = 0>
+PT_DEV void nodePhaseDual(
+	const DevParams& P,
+	const f2v oxyA, const f2v ozzA, const f2v ixyA, const f2v izzA, float rayTA,
+	const f2v oxyB, const f2v ozzB, const f2v ixyB, const f2v izzB, float rayTB,
+	int keep, int& refA, int& refB, unsigned& visits,
+	int& leafWordA, float& tNearA, int& parkedA, int& leafWordB, float& tNearB, int& parkedB
+) {
+	const float eps = EPSILON5;
+	keep = __builtin_amdgcn_readfirstlane( keep );
+
+	asm volatile(
+		"s_mov_b64 s[84:85], exec\n"
+		"v_cmp_le_i32 s[86:87], 0, %[refA]\n"                // lanes whose walk A goes on
+		"v_cmp_le_i32 s[88:89], 0, %[refB]\n"
+		"s_mov_b64 s[90:91], 0\n"
+		"s_mov_b64 s[92:93], 0\n"
+		"v_mov_b32 v53, %[refA]\n"
+		"v_mov_b32 v71, %[refB]\n"
+	"1:\n"
+		"s_mov_b64 exec, s[86:87]\n"
+		"s_cbranch_execz 2f\n"
+		"v_cmp_gt_i32 vcc, %[numHotBytes], v53\n"
+		"s_and_saveexec_b64 s[94:95], vcc\n"
+		"ds_read_b128 v[46:49], v53\n"
+		"ds_read_b128 v[50:53], v53 offset:16\n"
+		"s_xor_b64 exec, exec, s[94:95]\n"
+		"global_load_dwordx4 v[46:49], v53, %[nodes]\n"
+		"global_load_dwordx4 v[50:53], v53, %[nodes] offset:16\n"
+	"2:\n"
+		"s_mov_b64 exec, s[88:89]\n"
+		"s_cbranch_execz 3f\n"
+		"v_cmp_gt_i32 vcc, %[numHotBytes], v71\n"
+		"s_and_saveexec_b64 s[94:95], vcc\n"
+		"ds_read_b128 v[64:67], v71\n"
+		"ds_read_b128 v[68:71], v71 offset:16\n"
+		"s_xor_b64 exec, exec, s[94:95]\n"
+		"global_load_dwordx4 v[64:67], v71, %[nodes]\n"
+		"global_load_dwordx4 v[68:71], v71, %[nodes] offset:16\n"
+	"3:\n"
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+		// ---- walk A
+		"s_mov_b64 exec, s[86:87]\n"
+		"s_cbranch_execz 4f\n"
+		"v_add_u32 %[visits], 1, %[visits]\n"
+		PT_DUAL_SLAB( "46", "47", "48", "49", "50", "51", "%[oxyA]", "%[ozzA]", "%[ixyA]", "%[izzA]" )
+		"v_cmpx_lt_f32 %[eps], v61\n"
+		"v_cmpx_gt_f32 %[rayTA], v60\n"
+		"v_cmpx_le_f32 v60, v61\n"
+		"v_cmp_gt_i32 vcc, 0, v52\n"
+		"v_cndmask_b32 v53, v52, v53, vcc\n"
+		"s_or_b64 s[90:91], s[90:91], vcc\n"
+		"s_mov_b64 exec, vcc\n"                               // the lanes that park now: their leaf word and tNear (v60 is B's next)
+		"v_mov_b32 %[leafWordA], v52\n"
+		"v_mov_b32 %[tNearA], v60\n"
+		"s_mov_b64 exec, s[86:87]\n"
+		"v_cmp_le_i32 s[94:95], 0, v53\n"
+		"s_andn2_b64 s[86:87], s[94:95], s[90:91]\n"
+	"4:\n"
+		// ---- walk B
+		"s_mov_b64 exec, s[88:89]\n"
+		"s_cbranch_execz 5f\n"
+		"v_add_u32 %[visits], 1, %[visits]\n"
+		PT_DUAL_SLAB( "64", "65", "66", "67", "68", "69", "%[oxyB]", "%[ozzB]", "%[ixyB]", "%[izzB]" )
+		"v_cmpx_lt_f32 %[eps], v61\n"
+		"v_cmpx_gt_f32 %[rayTB], v60\n"
+		"v_cmpx_le_f32 v60, v61\n"
+		"v_cmp_gt_i32 vcc, 0, v70\n"
+		"v_cndmask_b32 v71, v70, v71, vcc\n"
+		"s_or_b64 s[92:93], s[92:93], vcc\n"
+		"s_mov_b64 exec, vcc\n"
+		"v_mov_b32 %[leafWordB], v70\n"
+		"v_mov_b32 %[tNearB], v60\n"
+		"s_mov_b64 exec, s[88:89]\n"
+		"v_cmp_le_i32 s[94:95], 0, v71\n"
+		"s_andn2_b64 s[88:89], s[94:95], s[92:93]\n"
+	"5:\n"
+		"s_bcnt1_i32_b64 s96, s[86:87]\n"
+		"s_bcnt1_i32_b64 s97, s[88:89]\n"
+		"s_add_i32 s96, s96, s97\n"
+		"s_cmp_gt_i32 s96, %[keep]\n"
+		"s_cbranch_scc1 1b\n"
+		"s_mov_b64 exec, s[84:85]\n"
+		"v_mov_b32 %[refA], v53\n"
+		"v_mov_b32 %[refB], v71\n"
+		"v_cndmask_b32 %[parkedA], 0, 1, s[90:91]\n"
+		"v_cndmask_b32 %[parkedB], 0, 1, s[92:93]\n"
+		: [refA] "+v"( refA ), [refB] "+v"( refB ), [visits] "+v"( visits ),
+		  [leafWordA] "+v"( leafWordA ), [tNearA] "+v"( tNearA ), [parkedA] "=v"( parkedA ),
+		  [leafWordB] "+v"( leafWordB ), [tNearB] "+v"( tNearB ), [parkedB] "=v"( parkedB )
+		: [oxyA] "v"( oxyA ), [ozzA] "v"( ozzA ), [ixyA] "v"( ixyA ), [izzA] "v"( izzA ), [rayTA] "v"( rayTA ),
+		  [oxyB] "v"( oxyB ), [ozzB] "v"( ozzB ), [ixyB] "v"( ixyB ), [izzB] "v"( izzB ), [rayTB] "v"( rayTB ),
+		  [keep] "s"( keep ), [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps )
+		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
+		  "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc"
+	);
+}
+#undef PT_DUAL_SLAB
+#endif
 
 // ---- the node phase, asynchronous (round 4) --------------------------------------------------------
 // nodePhaseAsm ends every iteration in `s_waitcnt vmcnt(0)`: it lasts as long as its SLOWEST lane's fetch.  Measured in
@@ -2834,6 +2958,98 @@ __global__ __launch_bounds__( PBR_BLOCK, 8 ) void diagTraceStream( const DevPara
 //   MODE 0  coalesced stream: lane l reads element base + l (16 B per lane, 1 KiB per wave)
 //   MODE 1  one random 16-B element per lane and step
 //   MODE 2  one random 32-B record (two adjacent float4, like a BVH node) per lane and step
+#if defined( PBR_LAB ) && defined( PT_NODE_PHASE_ASM )
+// Traversal-only probe, one or two walks per lane, at MINW waves / SIMD (round 4, lab).  ONE walk: traverse() as the
+// lock-step kernels run it.  TWO: every lane draws two rays and walks both with nodePhaseDual; a lane's parked walks take
+// their leaf tests one after the other.  Same rays, same (t, face) per ray, same visit and face-test counts.
+template<int MINW, bool DUAL>
+__global__ __launch_bounds__( PBR_BLOCK, MINW ) void diagTraceStreamDual( const DevParams P, const float4* rays, unsigned n, float2* out ) {
+	const float4* lds = gHotNodes;
+	stageHotNodes( P, gHotNodes );
+	unsigned nodes = 0, tris = 0;
+
+	if( !DUAL ) {
+		unsigned i = atomicAdd( P.workCounter, 1u );
+
+		while( i < n ) {
+			const float4 a = rays[(size_t) i * 2 + 0];
+			const float4 b = rays[(size_t) i * 2 + 1];
+			Ray ray;
+			ray.origin = mk3( a.x, a.y, a.z );
+			ray.dir = mk3( b.x, b.y, b.z );
+			Hit hit;
+			hit.t = inff();
+			hit.face = 0;
+			traverse<false, false, true, false, ( MINW <= 4 )>( P, lds, ray, hit, nodes, tris );
+			out[i] = make_float2( hit.t, __int_as_float( hit.face ) );
+			i = atomicAdd( P.workCounter, 1u );
+		}
+	}
+	else {
+		unsigned i = atomicAdd( P.workCounter, 2u );
+
+		while( i < n ) {
+			const bool haveB = ( i + 1u < n );
+			const unsigned j = haveB ? i + 1u : i;
+			const float4 a0 = rays[(size_t) i * 2 + 0], a1 = rays[(size_t) i * 2 + 1];
+			const float4 b0 = rays[(size_t) j * 2 + 0], b1 = rays[(size_t) j * 2 + 1];
+			Ray rayA, rayB;
+			rayA.origin = mk3( a0.x, a0.y, a0.z );
+			rayA.dir = mk3( a1.x, a1.y, a1.z );
+			rayB.origin = mk3( b0.x, b0.y, b0.z );
+			rayB.dir = mk3( b1.x, b1.y, b1.z );
+			Hit hitA, hitB;
+			hitA.t = hitB.t = inff();
+			hitA.face = hitB.face = 0;
+			const f3 invA = mk3( 1.0f / rayA.dir.x, 1.0f / rayA.dir.y, 1.0f / rayA.dir.z );
+			const f3 invB = mk3( 1.0f / rayB.dir.x, 1.0f / rayB.dir.y, 1.0f / rayB.dir.z );
+			const f2v oxyA = { rayA.origin.x, rayA.origin.y }, ozzA = { rayA.origin.z, rayA.origin.z }, ixyA = { invA.x, invA.y }, izzA = { invA.z, invA.z };
+			const f2v oxyB = { rayB.origin.x, rayB.origin.y }, ozzB = { rayB.origin.z, rayB.origin.z }, ixyB = { invB.x, invB.y }, izzB = { invB.z, invB.z };
+			int refA = P.firstRef, refB = haveB ? P.firstRef : -1;
+			unsigned visits = 0;
+
+			for( ;; ) {
+				int leafWordA = 0, leafWordB = 0, parkedA = 0, parkedB = 0;
+				float tNearA = 0.0f, tNearB = 0.0f;
+
+				if( refA >= 0 || refB >= 0 ) {
+					const int entered = __popcll( __ballot( refA >= 0 ) ) + __popcll( __ballot( refB >= 0 ) );
+					const int leave = ( entered * P.parkEighths ) >> 3;
+					const int keep = entered - ( ( leave < 1 ) ? 1 : leave );
+					__builtin_amdgcn_s_setprio( PT_WALK_PRIO );
+					nodePhaseDual( P, oxyA, ozzA, ixyA, izzA, hitA.t, oxyB, ozzB, ixyB, izzB, hitB.t, keep, refA, refB, visits,
+					               leafWordA, tNearA, parkedA, leafWordB, tNearB, parkedB );
+					__builtin_amdgcn_s_setprio( 0 );
+				}
+
+				if( parkedA != 0 ) {
+					testLeaf<false, ( MINW <= 4 )>( P, leafFace0( leafWordA ), leafFace1( leafWordA ), rayA, tNearA, 0.0f, hitA, tris );
+				}
+				if( parkedB != 0 ) {
+					testLeaf<false, ( MINW <= 4 )>( P, leafFace0( leafWordB ), leafFace1( leafWordB ), rayB, tNearB, 0.0f, hitB, tris );
+				}
+
+				if( __ballot( refA >= 0 || refB >= 0 ) == 0ull ) {
+					break;
+				}
+			}
+
+			nodes += visits;
+			out[i] = make_float2( hitA.t, __int_as_float( hitA.face ) );
+
+			if( haveB ) {
+				out[j] = make_float2( hitB.t, __int_as_float( hitB.face ) );
+			}
+
+			i = atomicAdd( P.workCounter, 2u );
+		}
+	}
+
+	atomicAdd( &P.counters[0], (unsigned long long) nodes );
+	atomicAdd( &P.counters[1], (unsigned long long) tris );
+}
+#endif
+
 template<int MODE>
 __global__ __launch_bounds__( 256 ) void diagCalibrate( const float4* table, unsigned long long count, unsigned steps, float* sink ) {
 	const unsigned long long tid = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;

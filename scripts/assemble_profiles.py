@@ -25,10 +25,24 @@ def last_line_json(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
+PLAN_NAMES = ["refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid"]
+
+
+def library_stamp():
+    """Digest of the sources + flags csrc/libpbrhip.so was built from (build.py writes it next to the library): the counters
+    collected here are of THAT build, and bench.py prices a run with them only while it loads the same one."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        with open(os.path.join(root, "physically-based-rendering_amd", "csrc", "libpbrhip.so.srchash")) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def collect(out, loads):
     summary = {}
     for key in loads:
-        rec = {}
+        rec = {"library_srchash": library_stamp()}
         try:
             rec["bench"] = last_line_json("%s/bench_%s.json" % (out, key))
         except Exception as e:
@@ -89,7 +103,9 @@ def assemble(src, round_name):
         rd = r.get("fabric_read_bytes_per_launch", 0.0); wr = r.get("write_size_bytes", 0.0)
         sq_keys = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS")
         traffic[key] = {"scene": cfg["scene"], "width": cfg["width"], "height": cfg["height"], "max_depth": cfg["max_depth"], "brdf": cfg["brdf"], "steps": b["steps"],
-                        "schedule": b.get("schedule"), "fabric_read_bytes_per_launch": rd, "fabric_write_bytes_per_launch": wr,
+                        "schedule": b.get("schedule"), "plan": PLAN_NAMES.index(b["schedule"]) if b.get("schedule") in PLAN_NAMES else None,
+                        "srchash": r.get("library_srchash"),
+                        "fabric_read_bytes_per_launch": rd, "fabric_write_bytes_per_launch": wr,
                         "bytes_per_sample": (rd + wr) / samples, "l2_requests_per_launch": p.get("TCC_REQ_sum"), "l2_hit_rate": r.get("l2_hit_rate"),
                         "sq": {k: p[k] for k in sq_keys if k in p}, "how": HOW}
         f = newest("%s/stats_%s/*/*_kernel_trace.csv" % (src, key))[0]
@@ -107,9 +123,9 @@ def assemble(src, round_name):
         r["issue"] = {"valu_busy": busy, "salu_busy": p["SQ_INSTS_SALU"] * 2.0 / (1024 * 1e9 * ns * 1e-9), "lane_utilisation": r["valu_lane_utilisation"],
                       "useful_lane_throughput_frac": busy * r["valu_lane_utilisation"]}
         rdns = [v for k, v in p.items() if k.startswith("duration_ns(TCC_EA0_RDREQ")][0]
-        print("%-11s %7.1f Msamples/s %-12s launch %.3f ms | fabric %4.0f + %3.0f B/sample = %.2f TB/s read (%.0f %% of 8) | L2 hit %.3f, %.1f TB/s of requests | VALU busy %.0f %% x lanes %.0f %% = %.0f %% | waiting %.0f %% | cpu %.2f (%.0fx) | rocprof stats %d calls avg %.3f ms, timed %.3f vs events %.3f" % (
+        print("%-11s %7.1f Msamples/s %-12s launch %.3f ms | fabric %4.0f + %3.0f B/sample = %.2f TB/s read (%.0f %% of 8) | L2 hit %.3f, %.1f G requests/s | VALU busy %.0f %% x lanes %.0f %% = %.0f %% | waiting %.0f %% | cpu %.2f (%.0fx) | rocprof stats %d calls avg %.3f ms, timed %.3f vs events %.3f" % (
             key, b["value"], b["schedule"], b["roofline"]["launch_ms"], rd / samples, wr / samples, rd / rdns / 1e3, 100 * rd / rdns / 1e3 / 8.0,
-            r["l2_hit_rate"], p.get("TCC_REQ_sum", 0) * 128 / rdns / 1e3, 100 * busy, 100 * r["valu_lane_utilisation"], 100 * busy * r["valu_lane_utilisation"],
+            r["l2_hit_rate"], p.get("TCC_REQ_sum", 0) / rdns, 100 * busy, 100 * r["valu_lane_utilisation"], 100 * busy * r["valu_lane_utilisation"],
             100 * r["wave_wait_fraction"], b["cpu_baseline"]["value"], b["value"] / b["cpu_baseline"]["value"], calls, avg, dur, u["roofline"]["launch_ms"]))
     json.dump(d, open(dst + "/summary.json", "w"), indent=1)
     json.dump(traffic, open(dst + "/pmc_traffic.json", "w"), indent=1)
@@ -119,4 +135,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "--collect":
         collect(sys.argv[2], sys.argv[3:])
     else:
-        assemble(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r03")
+        assemble(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r04")

@@ -17,10 +17,10 @@ for key in $loads; do
   cd /tmp
   # warm-up as long as the timed render: every launch of the path-tracing kernel in kernel_stats.csv is then the same
   # work, and their average is comparable with the timed launch the bench line reports
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats_$key -- python3 $R/bench.py --scene $s $size --steps $steps --warmup $steps --plan $plan --cpu-seconds 0 > $R/$out/stats_$key.json 2> /dev/null
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats_$key -- python3 $R/bench.py --scene $s $size --steps $steps --warmup $steps --plan $plan --cpu-seconds 0 --hold-seconds 0 > $R/$out/stats_$key.json 2> /dev/null
   i=0
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM"; do
-    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$out/pmc${i}_$key -- python3 $R/bench.py --scene $s $size --steps $steps --plan $plan --cpu-seconds 0 > /dev/null 2>&1 || echo "pmc pass $i failed for $key"
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$out/pmc${i}_$key -- python3 $R/bench.py --scene $s $size --steps $steps --plan $plan --cpu-seconds 0 --hold-seconds 0 > /dev/null 2>&1 || echo "pmc pass $i failed for $key"
     i=$((i+1))
   done
   cd $R
