@@ -267,6 +267,12 @@ const int kWalkMid = ptk::WALK_SYNC;
 const bool kAsyncLean = ( kWalkLean == ptk::WALK_ASYNC ), kAsyncMid = ( kWalkMid == ptk::WALK_ASYNC );
 
 KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) {
+#if defined( PBR_LAB ) && defined( PBR_DUAL_LEAN )
+	if( !wide ) {      // lab: two paths per lane in the place of phased-lean (pt_kernel.hpp, pathTracingDual)
+		(void) brdf; (void) shadow; (void) lights;
+		return ptk::pathTracingDual<1, false, false>;
+	}
+#endif
 	return wide ? pickKernelPhasedMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelPhasedMode<PBR_LEAN_MINW, kWalkLean>( brdf, shadow, lights );
 }
 
@@ -497,7 +503,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		const size_t ldsPerCU = 160 * 1024;
 		const size_t share = ldsPerCU / (size_t) blocksPerCU - 256;
 		// asynchronous node phase: 32 B of the share per lane are the lanes' record slots (two planes of 1024 x 16 B)
+#if defined( PBR_LAB ) && defined( PBR_DUAL_LEAN )
+		// two paths per lane: 2 slots x 4 planes x 16 B x 1024 lanes of path state behind the staged tree top
+		const size_t slotBytes = ( plan == &ctx->plans[2] ) ? (size_t) 2 * 4 * 16 * PBR_BLOCK : ( async ? (size_t) 2 * PT_SLOT_PLANE : 0 );
+#else
 		const size_t slotBytes = async ? (size_t) 2 * PT_SLOT_PLANE : 0;
+#endif
 		size_t slots = ( share - slotBytes ) / 32;
 		slots = std::min<size_t>( slots, ctx->numHotAvail );
 
