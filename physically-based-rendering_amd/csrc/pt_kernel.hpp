@@ -980,397 +980,12 @@ PT_DEV void nodePhaseAsm(
 #undef PT_NODE_PHASE_OPERANDS
 }
 
-// ---- the node phase with the adjacent record fetched along (round 4, lab) ----------------------------------
-// VERDICT r03 item 1.  A cold fetch brings 64 B: the record and the next one of the stream (in DFS order a container's hit
-// successor; the same 128-byte line three times out of four).  pbr_upload_scene keeps a second copy of the stream for
-// this plan in which a container's w0 carries bit 0 when (a) the record lies behind the ranked prefix — so every lane that
-// sees it has fetched from memory, whatever the plan's LDS share — and (b) its hit successor is the adjacent record.  A
-// lane whose box is hit and whose new cursor carries the flag takes its NEXT visit at once, from registers: same
-// visit, same counters, one round trip to memory less.  Per lane the sequence of visits is the reference's
-// (pt_bvh.cl:88-122).  Registers: as nodePhaseAsm + v[64:71] for the adjacent record.
-template<int DUMMY = 0>
-PT_DEV void nodePhasePair(
-	const DevParams& P, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep,
-	int& ref, unsigned& visits, int& leafWord, float& leafTNear, int& parked
-) {
-	const float eps = EPSILON5;
-	keep = __builtin_amdgcn_readfirstlane( keep );
-	unsigned long long saved, active, parkMask, mA;
-	int count;
-
-	asm volatile(
-		"s_mov_b64 %[saved], exec\n"
-		"s_mov_b64 %[parkMask], 0\n"
-		"v_mov_b32 v53, %[ref]\n"
-	"1:\n"
-		"v_cmp_gt_i32 vcc, %[numHotBytes], v53\n"
-		"s_and_saveexec_b64 %[active], vcc\n"
-		"ds_read_b128 v[46:49], v53\n"
-		"ds_read_b128 v[50:53], v53 offset:16\n"
-		"s_xor_b64 exec, exec, %[active]\n"
-		"global_load_dwordx4 v[46:49], v53, %[nodes]\n"
-		"global_load_dwordx4 v[64:67], v53, %[nodes] offset:32\n"
-		"global_load_dwordx4 v[68:71], v53, %[nodes] offset:48\n"
-		"global_load_dwordx4 v[50:53], v53, %[nodes] offset:16\n"
-		"s_mov_b64 exec, %[active]\n"
-		"v_add_u32 %[visits], 1, %[visits]\n"
-		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-		"v_pk_add_f32 v[54:55], v[46:47], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
-		"v_pk_add_f32 v[56:57], v[48:49], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
-		"v_pk_add_f32 v[58:59], v[50:51], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"
-		"v_pk_mul_f32 v[54:55], %[ixy], v[54:55]\n"
-		"v_pk_mul_f32 v[56:57], %[ixy], v[56:57]\n"
-		"v_pk_mul_f32 v[58:59], %[izz], v[58:59]\n"
-		"v_min_f32 v60, v54, v56\n"
-		"v_min_f32 v61, v55, v57\n"
-		"v_min_f32 v62, v58, v59\n"
-		"v_max3_f32 v60, v60, v61, v62\n"
-		"v_max_f32 v61, v54, v56\n"
-		"v_max_f32 v63, v58, v59\n"
-		"v_max_f32 v62, v55, v57\n"
-		"v_min3_f32 v61, v61, v62, v63\n"
-		"v_cmpx_lt_f32 %[eps], v61\n"
-		"v_cmpx_gt_f32 %[rayT], v60\n"
-		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_gt_i32 vcc, 0, v52\n"
-		"v_cndmask_b32 v53, v52, v53, vcc\n"
-		"s_or_b64 %[parkMask], %[parkMask], vcc\n"
-		// the lanes whose next record is the adjacent one they have fetched: their next visit, from registers
-		"v_and_b32 v62, 0x80000001, v53\n"                   // (a walk that has ended is all ones: not a flag)
-		"v_cmp_eq_u32 vcc, 1, v62\n"
-		"s_and_b64 exec, exec, vcc\n"
-		"s_cbranch_scc0 2f\n"
-		"s_mov_b64 %[mA], exec\n"
-		"v_add_u32 %[visits], 1, %[visits]\n"
-		"v_pk_add_f32 v[54:55], v[64:65], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
-		"v_pk_add_f32 v[56:57], v[66:67], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
-		"v_pk_add_f32 v[58:59], v[68:69], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"
-		"v_pk_mul_f32 v[54:55], %[ixy], v[54:55]\n"
-		"v_pk_mul_f32 v[56:57], %[ixy], v[56:57]\n"
-		"v_pk_mul_f32 v[58:59], %[izz], v[58:59]\n"
-		"v_min_f32 v60, v54, v56\n"
-		"v_min_f32 v61, v55, v57\n"
-		"v_min_f32 v62, v58, v59\n"
-		"v_max3_f32 v60, v60, v61, v62\n"
-		"v_max_f32 v61, v54, v56\n"
-		"v_max_f32 v63, v58, v59\n"
-		"v_max_f32 v62, v55, v57\n"
-		"v_min3_f32 v61, v61, v62, v63\n"
-		"v_cmpx_lt_f32 %[eps], v61\n"
-		"v_cmpx_gt_f32 %[rayT], v60\n"
-		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_gt_i32 vcc, 0, v70\n"
-		"v_cndmask_b32 v71, v70, v71, vcc\n"
-		"s_or_b64 %[parkMask], %[parkMask], vcc\n"
-		"v_mov_b32 v52, v70\n"                               // a lane that parks here: its leaf word where the epilogue reads it
-		"s_mov_b64 exec, %[mA]\n"
-		"v_and_b32 v53, -2, v71\n"                           // the cursor never carries the flag into an address
-	"2:\n"
-		"s_mov_b64 exec, %[active]\n"
-		"v_cmp_le_i32 %[mA], 0, v53\n"
-		"s_andn2_b64 exec, %[mA], %[parkMask]\n"
-		"s_bcnt1_i32_b64 %[count], exec\n"
-		"s_cmp_gt_i32 %[count], %[keep]\n"
-		"s_cbranch_scc1 1b\n"
-		"s_mov_b64 exec, %[saved]\n"
-		"v_mov_b32 %[ref], v53\n"
-		"v_cndmask_b32 %[parked], 0, 1, %[parkMask]\n"
-		"v_mov_b32 %[leafWord], v52\n"
-		"v_mov_b32 %[leafTNear], v60\n"
-		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [parked] "=v"( parked ),
-		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [count] "=&s"( count )
-		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ),
-		  [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps )
-		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
-		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "vcc", "scc"
-	);
-}
-
-// ---- the node phase with TWO walks per lane (round 4, lab: traversal-only probe) ----------------------------
-// VERDICT r03 item 2 asks what "two rays per lane" buys: memory-level parallelism without more waves.  This is the
-// doubled node phase by itself: every lane carries walk A and walk B (cursors in v53 / v71, records in v[46:53] /
-// v[64:71]); an iteration issues A's fetches, then B's, waits once, runs A's slab test and B's.  44 vector + ~22 scalar
-// instructions per iteration for up to 128 visits.  Used by diagTraceStreamDual only (lab builds): what it is worth at
-// equal occupancy is measured there before any state machine is rebuilt around it.
+// Round 4 measured three more node phases — the adjacent record fetched along (nodePhasePair), two walks per lane
+// (nodePhaseDual) and polled LDS-DMA slots (nodePhaseAsync) — all bit-identical, none faster than this one: lab/src/pt_r04_node_phases.hpp,
+// profiles/r04/experiments/{pair_fetch,two_paths_per_lane,async_node_phase}.txt.  Lab builds (-DPBR_LAB) compile them in; the product does not.
 #ifdef PBR_LAB
-#define PT_DUAL_SLAB( n0a, n0b, n0c, n0d, n1a, n1b, oxy, ozz, ixy, izz ) \
-		"v_pk_add_f32 v[54:55], v[" n0a ":" n0b "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
-		"v_pk_add_f32 v[56:57], v[" n0c ":" n0d "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
-		"v_pk_add_f32 v[58:59], v[" n1a ":" n1b "], " ozz " neg_lo:[0,1] neg_hi:[0,1]\n" \
-		"v_pk_mul_f32 v[54:55], " ixy ", v[54:55]\n" \
-		"v_pk_mul_f32 v[56:57], " ixy ", v[56:57]\n" \
-		"v_pk_mul_f32 v[58:59], " izz ", v[58:59]\n" \
-		"v_min_f32 v60, v54, v56\n" \
-		"v_min_f32 v61, v55, v57\n" \
-		"v_min_f32 v62, v58, v59\n" \
-		"v_max3_f32 v60, v60, v61, v62\n" \
-		"v_max_f32 v61, v54, v56\n" \
-		"v_max_f32 v63, v58, v59\n" \
-		"v_max_f32 v62, v55, v57\n" \
-		"v_min3_f32 v61, v61, v62, v63\n"
-
-template<int DUMMY = 0>
-PT_DEV void nodePhaseDual(
-	const DevParams& P,
-	const f2v oxyA, const f2v ozzA, const f2v ixyA, const f2v izzA, float rayTA,
-	const f2v oxyB, const f2v ozzB, const f2v ixyB, const f2v izzB, float rayTB,
-	int keep, int& refA, int& refB, unsigned& visitsA, unsigned& visitsB,
-	int& leafWordA, float& tNearA, int& leafWordB, float& tNearB      // leaf word != 0 on return: the walk parked on that hit leaf
-) {
-	const float eps = EPSILON5;
-	keep = __builtin_amdgcn_readfirstlane( keep );
-
-	asm volatile(
-		"s_mov_b64 s[84:85], exec\n"
-		"v_cmp_le_i32 s[86:87], 0, %[refA]\n"                // lanes whose walk A goes on
-		"v_cmp_le_i32 s[88:89], 0, %[refB]\n"
-		"s_mov_b64 s[90:91], 0\n"
-		"s_mov_b64 s[92:93], 0\n"
-		"v_mov_b32 v53, %[refA]\n"
-		"v_mov_b32 v71, %[refB]\n"
-	"1:\n"
-		"s_mov_b64 exec, s[86:87]\n"
-		"s_cbranch_execz 2f\n"
-		"v_cmp_gt_i32 vcc, %[numHotBytes], v53\n"
-		"s_and_saveexec_b64 s[94:95], vcc\n"
-		"ds_read_b128 v[46:49], v53\n"
-		"ds_read_b128 v[50:53], v53 offset:16\n"
-		"s_xor_b64 exec, exec, s[94:95]\n"
-		"global_load_dwordx4 v[46:49], v53, %[nodes]\n"
-		"global_load_dwordx4 v[50:53], v53, %[nodes] offset:16\n"
-	"2:\n"
-		"s_mov_b64 exec, s[88:89]\n"
-		"s_cbranch_execz 3f\n"
-		"v_cmp_gt_i32 vcc, %[numHotBytes], v71\n"
-		"s_and_saveexec_b64 s[94:95], vcc\n"
-		"ds_read_b128 v[64:67], v71\n"
-		"ds_read_b128 v[68:71], v71 offset:16\n"
-		"s_xor_b64 exec, exec, s[94:95]\n"
-		"global_load_dwordx4 v[64:67], v71, %[nodes]\n"
-		"global_load_dwordx4 v[68:71], v71, %[nodes] offset:16\n"
-	"3:\n"
-		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-		// ---- walk A
-		"s_mov_b64 exec, s[86:87]\n"
-		"s_cbranch_execz 4f\n"
-		"v_add_u32 %[visitsA], 1, %[visitsA]\n"
-		PT_DUAL_SLAB( "46", "47", "48", "49", "50", "51", "%[oxyA]", "%[ozzA]", "%[ixyA]", "%[izzA]" )
-		"v_cmpx_lt_f32 %[eps], v61\n"
-		"v_cmpx_gt_f32 %[rayTA], v60\n"
-		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_gt_i32 vcc, 0, v52\n"
-		"v_cndmask_b32 v53, v52, v53, vcc\n"
-		"s_or_b64 s[90:91], s[90:91], vcc\n"
-		"s_mov_b64 exec, vcc\n"                               // the lanes that park now: their leaf word and tNear (v60 is B's next)
-		"v_mov_b32 %[leafWordA], v52\n"
-		"v_mov_b32 %[tNearA], v60\n"
-		"s_mov_b64 exec, s[86:87]\n"
-		"v_cmp_le_i32 s[94:95], 0, v53\n"
-		"s_andn2_b64 s[86:87], s[94:95], s[90:91]\n"
-	"4:\n"
-		// ---- walk B
-		"s_mov_b64 exec, s[88:89]\n"
-		"s_cbranch_execz 5f\n"
-		"v_add_u32 %[visitsB], 1, %[visitsB]\n"
-		PT_DUAL_SLAB( "64", "65", "66", "67", "68", "69", "%[oxyB]", "%[ozzB]", "%[ixyB]", "%[izzB]" )
-		"v_cmpx_lt_f32 %[eps], v61\n"
-		"v_cmpx_gt_f32 %[rayTB], v60\n"
-		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_gt_i32 vcc, 0, v70\n"
-		"v_cndmask_b32 v71, v70, v71, vcc\n"
-		"s_or_b64 s[92:93], s[92:93], vcc\n"
-		"s_mov_b64 exec, vcc\n"
-		"v_mov_b32 %[leafWordB], v70\n"
-		"v_mov_b32 %[tNearB], v60\n"
-		"s_mov_b64 exec, s[88:89]\n"
-		"v_cmp_le_i32 s[94:95], 0, v71\n"
-		"s_andn2_b64 s[88:89], s[94:95], s[92:93]\n"
-	"5:\n"
-		"s_bcnt1_i32_b64 s96, s[86:87]\n"
-		"s_bcnt1_i32_b64 s97, s[88:89]\n"
-		"s_add_i32 s96, s96, s97\n"
-		"s_cmp_gt_i32 s96, %[keep]\n"
-		"s_cbranch_scc1 1b\n"
-		"s_mov_b64 exec, s[84:85]\n"
-		"v_mov_b32 %[refA], v53\n"
-		"v_mov_b32 %[refB], v71\n"
-		: [refA] "+v"( refA ), [refB] "+v"( refB ), [visitsA] "+v"( visitsA ), [visitsB] "+v"( visitsB ),
-		  [leafWordA] "+v"( leafWordA ), [tNearA] "+v"( tNearA ), [leafWordB] "+v"( leafWordB ), [tNearB] "+v"( tNearB )
-		: [oxyA] "v"( oxyA ), [ozzA] "v"( ozzA ), [ixyA] "v"( ixyA ), [izzA] "v"( izzA ), [rayTA] "v"( rayTA ),
-		  [oxyB] "v"( oxyB ), [ozzB] "v"( ozzB ), [ixyB] "v"( ixyB ), [izzB] "v"( izzB ), [rayTB] "v"( rayTB ),
-		  [keep] "s"( keep ), [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps )
-		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
-		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
-		  "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc"
-	);
-}
-#undef PT_DUAL_SLAB
+#include "pt_r04_node_phases.hpp"
 #endif
-
-// ---- the node phase, asynchronous (round 4) --------------------------------------------------------
-// nodePhaseAsm ends every iteration in `s_waitcnt vmcnt(0)`: it lasts as long as its SLOWEST lane's fetch.  Measured in
-// round 3 on the Sponza-class scene: an L1 miss comes back after 194 cycles on average, an iteration lasts ~900 — with
-// ~18 lanes on cold records and an L2 hit rate of 84 %, 96 % of all iterations contain at least one request that goes
-// on to the Infinity Cache or HBM, and 62 % of all wave-cycles are spent waiting.  s_waitcnt cannot wait for "most" of
-// a wave's lanes; a load to registers has no other way of telling that it has arrived.
-//
-// A load to LDS has: the bytes are simply there at some point.  Here every lane owns a 32-byte SLOT in LDS (two 16-byte
-// halves, PT_SLOT_PLANE apart, lane-linear — the only destination shape an LDS-DMA has: M0 + offset + 16 * lane).  A
-// lane whose next record is cold writes a marker into each half of its slot (the record's last word, w1, is a byte
-// offset or negative — never 1; the last word of the first half is a box coordinate — never the NaN 0xFFFFFFFF:
-// pbr_upload_scene stores every NaN of a box as 0x7FC00000, which no comparison can tell apart), requests the record
-// with two `global_load_lds_dwordx4` and goes on polling: every iteration
-// reads, for every walking lane, either the staged record (hot) or the lane's slot (cold), and the lanes whose record
-// is there — hot, or marker overwritten — take their visit; the others keep their state and are asked again in the
-// next iteration.  An iteration starts as soon as P.asyncEighths / 8 of the walking lanes are ready (else the wave
-// sleeps 64 cycles and polls again), so a far miss delays ITS lane, not the wave.  No wait on vmcnt anywhere in the loop.
-// Nothing orders a ds_read behind a pending LDS-DMA (MI355X_MICROARCH.md, item 7: "a read issued earlier returns the OLD
-// LDS bytes, no stall") — which is exactly the behaviour polled for.  Measured with scripts/micro/glds_poll.hip
-// (profiles/r04/experiments/glds_poll.txt, 6e9 records per variant, each checked word by word): a lane's 16 bytes land
-// at once, but the two halves of a record land IN EITHER ORDER (with a marker in the second half only, 0.02 % of the
-// records were consumed torn; with both, none) — hence the two markers.
-// Invariant between phases: a walking lane's cursor is either the reference of a staged record (< P.slotBase) or the
-// LDS address of its own slot, with the request issued (cold cursors are replaced by the slot address when the request
-// goes out; a lane that parks on a leaf has its next record requested before the leaf phase).  Per lane the sequence of
-// visits is the reference's; only which iteration a visit falls into changes.
-// Registers: v46-v63 as nodePhaseAsm; v64 = address of the second half - 16, v65 = this lane's slot + 12, v66 / v67 = the markers.
-// Scalars s84-s99 are the block's own (clobbered): saved exec, walking lanes, ready lanes, parked lanes, a temporary
-// mask, counts, the compiler's M0, the error flag (s83).
-#if defined( PBR_DBG_NOREARM )
-#define PT_ASYNC_REARM ""
-#elif defined( PBR_DBG_REARM2 )
-#define PT_ASYNC_REARM "ds_write_b32 v65, v67\n" "ds_write_b32 v65, v66 offset:16384\n"
-#else
-#define PT_ASYNC_REARM "ds_write2st64_b32 v65, v67, v66 offset1:64\n"        // both markers back into this lane's slot (+ 12, + PT_SLOT_PLANE + 12)
-#endif
-#if defined( PBR_DBG_NOP )
-#define PT_ASYNC_NOP "s_nop 7\n"
-#else
-#define PT_ASYNC_NOP ""
-#endif
-#define PT_ASYNC_POLL_LIMIT 0x100000
-
-template<int DUMMY = 0>
-PT_DEV void nodePhaseAsync(
-	const DevParams& P, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep, int m0a,
-	int& ref, unsigned& visits, int& leafWord, float& leafTNear, int& parked, int& err
-) {
-	const float eps = EPSILON5;
-	keep = __builtin_amdgcn_readfirstlane( keep );
-	m0a = __builtin_amdgcn_readfirstlane( m0a );         // P.slotBase + 1024 * (wave of the block): + 16 * lane by the hardware
-
-	asm volatile(
-		"s_mov_b64 s[84:85], exec\n"
-		"s_mov_b64 s[86:87], exec\n"
-		"s_mov_b64 s[90:91], 0\n"
-		"s_mov_b32 s98, m0\n"
-		"s_mov_b32 s97, 0\n"
-		"s_mov_b32 s83, 0\n"
-		"s_add_u32 s99, %[m0a], 16368\n"                     // second half: M0 + offset:16 + 16 * lane = slot + PT_SLOT_PLANE
-		"v_mbcnt_lo_u32_b32 v65, -1, 0\n"
-		"v_mbcnt_hi_u32_b32 v65, -1, v65\n"
-		"v_lshl_add_u32 v65, v65, 4, %[m0a]\n"
-		"v_add_u32 v65, 12, v65\n"                           // this lane's slot + 12: its first marker
-		"v_mov_b32 v66, 1\n"
-		"v_mov_b32 v67, -1\n"
-		"v_add_u32 v64, 16356, v65\n"                        // slot + PT_SLOT_PLANE - 16
-		"v_cmp_gt_i32 vcc, %[slotBase], %[ref]\n"            // staged record?  else the cursor is the slot (request issued)
-		"v_cndmask_b32 v64, v64, %[ref], vcc\n"
-		"s_bcnt1_i32_b64 s95, exec\n"
-	"1:\n"
-		"s_mul_i32 s96, s95, %[eighths]\n"                    // lanes that must be ready for an iteration to start
-		"s_lshr_b32 s96, s96, 3\n"
-		"s_max_i32 s96, s96, 1\n"
-	"2:\n"
-		"ds_read_b128 v[46:49], %[ref]\n"
-		"ds_read_b128 v[50:53], v64 offset:16\n"
-		"s_waitcnt lgkmcnt(0)\n"
-		"v_cmp_ne_u32 vcc, 1, v53\n"                          // the record is there: staged, or BOTH markers are gone
-		"v_cmp_ne_u32 s[92:93], -1, v49\n"                   // (the halves land in either order, scripts/micro/glds_poll.hip)
-		"s_and_b64 vcc, vcc, s[92:93]\n"
-		"s_bcnt1_i32_b64 s94, vcc\n"
-		"s_cmp_ge_i32 s94, s96\n"
-		"s_cbranch_scc1 3f\n"
-		"s_add_i32 s97, s97, 1\n"
-		"s_cmp_gt_i32 s97, %[pollLimit]\n"
-		"s_cbranch_scc1 8f\n"
-		"s_sleep 1\n"
-		"s_branch 2b\n"
-	"3:\n"
-		"s_mov_b64 s[88:89], vcc\n"
-		"s_mov_b64 exec, vcc\n"
-		PT_ASYNC_REARM
-		"v_add_u32 %[visits], 1, %[visits]\n"
-		"v_pk_add_f32 v[54:55], v[46:47], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
-		"v_pk_add_f32 v[56:57], v[48:49], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
-		"v_pk_add_f32 v[58:59], v[50:51], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"
-		"v_pk_mul_f32 v[54:55], %[ixy], v[54:55]\n"
-		"v_pk_mul_f32 v[56:57], %[ixy], v[56:57]\n"
-		"v_pk_mul_f32 v[58:59], %[izz], v[58:59]\n"
-		"v_min_f32 v60, v54, v56\n"
-		"v_min_f32 v61, v55, v57\n"
-		"v_min_f32 v62, v58, v59\n"
-		"v_max3_f32 v60, v60, v61, v62\n"
-		"v_max_f32 v61, v54, v56\n"
-		"v_max_f32 v63, v58, v59\n"
-		"v_max_f32 v62, v55, v57\n"
-		"v_min3_f32 v61, v61, v62, v63\n"
-		"v_cmpx_lt_f32 %[eps], v61\n"
-		"v_cmpx_gt_f32 %[rayT], v60\n"
-		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_le_i32 vcc, 0, v52\n"                          // hit container
-		PT_ASYNC_NOP
-		"s_andn2_b64 s[92:93], exec, vcc\n"                   // hit leaf: parks
-		"s_or_b64 s[90:91], s[90:91], s[92:93]\n"
-		"s_mov_b64 exec, s[88:89]\n"
-		"v_cndmask_b32 %[ref], v53, v52, vcc\n"               // hit container -> w0, everything else -> w1
-		"v_mov_b32 v64, %[ref]\n"
-		"v_cmp_gt_i32 vcc, 0, %[ref]\n"                       // the walk has ended
-		"s_or_b64 s[92:93], s[92:93], vcc\n"
-		"s_andn2_b64 s[86:87], s[86:87], s[92:93]\n"
-		"v_cmp_le_i32 vcc, %[slotBase], %[ref]\n"             // next record cold: request it (parked lanes too)
-		"s_and_b64 exec, exec, vcc\n"
-		"s_cbranch_scc0 4f\n"
-		"s_waitcnt lgkmcnt(0)\n"                              // the marker is in the slot before the request leaves
-		"s_mov_b32 m0, %[m0a]\n"
-		"s_nop 0\n"
-		"global_load_lds_dwordx4 %[ref], %[nodes]\n"
-		"s_mov_b32 m0, s99\n"
-		"s_nop 0\n"
-		"global_load_lds_dwordx4 %[ref], %[nodes] offset:16\n"
-		"v_add_u32 %[ref], -12, v65\n"
-		"v_add_u32 v64, 16356, v65\n"
-	"4:\n"
-		"s_mov_b64 exec, s[86:87]\n"
-		"s_bcnt1_i32_b64 s95, s[86:87]\n"
-		"s_cmp_gt_i32 s95, %[keep]\n"
-		"s_cbranch_scc1 1b\n"
-	"5:\n"
-		"s_mov_b64 exec, s[84:85]\n"
-		"s_mov_b32 m0, s98\n"
-		"v_cndmask_b32 %[parked], 0, 1, s[90:91]\n"
-		"v_mov_b32 %[leafWord], v52\n"
-		"v_mov_b32 %[leafTNear], v60\n"
-		"v_mov_b32 %[err], s83\n"
-		"s_branch 7f\n"
-	"8:\n"                                                    // the poll limit: never hang a GPU
-		"s_waitcnt vmcnt(0)\n"
-		"s_cmp_eq_u32 s83, 0\n"
-		"s_mov_b32 s83, 1\n"
-		"s_mov_b32 s97, 0\n"
-		"s_cbranch_scc1 2b\n"
-		"v_mov_b32 %[ref], -1\n"
-		"s_branch 5b\n"
-	"7:\n"
-		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [parked] "=v"( parked ), [err] "=v"( err )
-		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ),
-		  [slotBase] "s"( P.slotBase ), [nodes] "s"( P.nodes ), [eps] "s"( eps ), [m0a] "s"( m0a ), [eighths] "s"( P.asyncEighths ),
-		  [pollLimit] "n"( PT_ASYNC_POLL_LIMIT )
-		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
-		  "v64", "v65", "v66", "v67", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
-		  "vcc", "scc", "memory"
-	);
-}
 #endif
 
 // traverse (pt_bvh.cl:82-123) / traverseShadows (:133-177).  ANYHIT: the shadow variant — no
@@ -2584,6 +2199,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				int leafWord = 0, parkedFlag;
 				float unusedTFar;
 				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );   // through the leaf phase below
+#ifdef PBR_LAB      // the round-4 variants exist in lab builds only (lab/src/pt_r04_node_phases.hpp)
 				if( ASYNC ) {
 					(void) unusedTFar;
 					int phaseErr;
@@ -2594,7 +2210,9 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 					(void) unusedTFar;
 					nodePhasePair( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, parkedFlag );
 				}
-				else {
+				else
+#endif
+				{
 #ifdef PBR_EXP_PARKED_ONLY
 					// lab: the phase ends once parkNow lanes (at most half of those that entered) stand on a leaf
 					const int entered = keep + parkNow;
@@ -2718,225 +2336,8 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 }
 
 
-// ---------------------------------------------------------------------------------------
-// Phased schedule with TWO paths per lane (round 4, lab: VERDICT r03 item 2)
-// ---------------------------------------------------------------------------------------
-// The lane state machine above, with two path slots A and B per lane: 128 paths per wave at 4 waves / SIMD.
-//   node phase   nodePhaseDual: both slots' fetches are issued before one wait, then both slab tests — twice the
-//                requests in flight per wave without a second wave's registers
-//   leaf phase   POOLED: a lane tests the leaf of whichever of its slots stands on one (A first; the other in the next
-//                round) — one pass of the face tests serves lanes of both slots
-//   shade phase  POOLED the same way: a lane shades whichever slot waits for shading; the threshold counts lanes
-// In registers per slot: ray, 1 / direction, cursor, closest hit, the parked leaf, mode, the walk's counters (17).  Everything
-// else a path carries between bounces (PixelState's cold half: 16 dwords) lives in LDS, in four lane-linear 16-byte planes
-// per slot behind the staged tree top (2 x 64 B x 1024 lanes = 128 KiB), and is in registers only while its slot is shaded.
-// Per path the sequence of visits, face tests and random draws is the reference's: same image, same debug image, same counters.
 #if defined( PBR_LAB ) && defined( PT_NODE_PHASE_ASM )
-struct DualSlot {
-	Ray ray;
-	f3 invDir;
-	int cur;            // cursor (byte offset of the next record); < 0: the walk has ended
-	float t;            // closest hit so far
-	int face;
-	int leafWord;       // != 0: parked on this hit leaf (MODE_LEAF)
-	float leafTNear;
-	int mode;
-	unsigned nodes, tris;   // of the current walk(s) since the slot was last shaded: added to the path's counters there
-};
-
-PT_DEV float4* coldPlane( const DevParams& P, int slot, int plane ) {
-	return (float4*) ( (char*) gHotNodes + P.slotBase ) + ( slot * 4 + plane ) * PBR_BLOCK + (int) threadIdx.x;
-}
-
-PT_DEV void loadCold( const DevParams& P, int slot, PixelState& st ) {
-	const float4 a = *coldPlane( P, slot, 0 ), b = *coldPlane( P, slot, 1 ), c = *coldPlane( P, slot, 2 ), d = *coldPlane( P, slot, 3 );
-	st.slot = __float_as_uint( a.x ); st.frame = __float_as_int( a.y ); st.sample = __float_as_int( a.z ); st.finalColor.x = a.w;
-	st.finalColor.y = b.x; st.finalColor.z = b.y; st.secondaryPaths = __float_as_uint( b.z ); st.focus = b.w;
-	st.seed = c.x; st.dbgNodes = __float_as_uint( c.y ); st.dbgTris = __float_as_uint( c.z ); st.color.x = c.w;
-	st.color.y = d.x; st.color.z = d.y; st.depth = __float_as_int( d.z ); st.depthAdded = __float_as_int( d.w );
-}
-
-PT_DEV void storeCold( const DevParams& P, int slot, const PixelState& st ) {
-	*coldPlane( P, slot, 0 ) = make_float4( __uint_as_float( st.slot ), __int_as_float( st.frame ), __int_as_float( st.sample ), st.finalColor.x );
-	*coldPlane( P, slot, 1 ) = make_float4( st.finalColor.y, st.finalColor.z, __uint_as_float( st.secondaryPaths ), st.focus );
-	*coldPlane( P, slot, 2 ) = make_float4( st.seed, __uint_as_float( st.dbgNodes ), __uint_as_float( st.dbgTris ), st.color.x );
-	*coldPlane( P, slot, 3 ) = make_float4( st.color.y, st.color.z, __int_as_float( st.depth ), __int_as_float( st.depthAdded ) );
-}
-
-template<bool LIGHTS>
-PT_DEV void startWalkDual( const DevParams& P, DualSlot& s ) {
-	s.invDir = mk3( 1.0f / s.ray.dir.x, 1.0f / s.ray.dir.y, 1.0f / s.ray.dir.z );
-	s.cur = P.firstRef;
-	Hit h;
-	h.t = inff();
-	h.face = 0;
-
-	if( LIGHTS ) {
-		traverseLights( P, s.ray, h );
-	}
-
-	s.t = h.t;
-	s.face = h.face;
-	s.leafWord = 0;
-	s.leafTNear = 0.0f;
-	s.mode = MODE_NODE;
-}
-
-template<int BRDF, bool SHADOW, bool LIGHTS>
-__global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual( const DevParams P ) {
-	const float4* lds = gHotNodes;
-	stageHotNodes( P, gHotNodes );
-	LaneCounters cnt;
-	cnt.nodes = cnt.tris = cnt.hits = cnt.paths = 0;
-	DualSlot A, B;
-	A.mode = B.mode = MODE_DONE;
-	A.cur = B.cur = -1;
-	A.leafWord = B.leafWord = 0;
-	A.nodes = A.tris = B.nodes = B.tris = 0;
-	A.t = B.t = 0.0f;
-	A.face = B.face = 0;
-	A.leafTNear = B.leafTNear = 0.0f;
-	A.ray.origin = A.ray.dir = A.invDir = B.ray.origin = B.ray.dir = B.invDir = mk3( 0.0f, 0.0f, 0.0f );
-	WorkCursor work = beginWork();
-
-	// both slots take their first unit
-	for( int k = 0; k < 2; k++ ) {
-		unsigned frame = 0;
-		const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
-
-		if( slot != PT_NO_WORK ) {
-			PixelState st;
-			beginPixel( P, st, slot, cnt, frame );
-			DualSlot& S = ( k == 0 ) ? A : B;
-			S.ray = st.ray;
-			startWalkDual<LIGHTS>( P, S );
-			storeCold( P, k, st );
-		}
-	}
-
-	while( __ballot( A.mode != MODE_DONE || B.mode != MODE_DONE ) != 0ull ) {
-		// ---- node phase: both slots of every lane ----------------------------------------------------
-		if( A.mode == MODE_NODE || B.mode == MODE_NODE ) {
-			const int walking = __popcll( __ballot( A.mode == MODE_NODE ) ) + __popcll( __ballot( B.mode == MODE_NODE ) );
-			const int keep = walking - P.phPark;
-			const f2v oxyA = { A.ray.origin.x, A.ray.origin.y }, ozzA = { A.ray.origin.z, A.ray.origin.z }, ixyA = { A.invDir.x, A.invDir.y }, izzA = { A.invDir.z, A.invDir.z };
-			const f2v oxyB = { B.ray.origin.x, B.ray.origin.y }, ozzB = { B.ray.origin.z, B.ray.origin.z }, ixyB = { B.invDir.x, B.invDir.y }, izzB = { B.invDir.z, B.invDir.z };
-			int refA = ( A.mode == MODE_NODE ) ? A.cur : -1;      // a slot that is not walking sits the phase out
-			int refB = ( B.mode == MODE_NODE ) ? B.cur : -1;
-			int leafWordA = 0, leafWordB = 0;
-			float tNearA = 0.0f, tNearB = 0.0f;
-			__builtin_amdgcn_s_setprio( PT_WALK_PRIO );
-			nodePhaseDual( P, oxyA, ozzA, ixyA, izzA, A.t, oxyB, ozzB, ixyB, izzB, B.t, ( keep < 0 ) ? 0 : keep, refA, refB, A.nodes, B.nodes,
-			               leafWordA, tNearA, leafWordB, tNearB );
-			__builtin_amdgcn_s_setprio( 0 );
-
-			if( A.mode == MODE_NODE ) {
-				A.cur = refA;
-				A.leafWord = leafWordA;
-				A.leafTNear = tNearA;
-				A.mode = ( leafWordA != 0 ) ? MODE_LEAF : ( ( refA < 0 ) ? MODE_SHADE : MODE_NODE );
-			}
-			if( B.mode == MODE_NODE ) {
-				B.cur = refB;
-				B.leafWord = leafWordB;
-				B.leafTNear = tNearB;
-				B.mode = ( leafWordB != 0 ) ? MODE_LEAF : ( ( refB < 0 ) ? MODE_SHADE : MODE_NODE );
-			}
-		}
-
-		// ---- leaf phase, pooled: the slot that stands on a leaf (A first) ---------------------------------
-		// (PBR_DUAL_LEAF2 = n: a second pass at once when n or more lanes still have a slot on a leaf — both were parked)
-#ifndef PBR_DUAL_LEAF2
-#define PBR_DUAL_LEAF2 0
-#endif
-		for( int pass = 0; pass < 2; pass++ ) {
-			const bool leafA = ( A.mode == MODE_LEAF ), leafB = ( B.mode == MODE_LEAF );
-
-			if( pass == 1 && ( PBR_DUAL_LEAF2 == 0 || __popcll( __ballot( leafA || leafB ) ) < PBR_DUAL_LEAF2 ) ) {
-				break;
-			}
-
-			if( leafA || leafB ) {
-				const bool useB = !leafA;
-				Ray ray;
-				ray.origin = useB ? B.ray.origin : A.ray.origin;
-				ray.dir = useB ? B.ray.dir : A.ray.dir;
-				Hit hit;
-				hit.t = useB ? B.t : A.t;
-				hit.face = useB ? B.face : A.face;
-				const int leafWord = useB ? B.leafWord : A.leafWord;
-				const float tNear = useB ? B.leafTNear : A.leafTNear;
-				unsigned tests = 0;
-				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );
-				testLeaf<false, true>( P, leafFace0( leafWord ), leafFace1( leafWord ), ray, tNear, 0.0f, hit, tests );
-				__builtin_amdgcn_s_setprio( 0 );
-
-				if( useB ) {
-					B.t = hit.t; B.face = hit.face; B.tris += tests; B.leafWord = 0;
-					B.mode = ( B.cur < 0 ) ? MODE_SHADE : MODE_NODE;
-				}
-				else {
-					A.t = hit.t; A.face = hit.face; A.tris += tests; A.leafWord = 0;
-					A.mode = ( A.cur < 0 ) ? MODE_SHADE : MODE_NODE;
-				}
-			}
-		}
-
-		// ---- shade phase, pooled: the slot that waits for shading (A first); the threshold counts lanes ------
-		{
-			const bool shadeA = ( A.mode == MODE_SHADE ), shadeB = ( B.mode == MODE_SHADE );
-			const int nShade = __popcll( __ballot( shadeA || shadeB ) );
-			const bool busy = ( __ballot( A.mode == MODE_NODE || A.mode == MODE_LEAF || B.mode == MODE_NODE || B.mode == MODE_LEAF ) != 0ull );
-
-			if( ( shadeA || shadeB ) && ( nShade >= P.phShade || !busy ) ) {
-				const bool useB = !shadeA;
-				const int which = useB ? 1 : 0;
-				PixelState st;
-				loadCold( P, which, st );
-				st.ray.origin = useB ? B.ray.origin : A.ray.origin;
-				st.ray.dir = useB ? B.ray.dir : A.ray.dir;
-				st.dbgNodes += useB ? B.nodes : A.nodes;
-				st.dbgTris += useB ? B.tris : A.tris;
-				Hit hit;
-				hit.t = useB ? B.t : A.t;
-				hit.face = useB ? B.face : A.face;
-				hit.normal = mk3( 0.0f, 0.0f, 0.0f );
-				bool more = true;
-
-				if( shadeStep<BRDF, SHADOW, LIGHTS, false, true, true>( P, lds, st, cnt, hit ) ) {
-					finishPixel( P, st );
-
-					if( cnt.nodes > 0x40000000u || cnt.tris > 0x40000000u ) {
-						flushCounters( P, cnt );
-					}
-
-					unsigned frame = 0;
-					const unsigned slot = nextSlot( P, work, (unsigned) P.nFrames, frame );
-
-					if( slot != PT_NO_WORK ) {
-						beginPixel( P, st, slot, cnt, frame );
-					}
-					else {
-						more = false;
-					}
-				}
-
-				storeCold( P, which, st );
-
-				if( useB ) {
-					B.nodes = 0; B.tris = 0; B.ray = st.ray;
-					if( more ) { startWalkDual<LIGHTS>( P, B ); } else { B.mode = MODE_DONE; B.cur = -1; }
-				}
-				else {
-					A.nodes = 0; A.tris = 0; A.ray = st.ray;
-					if( more ) { startWalkDual<LIGHTS>( P, A ); } else { A.mode = MODE_DONE; A.cur = -1; }
-				}
-			}
-		}
-	}
-
-	flushCounters( P, cnt );
-}
+#include "pt_r04_dual_kernel.hpp"   // pathTracingDual: two paths per lane (lab)
 #endif
 
 // ---------------------------------------------------------------------------------------
@@ -3171,103 +2572,15 @@ __global__ __launch_bounds__( PBR_BLOCK, 8 ) void diagTraceStream( const DevPara
 	atomicAdd( &P.counters[1], (unsigned long long) tris );
 }
 
+#if defined( PBR_LAB ) && defined( PT_NODE_PHASE_ASM )
+#include "pt_r04_probe.hpp"   // diagTraceStreamDual (lab)
+#endif
+
 // Counter calibration: read a table of `count` float4 in a KNOWN pattern so that
 // FETCH_SIZE / TCC_EA0_RDREQ_* can be interpreted for this path's access shapes.
 //   MODE 0  coalesced stream: lane l reads element base + l (16 B per lane, 1 KiB per wave)
 //   MODE 1  one random 16-B element per lane and step
 //   MODE 2  one random 32-B record (two adjacent float4, like a BVH node) per lane and step
-#if defined( PBR_LAB ) && defined( PT_NODE_PHASE_ASM )
-// Traversal-only probe, one or two walks per lane, at MINW waves / SIMD (round 4, lab).  ONE walk: traverse() as the
-// lock-step kernels run it.  TWO: every lane draws two rays and walks both with nodePhaseDual; a lane's parked walks take
-// their leaf tests one after the other.  Same rays, same (t, face) per ray, same visit and face-test counts.
-template<int MINW, bool DUAL>
-__global__ __launch_bounds__( PBR_BLOCK, MINW ) void diagTraceStreamDual( const DevParams P, const float4* rays, unsigned n, float2* out ) {
-	const float4* lds = gHotNodes;
-	stageHotNodes( P, gHotNodes );
-	unsigned nodes = 0, tris = 0;
-
-	if( !DUAL ) {
-		unsigned i = atomicAdd( P.workCounter, 1u );
-
-		while( i < n ) {
-			const float4 a = rays[(size_t) i * 2 + 0];
-			const float4 b = rays[(size_t) i * 2 + 1];
-			Ray ray;
-			ray.origin = mk3( a.x, a.y, a.z );
-			ray.dir = mk3( b.x, b.y, b.z );
-			Hit hit;
-			hit.t = inff();
-			hit.face = 0;
-			traverse<false, false, true, false, ( MINW <= 4 )>( P, lds, ray, hit, nodes, tris );
-			out[i] = make_float2( hit.t, __int_as_float( hit.face ) );
-			i = atomicAdd( P.workCounter, 1u );
-		}
-	}
-	else {
-		unsigned i = atomicAdd( P.workCounter, 2u );
-
-		while( i < n ) {
-			const bool haveB = ( i + 1u < n );
-			const unsigned j = haveB ? i + 1u : i;
-			const float4 a0 = rays[(size_t) i * 2 + 0], a1 = rays[(size_t) i * 2 + 1];
-			const float4 b0 = rays[(size_t) j * 2 + 0], b1 = rays[(size_t) j * 2 + 1];
-			Ray rayA, rayB;
-			rayA.origin = mk3( a0.x, a0.y, a0.z );
-			rayA.dir = mk3( a1.x, a1.y, a1.z );
-			rayB.origin = mk3( b0.x, b0.y, b0.z );
-			rayB.dir = mk3( b1.x, b1.y, b1.z );
-			Hit hitA, hitB;
-			hitA.t = hitB.t = inff();
-			hitA.face = hitB.face = 0;
-			const f3 invA = mk3( 1.0f / rayA.dir.x, 1.0f / rayA.dir.y, 1.0f / rayA.dir.z );
-			const f3 invB = mk3( 1.0f / rayB.dir.x, 1.0f / rayB.dir.y, 1.0f / rayB.dir.z );
-			const f2v oxyA = { rayA.origin.x, rayA.origin.y }, ozzA = { rayA.origin.z, rayA.origin.z }, ixyA = { invA.x, invA.y }, izzA = { invA.z, invA.z };
-			const f2v oxyB = { rayB.origin.x, rayB.origin.y }, ozzB = { rayB.origin.z, rayB.origin.z }, ixyB = { invB.x, invB.y }, izzB = { invB.z, invB.z };
-			int refA = P.firstRef, refB = haveB ? P.firstRef : -1;
-			unsigned visits = 0, visitsB = 0;
-
-			for( ;; ) {
-				int leafWordA = 0, leafWordB = 0;
-				float tNearA = 0.0f, tNearB = 0.0f;
-
-				if( refA >= 0 || refB >= 0 ) {
-					const int entered = __popcll( __ballot( refA >= 0 ) ) + __popcll( __ballot( refB >= 0 ) );
-					const int leave = ( entered * P.parkEighths ) >> 3;
-					const int keep = entered - ( ( leave < 1 ) ? 1 : leave );
-					__builtin_amdgcn_s_setprio( PT_WALK_PRIO );
-					nodePhaseDual( P, oxyA, ozzA, ixyA, izzA, hitA.t, oxyB, ozzB, ixyB, izzB, hitB.t, keep, refA, refB, visits, visitsB,
-					               leafWordA, tNearA, leafWordB, tNearB );
-					__builtin_amdgcn_s_setprio( 0 );
-				}
-
-				if( leafWordA != 0 ) {
-					testLeaf<false, ( MINW <= 4 )>( P, leafFace0( leafWordA ), leafFace1( leafWordA ), rayA, tNearA, 0.0f, hitA, tris );
-				}
-				if( leafWordB != 0 ) {
-					testLeaf<false, ( MINW <= 4 )>( P, leafFace0( leafWordB ), leafFace1( leafWordB ), rayB, tNearB, 0.0f, hitB, tris );
-				}
-
-				if( __ballot( refA >= 0 || refB >= 0 ) == 0ull ) {
-					break;
-				}
-			}
-
-			nodes += visits + visitsB;
-			out[i] = make_float2( hitA.t, __int_as_float( hitA.face ) );
-
-			if( haveB ) {
-				out[j] = make_float2( hitB.t, __int_as_float( hitB.face ) );
-			}
-
-			i = atomicAdd( P.workCounter, 2u );
-		}
-	}
-
-	atomicAdd( &P.counters[0], (unsigned long long) nodes );
-	atomicAdd( &P.counters[1], (unsigned long long) tris );
-}
-#endif
-
 template<int MODE>
 __global__ __launch_bounds__( 256 ) void diagCalibrate( const float4* table, unsigned long long count, unsigned steps, float* sink ) {
 	const unsigned long long tid = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
