@@ -58,8 +58,6 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
  *   "face_normals"  0 = recompute the face normal on every hit (takes effect at the next pbr_upload_scene)
  *   "bvh_builder"   pbr_build_bvh: 0 clustering (default), 1 round 1's radix tree; "ploc_radius": its search radius
  *   "tune_log"      1 = the schedule tuner logs its launches to stderr
- *   "async_eighths" lab builds with the asynchronous node phase only: eighths of the walking lanes that must be ready before an
- *                   iteration starts (no effect on the product's plans)
  * Setting a knob rebuilds the plans and restarts the schedule tuner. */
 int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value );
 

@@ -23,7 +23,9 @@
 using ptk::DevParams;
 
 typedef void ( *KernelFn )( const ptk::DevParams );
-typedef void ( *KernelFn2 )( const ptk::DevParams, const float4*, unsigned, float2* );
+#ifdef PBR_LAB
+typedef void ( *KernelFn2 )( const ptk::DevParams, const float4*, unsigned, float2* );   // lab probe kernels
+#endif
 
 // A plan = kernel + persistent grid + LDS split (launch()).  Built once per scene + configuration and kept in the
 // context: six occupancy queries and six function-attribute calls are host time a frame-by-frame caller would pay
@@ -31,8 +33,10 @@ typedef void ( *KernelFn2 )( const ptk::DevParams, const float4*, unsigned, floa
 struct Plan {
 	KernelFn kernel = nullptr;
 	int blocks = 0, blockThreads = 0, numHot = 0, park = 0, shade = 0, parkEighths = 4;
-	bool async = false;     // the node phase polls per-lane LDS slots filled by LDS-DMA (pt_kernel.hpp, nodePhaseAsync)
+#ifdef PBR_LAB             // round-4 lab variants (lab/src/pt_r04_*.hpp)
+	bool async = false;     // the node phase polls per-lane LDS slots filled by LDS-DMA (nodePhaseAsync)
 	bool pair = false;      // the node phase fetches the adjacent record along: reads the flagged copy of the stream (nodePhasePair)
+#endif
 	size_t ldsBytes = 0;
 	const char* name = "";
 };
@@ -51,7 +55,9 @@ struct Knobs {
 	int bvhBuilder = -1;    // pbr_build_bvh: 1 = round 1's radix tree instead of the clustering builder
 	int plocRadius = -1;    // pbr_build_bvh: search radius of the clustering builder
 	int tuneLog = -1;       // 1 = the schedule tuner logs its launches to stderr
-	int asyncEighths = -1;  // asynchronous node phase: eighths of the walking lanes that must be ready before an iteration starts
+#ifdef PBR_LAB
+	int asyncEighths = -1;  // lab, asynchronous node phase: eighths of the walking lanes that must be ready before an iteration starts
+#endif
 };
 
 struct pbr_ctx {
@@ -66,7 +72,9 @@ struct pbr_ctx {
 	// scene
 	bool hasScene = false;
 	float4* dNodes = nullptr;
+#ifdef PBR_LAB
 	float4* dNodesPair = nullptr;  // lab: the stream with `hit successor is the adjacent record` flags (nodePhasePair)
+#endif
 	float4* dTris = nullptr;
 	float4* dTriPN = nullptr;      // exact vertices + vertex normals per face (Phong tessellation); null if the normal indices are unusable
 	float4* dMats = nullptr;
@@ -147,8 +155,10 @@ int fail( pbr_ctx* ctx, int code, const char* fmt, ... ) {
 
 void freeScene( pbr_ctx* ctx ) {
 	(void) hipFree( ctx->dNodes );
+#ifdef PBR_LAB
 	(void) hipFree( ctx->dNodesPair );
 	ctx->dNodesPair = nullptr;
+#endif
 	(void) hipFree( ctx->dTris );
 	(void) hipFree( ctx->dTriPN );
 	ctx->dTriPN = nullptr;
@@ -250,6 +260,7 @@ KernelFn pickKernelPhasedMode( uint32_t brdf, bool shadow, bool lights ) {
 #endif
 }
 
+// Which node phase the two state-machine plans use: nodePhaseAsm (WALK_SYNC) in the product, always.
 // lab builds: -DPBR_ASYNC_LEAN / -DPBR_ASYNC_MID put the asynchronous node phase in the place of phased-lean / phased-mid
 // (-DPBR_PAIR_LEAN: the adjacent-record fetch in the place of phased-lean)
 #if defined( PBR_ASYNC_LEAN )
@@ -502,13 +513,15 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		// a block's share of the CU's 160 KB, for the staged tree top
 		const size_t ldsPerCU = 160 * 1024;
 		const size_t share = ldsPerCU / (size_t) blocksPerCU - 256;
-		// asynchronous node phase: 32 B of the share per lane are the lanes' record slots (two planes of 1024 x 16 B)
+		// (lab variants keep per-lane state behind the staged prefix: the asynchronous node phase 32 B per lane of record slots,
+		// two paths per lane 2 slots x 4 planes x 16 B of path state)
+		size_t slotBytes = 0;
 #if defined( PBR_LAB ) && defined( PBR_DUAL_LEAN )
-		// two paths per lane: 2 slots x 4 planes x 16 B x 1024 lanes of path state behind the staged tree top
-		const size_t slotBytes = ( plan == &ctx->plans[2] ) ? (size_t) 2 * 4 * 16 * PBR_BLOCK : ( async ? (size_t) 2 * PT_SLOT_PLANE : 0 );
-#else
-		const size_t slotBytes = async ? (size_t) 2 * PT_SLOT_PLANE : 0;
+		slotBytes = ( plan == &ctx->plans[2] ) ? (size_t) 2 * 4 * 16 * PBR_BLOCK : 0;
+#elif defined( PBR_LAB )
+		slotBytes = async ? (size_t) 2 * PT_SLOT_PLANE : 0;
 #endif
+		(void) async;
 		size_t slots = ( share - slotBytes ) / 32;
 		slots = std::min<size_t>( slots, ctx->numHotAvail );
 
@@ -525,7 +538,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		plan->blocks = ctx->numCUs * blocksPerCU;   // all that are resident at once; run() launches fewer when there is less work
 		plan->numHot = (int) slots;
 		plan->ldsBytes = slots * 32 + slotBytes;
+#ifdef PBR_LAB
 		plan->async = async;
+#endif
 		plan->park = park;
 		plan->shade = shade;
 		plan->parkEighths = ( ctx->numNodes >= kWideMinNodes ) ? 4 : 6;   // see traverse(), pt_kernel.hpp
@@ -552,6 +567,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		const unsigned blocks = (unsigned) std::min<size_t>( (size_t) plan.blocks, needed );
 		P.numHot = plan.numHot;
 		P.numHotBytes = plan.numHot * 32;
+#ifdef PBR_LAB
 		P.slotBase = plan.numHot * 32;
 		P.nodes = ( plan.pair && ctx->dNodesPair != nullptr ) ? ctx->dNodesPair : ctx->dNodes;
 		// measured (profiles/r04/experiments/async_node_phase.txt): the share of the walking lanes an iteration waits for
@@ -560,6 +576,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		if( plan.async && ( plan.numHot < 1 || ctx->firstRef >= plan.numHot * 32 ) ) {
 			return fail( ctx, PBR_ESTATE, "asynchronous node phase: the walk's first record must be staged in LDS" );
 		}
+#endif
 
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
@@ -604,7 +621,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		int status = makePlan( pickKernel( brdf, shadow, lights, true, false ), "refill-lean", 0, 0, &plans[0] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernel( brdf, shadow, lights, true, true ), "refill-wide", 0, 0, &plans[1] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2], PBR_BLOCK, kAsyncLean );
+#ifdef PBR_LAB
 		plans[2].pair = ( kWalkLean == ptk::WALK_PAIR );
+#endif
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 48, &plans[3] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhasedMid( brdf, shadow, lights ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads, kAsyncMid );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelMid( brdf, shadow, lights ), "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
@@ -1184,10 +1203,14 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 			w1 = refOf( (long long) i + 1 );
 		}
 
-		// every NaN of a box is stored as THE quiet NaN 0x7FC00000: the slab test only ever compares (a NaN's payload
-		// changes nothing), and the asynchronous node phase marks an empty record slot with the NaN 0xFFFFFFFF in a
-		// box word (pt_kernel.hpp, nodePhaseAsync) — a record must never look like an empty slot
+#ifdef PBR_LAB
+		// lab (nodePhaseAsync): every NaN of a box is stored as THE quiet NaN 0x7FC00000 — the slab test only ever compares (a
+		// NaN's payload changes nothing), and an empty record slot is marked with the NaN 0xFFFFFFFF in a box word: a record
+		// must never look like an empty slot
 		auto boxWord = []( float x ) { return ( x != x ) ? __builtin_bit_cast( float, 0x7FC00000u ) : x; };
+#else
+		auto boxWord = []( float x ) { return x; };
+#endif
 		const size_t r = (size_t) recordOf[i];
 		nodes[r * 2 + 0] = make_float4( boxWord( n.bbMin.x ), boxWord( n.bbMin.y ), boxWord( n.bbMax.x ), boxWord( n.bbMax.y ) );
 		nodes[r * 2 + 1] = make_float4( boxWord( n.bbMin.z ), boxWord( n.bbMax.z ), __builtin_bit_cast( float, w0 ), __builtin_bit_cast( float, w1 ) );
@@ -1280,6 +1303,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dLights, sizeof( float4 ) * lights.size() ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dNodes, nodes.data(), sizeof( float4 ) * nodes.size(), hipMemcpyHostToDevice ) );
 
+#ifdef PBR_LAB
 	if( kWalkLean == ptk::WALK_PAIR ) {
 		// lab (nodePhasePair): bit 0 of a container's w0 = "my hit successor is the adjacent record", only behind the ranked
 		// prefix (every plan fetches those records from memory)
@@ -1299,6 +1323,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 		HIP_TRY( ctx, hipMemcpy( ctx->dNodesPair, flagged.data(), sizeof( float4 ) * flagged.size(), hipMemcpyHostToDevice ) );
 		std::fprintf( stderr, "[pbr pair] %zu of %zu records carry the adjacent-successor flag\n", flags, numRecords );
 	}
+#endif
 	HIP_TRY( ctx, hipMemcpy( ctx->dTris, tris.data(), sizeof( float4 ) * tris.size(), hipMemcpyHostToDevice ) );
 
 	if( !triPN.empty() ) {
@@ -2275,7 +2300,10 @@ int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value ) {
 		{ "lds_slots", &k.ldsSlots }, { "blocks_per_cu", &k.blocksPerCU }, { "ph_park", &k.phPark }, { "ph_shade", &k.phShade },
 		{ "park_eighths", &k.parkEighths }, { "drain_mode", &k.drainMode }, { "refill_batch", &k.refillBatch },
 		{ "chunk_frames", &k.chunkFrames }, { "face_normals", &k.faceNormals }, { "bvh_builder", &k.bvhBuilder },
-		{ "ploc_radius", &k.plocRadius }, { "tune_log", &k.tuneLog }, { "async_eighths", &k.asyncEighths },
+		{ "ploc_radius", &k.plocRadius }, { "tune_log", &k.tuneLog },
+#ifdef PBR_LAB
+		{ "async_eighths", &k.asyncEighths },
+#endif
 	};
 
 	for( const auto& entry : table ) {

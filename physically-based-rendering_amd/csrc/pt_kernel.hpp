@@ -84,8 +84,10 @@ using namespace ptm;
 #ifndef PT_WALK_PRIO
 #define PT_WALK_PRIO 1
 #endif
-// asynchronous node phase (nodePhaseAsync): bytes between the two halves of a lane's record slot in LDS: 1024 lanes x 16 B
+#ifdef PBR_LAB
+// lab, asynchronous node phase (nodePhaseAsync): bytes between the two halves of a lane's record slot in LDS: 1024 lanes x 16 B
 #define PT_SLOT_PLANE 16384
+#endif
 #ifndef PT_EAGER_REFILL_UP_TO
 #define PT_EAGER_REFILL_UP_TO 8
 #endif
@@ -135,8 +137,10 @@ struct DevParams {
 	int numHot;             // records [0, numHot) of the node stream are resident in LDS
 	int numHotBytes;        // = numHot * 32: a record reference (byte offset) below this is resident
 	int firstRef;           // reference (byte offset) of node 1's record, where every walk starts
-	int slotBase;           // asynchronous node phase: LDS byte address of the lanes' record slots (= numHotBytes), nodePhaseAsync
-	int asyncEighths;       // ... and the share of the walking lanes (in eighths) that must be ready before an iteration starts
+#ifdef PBR_LAB             // round-4 lab variants (lab/src/pt_r04_*.hpp)
+	int slotBase;           // LDS byte address of the per-lane state behind the staged prefix (= numHotBytes): nodePhaseAsync, pathTracingDual
+	int asyncEighths;       // nodePhaseAsync: the share of the walking lanes (in eighths) that must be ready before an iteration starts
+#endif
 	int nFrames, firstCount;
 	int useExplicitWeight;
 	float explicitWeight;
@@ -2114,11 +2118,12 @@ enum { WALK_SYNC = 0, WALK_ASYNC = 1, WALK_PAIR = 2 };
 template<int BRDF, bool SHADOW, bool LIGHTS, int MINW, int WALK = WALK_SYNC>
 __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const DevParams P ) {
 	constexpr bool ASYNC = ( WALK == WALK_ASYNC );
+	(void) ASYNC;
 	const float4* lds = gHotNodes;
 	PT_LAB_WAVE_BEGIN
 	stageHotNodes( P, gHotNodes );
-#ifdef PT_NODE_PHASE_ASM
-	// asynchronous node phase: every lane's slot starts out empty (marker in the last word of its second half);
+#if defined( PT_NODE_PHASE_ASM ) && defined( PBR_LAB )
+	// lab, asynchronous node phase: every lane's slot starts out empty (marker in the last word of its second half);
 	// the slots of a wave are 1 KiB per half, lane-linear (nodePhaseAsync)
 	const int slotM0 = __builtin_amdgcn_readfirstlane( P.slotBase + (int) ( threadIdx.x >> 6 ) * 1024 );
 	int asyncErr = 0;
@@ -2321,7 +2326,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 	}
 
 	flushCounters( P, cnt );
-#ifdef PT_NODE_PHASE_ASM
+#if defined( PT_NODE_PHASE_ASM ) && defined( PBR_LAB )
 	if( ASYNC ) {
 		// every request has been consumed by the lane that made it; a block's LDS must not be handed on with a DMA in flight
 		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
