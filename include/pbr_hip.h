@@ -87,8 +87,8 @@ typedef struct {
 	uint32_t samples;             /* SAMPLES (paths per pixel per frame) */
 	float anti_aliasing;          /* ANTI_ALIASING */
 	float phong_tessellation;     /* PHONGTESS_ALPHA; > 0 = PHONGTESS on (pt_phongtess.cl; needs facesN / normals in the scene), 0 = flat triangles.
-	                               * Phong tessellation pins its own schedule: the lock-step kernel in the 64-register budget is the only one built
-	                               * with the patch intersection (the cubic solve spills in every budget, and a state machine that parks lanes on
+	                               * Phong tessellation pins its own schedule: the lock-step kernel in the 128-register budget is the only one built
+	                               * with the patch intersection (the cubic solve spills in every budget, least in this one, and a state machine that parks lanes on
 	                               * leaves would have to carry the patch normal through the park) — the tuner and pbr_diag_pin_plan do not apply. */
 	float sky_light[4];           /* SKY_LIGHT */
 	/* Tile sharding (not in the reference, which is single-device): this context renders the

@@ -42,7 +42,7 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int lds_slots, const float* rays8, uint
 int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t reads, double* ms_out );
 
 /* Which schedule rendered (the largest chunk of) the last render: "refill-lean", "refill-wide", "phased-lean",
- * "phased-wide", "phased-mid", "refill-mid" ("refill-wide-phong" with Phong tessellation); *tuned = index of the schedule the auto-tuner
+ * "phased-wide", "phased-mid", "refill-mid" ("refill-lean-phong" with Phong tessellation); *tuned = index of the schedule the auto-tuner
  * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
 int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
 

@@ -319,9 +319,15 @@ KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights ) {
 	return pickKernelMode<kMidMinWaves>( brdf, shadow, lights );
 }
 
-// PHONGTESS == 1: the refill schedule in the wide budget only (the long cubic solve spills either way)
+// PHONGTESS == 1: the lock-step kernel in the LEAN budget (round 4).  The long cubic solve spills in every budget — 336 B /
+// 272 B / 72 B of scratch per lane at 64 / 80 / 128 registers — and 4 waves with 8 spilled registers beat 8 waves with 208:
+// 4133 against 2731 Msamples/s on a 288-face sphere over a floor at 1080p, 2850 against 2015 on a 9 000-face one
+// (profiles/r04/experiments/phong_register_budget.txt; rounds 2-3 built it in the 64-register budget).
+#ifndef PBR_PHONG_MINW      // lab: other register budgets for the Phong-tessellation build
+#define PBR_PHONG_MINW PBR_LEAN_MINW
+#endif
 KernelFn pickKernelPhong( uint32_t brdf, bool shadow, bool lights ) {
-	return pickKernelMode<PBR_WIDE_MINW, true>( brdf, shadow, lights );
+	return pickKernelMode<PBR_PHONG_MINW, true>( brdf, shadow, lights );
 }
 
 KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights, bool refill, bool wide ) {
@@ -658,9 +664,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	}
 
 	if( phong ) {
-		// one plan: the Phong-tessellation build of the refill kernel takes the place of refill-wide
+		// one plan: the Phong-tessellation build of the lock-step kernel (lean budget), in the slot of plan 1
 		if( !ctx->phongPlanBuilt ) {
-			const int made = makePlan( pickKernelPhong( ctx->cfg.brdf, shadow, lights ), "refill-wide-phong", 0, 0, &ctx->phongPlan );
+			const int made = makePlan( pickKernelPhong( ctx->cfg.brdf, shadow, lights ), "refill-lean-phong", 0, 0, &ctx->phongPlan );
 
 			if( made != PBR_OK ) {
 				return made;

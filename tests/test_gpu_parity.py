@@ -649,7 +649,7 @@ def test_phong_tessellation_bit_exact(pbr, oracle, device, tmp_path, brdf):
     assert same_values(got, want), describe_mismatch(got, want)
     assert same_values(device.read_debug(), ref.debug)
     assert device.counters() == ref.counter_dict()
-    assert device.last_plan()[0] == "refill-wide-phong"
+    assert device.last_plan()[0] == "refill-lean-phong"
     # the tessellation changes the picture: the same scene with PHONGTESS off renders differently
     flat = sc.config(w, h)
     flat.phong_tessellation = 0.0
@@ -658,7 +658,7 @@ def test_phong_tessellation_bit_exact(pbr, oracle, device, tmp_path, brdf):
     # Phong tessellation pins its own plan (include/pbr_hip.h): a pinned state-machine plan does not apply to it
     device.pin_plan(PLANS["phased-mid"])
     device.render(4, pbr.frame_seeds(4, 1), pbr.pixel_dimension(w, h), sc.camera())
-    assert device.last_plan()[0] == "refill-wide-phong"
+    assert device.last_plan()[0] == "refill-lean-phong"
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PBR_SOAK_SEEDS", "256"))))
