@@ -66,6 +66,20 @@ PT_DEV void startWalkDual( const DevParams& P, DualSlot& s ) {
 	s.mode = MODE_NODE;
 }
 
+// PBR_DUAL_SWAP: ONE walk per lane at a time (the product's nodePhaseAsm), the lane's other path as its reserve — a lane
+// whose path A waits (for shading, or has none) and whose path B can walk exchanges the two before the node phase, so a lane
+// sits a node phase out only when neither of its paths can walk.
+PT_DEV void swapWord( float& a, float& b ) { asm volatile( "v_swap_b32 %0, %1" : "+v"( a ), "+v"( b ) ); }
+PT_DEV void swapWord( int& a, int& b ) { asm volatile( "v_swap_b32 %0, %1" : "+v"( a ), "+v"( b ) ); }
+PT_DEV void swapWord( unsigned& a, unsigned& b ) { asm volatile( "v_swap_b32 %0, %1" : "+v"( a ), "+v"( b ) ); }
+PT_DEV void swapSlots( DualSlot& a, DualSlot& b ) {
+	swapWord( a.ray.origin.x, b.ray.origin.x ); swapWord( a.ray.origin.y, b.ray.origin.y ); swapWord( a.ray.origin.z, b.ray.origin.z );
+	swapWord( a.ray.dir.x, b.ray.dir.x ); swapWord( a.ray.dir.y, b.ray.dir.y ); swapWord( a.ray.dir.z, b.ray.dir.z );
+	swapWord( a.invDir.x, b.invDir.x ); swapWord( a.invDir.y, b.invDir.y ); swapWord( a.invDir.z, b.invDir.z );
+	swapWord( a.cur, b.cur ); swapWord( a.t, b.t ); swapWord( a.face, b.face ); swapWord( a.leafWord, b.leafWord );
+	swapWord( a.leafTNear, b.leafTNear ); swapWord( a.mode, b.mode ); swapWord( a.nodes, b.nodes ); swapWord( a.tris, b.tris );
+}
+
 template<int BRDF, bool SHADOW, bool LIGHTS>
 __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual( const DevParams P ) {
 	const float4* lds = gHotNodes;
@@ -82,6 +96,7 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual( const DevPara
 	A.leafTNear = B.leafTNear = 0.0f;
 	A.ray.origin = A.ray.dir = A.invDir = B.ray.origin = B.ray.dir = B.invDir = mk3( 0.0f, 0.0f, 0.0f );
 	WorkCursor work = beginWork();
+	int flip = 0;       // PBR_DUAL_SWAP: path A's cold state is in LDS slot `flip`, path B's in the other
 
 	// both slots take their first unit
 	for( int k = 0; k < 2; k++ ) {
@@ -99,6 +114,27 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual( const DevPara
 	}
 
 	while( __ballot( A.mode != MODE_DONE || B.mode != MODE_DONE ) != 0ull ) {
+#ifdef PBR_DUAL_SWAP
+		// ---- node phase: the lane's walkable path, A before B ------------------------------------------
+		if( A.mode != MODE_NODE && B.mode == MODE_NODE ) {
+			swapSlots( A, B );
+			flip ^= 1;
+		}
+
+		if( A.mode == MODE_NODE ) {
+			const int keep = __popcll( __ballot( 1 ) ) - P.phPark;
+			const f2v oxyA = { A.ray.origin.x, A.ray.origin.y }, ozzA = { A.ray.origin.z, A.ray.origin.z }, ixyA = { A.invDir.x, A.invDir.y }, izzA = { A.invDir.z, A.invDir.z };
+			int leafWordA = 0, parkedFlag;
+			float unusedTFar;
+			unsigned visits = 0;
+			__builtin_amdgcn_s_setprio( PT_WALK_PRIO );
+			nodePhaseAsm<false>( P, oxyA, ozzA, ixyA, izzA, A.t, ( keep < 0 ) ? 0 : keep, A.cur, visits, leafWordA, A.leafTNear, unusedTFar, parkedFlag );
+			__builtin_amdgcn_s_setprio( 0 );
+			A.nodes += visits;
+			A.leafWord = ( parkedFlag != 0 ) ? leafWordA : 0;
+			A.mode = ( parkedFlag != 0 ) ? MODE_LEAF : ( ( A.cur < 0 ) ? MODE_SHADE : MODE_NODE );
+		}
+#else
 		// ---- node phase: both slots of every lane ----------------------------------------------------
 		if( A.mode == MODE_NODE || B.mode == MODE_NODE ) {
 			const int walking = __popcll( __ballot( A.mode == MODE_NODE ) ) + __popcll( __ballot( B.mode == MODE_NODE ) );
@@ -110,8 +146,13 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual( const DevPara
 			int leafWordA = 0, leafWordB = 0;
 			float tNearA = 0.0f, tNearB = 0.0f;
 			__builtin_amdgcn_s_setprio( PT_WALK_PRIO );
+#ifdef PBR_DUAL_PIPE
+			nodePhaseDualPipe( P, oxyA, ozzA, ixyA, izzA, A.t, oxyB, ozzB, ixyB, izzB, B.t, ( keep < 0 ) ? 0 : keep, refA, refB, A.nodes, B.nodes,
+			                   leafWordA, tNearA, leafWordB, tNearB );
+#else
 			nodePhaseDual( P, oxyA, ozzA, ixyA, izzA, A.t, oxyB, ozzB, ixyB, izzB, B.t, ( keep < 0 ) ? 0 : keep, refA, refB, A.nodes, B.nodes,
 			               leafWordA, tNearA, leafWordB, tNearB );
+#endif
 			__builtin_amdgcn_s_setprio( 0 );
 
 			if( A.mode == MODE_NODE ) {
@@ -127,6 +168,8 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual( const DevPara
 				B.mode = ( leafWordB != 0 ) ? MODE_LEAF : ( ( refB < 0 ) ? MODE_SHADE : MODE_NODE );
 			}
 		}
+
+#endif
 
 		// ---- leaf phase, pooled: the slot that stands on a leaf (A first) ---------------------------------
 		// (PBR_DUAL_LEAF2 = n: a second pass at once when n or more lanes still have a slot on a leaf — both were parked)
@@ -174,7 +217,7 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual( const DevPara
 
 			if( ( shadeA || shadeB ) && ( nShade >= P.phShade || !busy ) ) {
 				const bool useB = !shadeA;
-				const int which = useB ? 1 : 0;
+				const int which = useB ? ( flip ^ 1 ) : flip;
 				PixelState st;
 				loadCold( P, which, st );
 				st.ray.origin = useB ? B.ray.origin : A.ray.origin;
