@@ -28,9 +28,26 @@ struct DualSlot {
 	unsigned nodes, tris;   // of the current walk(s) since the slot was last shaded: added to the path's counters there
 };
 
+#ifdef PBR_DUAL_COLD_GLOBAL
+// The paths' cold state in memory instead of LDS (lane-linear 16-byte planes per block: the same layout, coalesced) — 64 B read
+// + 64 B written per lane and shading; what 5 waves per SIMD (five 256-thread blocks per CU, 32 KB of LDS each) would need.
+#ifdef PBR_LAB_LEAN_BLOCK
+#define PBR_DUAL_BLOCK PBR_LAB_LEAN_BLOCK
+#else
+#define PBR_DUAL_BLOCK PBR_BLOCK
+#endif
+#define PBR_DUAL_COLD_BYTES ( 1536 * 2 * 4 * 256 * 16 )
+__device__ float4 gColdState[PBR_DUAL_COLD_BYTES / 16];
+
+PT_DEV float4* coldPlane( const DevParams& P, int slot, int plane ) {
+	(void) P;
+	return gColdState + ( ( (int) blockIdx.x * 2 + slot ) * 4 + plane ) * PBR_DUAL_BLOCK + (int) threadIdx.x;
+}
+#else
 PT_DEV float4* coldPlane( const DevParams& P, int slot, int plane ) {
 	return (float4*) ( (char*) gHotNodes + P.slotBase ) + ( slot * 4 + plane ) * PBR_BLOCK + (int) threadIdx.x;
 }
+#endif
 
 PT_DEV void loadCold( const DevParams& P, int slot, PixelState& st ) {
 	const float4 a = *coldPlane( P, slot, 0 ), b = *coldPlane( P, slot, 1 ), c = *coldPlane( P, slot, 2 ), d = *coldPlane( P, slot, 3 );
@@ -81,7 +98,17 @@ PT_DEV void swapSlots( DualSlot& a, DualSlot& b ) {
 }
 
 template<int BRDF, bool SHADOW, bool LIGHTS>
-__global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual( const DevParams P ) {
+#ifdef PBR_DUAL_WAVES5
+__global__ __launch_bounds__( PBR_LAB_LEAN_BLOCK ) __attribute__(( amdgpu_waves_per_eu( 5, 5 ) )) void pathTracingDual(
+#else
+__global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual(
+#endif
+ const DevParams P ) {
+#ifdef PBR_DUAL_COLD_GLOBAL
+	if( ( (size_t) blockIdx.x + 1 ) * 2 * 4 * PBR_DUAL_BLOCK * 16 > (size_t) PBR_DUAL_COLD_BYTES || blockDim.x != PBR_DUAL_BLOCK ) {
+		__builtin_trap();
+	}
+#endif
 	const float4* lds = gHotNodes;
 	stageHotNodes( P, gHotNodes );
 	LaneCounters cnt;
