@@ -56,6 +56,19 @@ def test_no_device_means_failure_not_fallback(pbr):
         pbr.Device(0)
 
 
+def test_device_code_is_built_for_gfx950_without_xnack(pbr):
+    """The hand-scheduled node phase lets a record load overwrite its own address register (csrc/pt_kernel.hpp,
+    PT_NODE_PHASE_HEAD), which is only legal where a faulted load is never replayed: the code objects must say
+    gfx950:xnack-, so that the loader refuses them in an XNACK-enabled process instead of running them there."""
+    from importlib import import_module
+    build = import_module(pbr.__name__ + ".build")
+    libs = [build.HIP_LIB] + ([build.HIP_GUARD_LIB] if os.path.exists(build.HIP_GUARD_LIB) else [])
+    for lib in libs:
+        blob = open(lib, "rb").read()
+        targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+(?::[a-z+\-]+)*)", blob))
+        assert targets == {b"gfx950:xnack-"}, (lib, targets)
+
+
 def test_product_does_not_touch_the_oracle():
     """The oracle is test infrastructure: nothing in the package or the headers may name it."""
     pkg = os.path.join(ROOT, "physically-based-rendering_amd")
