@@ -108,6 +108,126 @@ PT_DEV void nodePhasePair(
 	);
 }
 
+// ---- the node phase with PAIRED cold fetches (round 4, lab; -DPBR_HALVES with -DPBR_PAIR_LEAN) ----------------------
+// scripts/micro/pair_coalesce.hip: the L1 / TA charges a divergent global_load_dwordx4 partly per distinct 64-byte segment.
+// Here the two lanes of a pair (2k, 2k + 1) fetch the two 16-byte halves of ONE record with one instruction — first the
+// even lane's record (if it is cold), then the odd lane's: every load instruction touches one segment per pair instead of
+// one per lane.  Afterwards a lane takes the half its partner fetched for it (DPP quad_perm [1,0,3,2]) and its own from
+// the pair registers; lanes on staged records and lanes that do not walk only lend their load slots (their own registers
+// v46 - v63 are not written: the selects keep them).  Per lane the sequence of visits is the reference's; +20 vector and
+// +13 scalar instructions per iteration.  Registers: as nodePhaseAsm + v[64:71] (the two paired loads), v72 / v73.
+template<int DUMMY = 0>
+PT_DEV void nodePhaseHalves(
+	const DevParams& P, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep,
+	int& ref, unsigned& visits, int& leafWord, float& leafTNear, int& parked
+) {
+	const float eps = EPSILON5;
+	keep = __builtin_amdgcn_readfirstlane( keep );
+	unsigned long long saved, active, parkMask, mA;
+	int count;
+	const int laneHalf = ( (int) threadIdx.x & 1 ) * 16;     // which half of a record this lane fetches
+
+	asm volatile(
+		"s_mov_b64 %[saved], exec\n"
+		"s_mov_b64 %[parkMask], 0\n"
+		"v_mov_b32 v53, %[ref]\n"
+		"v_mov_b32 v72, %[laneHalf]\n"
+		"s_mov_b32 s80, 0x55555555\n"
+		"s_mov_b32 s81, 0x55555555\n"
+	"1:\n"
+		"v_cmp_gt_i32 vcc, %[numHotBytes], v53\n"
+		"s_and_saveexec_b64 %[active], vcc\n"
+		"ds_read_b128 v[46:49], v53\n"
+		"ds_read_b128 v[50:53], v53 offset:16\n"
+		"s_xor_b64 exec, exec, %[active]\n"                  // the lanes on cold records
+		"s_cbranch_execz 2f\n"
+		"s_and_b64 s[82:83], exec, s[80:81]\n"               // cold even lanes
+		"s_andn2_b64 s[84:85], exec, s[80:81]\n"             // cold odd lanes
+		"s_lshl_b64 s[86:87], s[82:83], 1\n"
+		"s_or_b64 s[86:87], s[86:87], s[82:83]\n"            // both lanes of the pairs whose even lane is cold
+		"s_lshr_b64 s[88:89], s[84:85], 1\n"
+		"s_or_b64 s[88:89], s[88:89], s[84:85]\n"            // both lanes of the pairs whose odd lane is cold
+		"s_mov_b64 exec, s[86:87]\n"
+		"s_nop 4\n"
+		"v_mov_b32_dpp v73, v53 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n"
+		"v_add_u32 v73, v73, v72\n"
+		"global_load_dwordx4 v[64:67], v73, %[nodes]\n"      // even lane: its record's first half; odd lane: the second
+		"s_mov_b64 exec, s[88:89]\n"
+		"s_nop 4\n"
+		"v_mov_b32_dpp v73, v53 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n"
+		"v_add_u32 v73, v73, v72\n"
+		"global_load_dwordx4 v[68:71], v73, %[nodes]\n"      // the odd lane's record, the same way
+		"s_or_b64 exec, s[86:87], s[88:89]\n"
+		"s_not_b64 vcc, s[82:83]\n"                          // vcc = 1: keep
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+		// a cold even lane: n0 = its own first load, n1 = what its partner fetched with it
+		"v_cndmask_b32 v46, v64, v46, vcc\n"
+		"v_cndmask_b32 v47, v65, v47, vcc\n"
+		"v_cndmask_b32 v48, v66, v48, vcc\n"
+		"v_cndmask_b32 v49, v67, v49, vcc\n"
+		"v_cndmask_b32_dpp v50, v64, v50, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		"v_cndmask_b32_dpp v51, v65, v51, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		"v_cndmask_b32_dpp v52, v66, v52, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		"v_cndmask_b32_dpp v53, v67, v53, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"   // the record's last word = the cursor's next value
+		"s_not_b64 vcc, s[84:85]\n"
+		// a cold odd lane: n0 = what its partner fetched with it, n1 = its own second load
+		"v_cndmask_b32_dpp v46, v68, v46, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		"v_cndmask_b32_dpp v47, v69, v47, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		"v_cndmask_b32_dpp v48, v70, v48, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		"v_cndmask_b32_dpp v49, v71, v49, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		"v_cndmask_b32 v50, v68, v50, vcc\n"
+		"v_cndmask_b32 v51, v69, v51, vcc\n"
+		"v_cndmask_b32 v52, v70, v52, vcc\n"
+		"v_cndmask_b32 v53, v71, v53, vcc\n"
+	"2:\n"
+		"s_mov_b64 exec, %[active]\n"
+		"v_add_u32 %[visits], 1, %[visits]\n"
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+		"v_pk_add_f32 v[54:55], v[46:47], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_add_f32 v[56:57], v[48:49], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_add_f32 v[58:59], v[50:51], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n"
+		"v_pk_mul_f32 v[54:55], %[ixy], v[54:55]\n"
+		"v_pk_mul_f32 v[56:57], %[ixy], v[56:57]\n"
+		"v_pk_mul_f32 v[58:59], %[izz], v[58:59]\n"
+		"v_min_f32 v60, v54, v56\n"
+		"v_min_f32 v61, v55, v57\n"
+		"v_min_f32 v62, v58, v59\n"
+		"v_max3_f32 v60, v60, v61, v62\n"
+		"v_max_f32 v61, v54, v56\n"
+		"v_max_f32 v63, v58, v59\n"
+		"v_max_f32 v62, v55, v57\n"
+		"v_min3_f32 v61, v61, v62, v63\n"
+		"v_cmpx_lt_f32 %[eps], v61\n"
+		"v_cmpx_gt_f32 %[rayT], v60\n"
+		"v_cmpx_le_f32 v60, v61\n"
+		"v_cmp_gt_i32 vcc, 0, v52\n"
+		"v_cndmask_b32 v53, v52, v53, vcc\n"
+		"s_or_b64 %[parkMask], %[parkMask], vcc\n"
+		"s_mov_b64 exec, %[active]\n"
+		"v_cmp_le_i32 %[mA], 0, v53\n"
+		"s_andn2_b64 exec, %[mA], vcc\n"
+		"s_bcnt1_i32_b64 %[count], exec\n"
+		"s_cmp_gt_i32 %[count], %[keep]\n"
+		"s_cbranch_scc1 1b\n"
+		"s_mov_b64 exec, %[saved]\n"
+		"v_mov_b32 %[ref], v53\n"
+		"v_cndmask_b32 %[parked], 0, 1, %[parkMask]\n"
+		"v_mov_b32 %[leafWord], v52\n"
+		"v_mov_b32 %[leafTNear], v60\n"
+		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [parked] "=v"( parked ),
+		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [count] "=&s"( count )
+		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ),
+		  [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps ), [laneHalf] "v"( laneHalf )
+		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
+		  "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "vcc", "scc"
+	);
+}
+
+#ifdef PBR_HALVES
+#define nodePhasePair nodePhaseHalves     // the kernel in phased-lean's place (-DPBR_PAIR_LEAN) calls this one
+#endif
+
 // ---- the node phase with TWO walks per lane (round 4, lab: traversal-only probe) ----------------------------
 // VERDICT r03 item 2 asks what "two rays per lane" buys: memory-level parallelism without more waves.  This is the
 // doubled node phase by itself: every lane carries walk A and walk B (cursors in v53 / v71, records in v[46:53] /
