@@ -7,7 +7,7 @@ One "step" = one frame = one pass of the hot path over every pixel (SAMPLES = 1 
 the reference's default).  The K timed steps run as ONE pbr_render call = one path-tracing launch
 over all (pixel, frame) units + one foldFrames launch that applies the running mean in frame order
 (several such pairs only if K frames x 16 B x pixels exceed 16 GiB), after W untimed warm-up
-frames — during which the library also times its six schedules on this scene and keeps the
+frames — during which the library also times its seven schedules on this scene and keeps the
 fastest (2 frames each, then the best two or three again on 32 frames each: W >= 112, the default, settles it
 before the timed region; with a smaller W the difference is rendered as untimed set-up before the warm-up).  Scene arrays and the
 accumulated image are resident in HBM before the timed region starts.  Default workload = the configuration
@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
     ap.add_argument("--repeats", type=int, default=0, help="repetitions of the K-step render (0 = until 250 ms have been timed, at most 15); the median is reported")
     ap.add_argument("--plan", type=int, default=-1,
-                    help="pin schedule 0..5 (refill-lean, refill-wide, phased-lean, phased-wide, phased-mid, refill-mid) instead of tuning; profiling runs")
+                    help="pin schedule 0..6 (refill-lean, refill-wide, phased-lean, phased-wide, phased-mid, refill-mid, phased-dual) instead of tuning; profiling runs")
     ap.add_argument("--dump", default="", help="rank 0 writes the gathered / rendered frame to this .npy")
     ap.add_argument("--rank-limit", type=float, default=1500.0, help="self-launched ranks (--gpus N without a launcher): wall-clock seconds after which the parent ends them and fails")
     ap.add_argument("--hold-seconds", type=float, default=3.0, help="N = 1: keep the GPU rendering (untimed) this long after the timed region, so that an outside utilisation sampler sees the GPU leg at all")
@@ -414,7 +414,7 @@ def main():
         dev.pin_plan(args.plan)
     setup_frames, t_setup = 0, time.perf_counter()
     if not forced:
-        budget = dev.tune_budget()                             # 108 frames at 1080p on one GPU, N x as many on a rank of N (1/N of the pixels each)
+        budget = dev.tune_budget()                             # 110 frames at 1080p on one GPU, N x as many on a rank of N (1/N of the pixels each)
         while setup_frames < budget or dev.last_plan()[1] < 0:
             n = max(1, min(args.steps, 4 * budget - setup_frames))
             dev.render(setup_frames, pbr.frame_seeds(setup_frames, n), px, cam)

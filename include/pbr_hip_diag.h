@@ -42,7 +42,7 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int lds_slots, const float* rays8, uint
 int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t reads, double* ms_out );
 
 /* Which schedule rendered (the largest chunk of) the last render: "refill-lean", "refill-wide", "phased-lean",
- * "phased-wide", "phased-mid", "refill-mid" ("refill-lean-phong" with Phong tessellation); *tuned = index of the schedule the auto-tuner
+ * "phased-wide", "phased-mid", "refill-mid", "phased-dual" ("refill-lean-phong" with Phong tessellation); *tuned = index of the schedule the auto-tuner
  * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
 int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
 
@@ -50,7 +50,7 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
  * lab scripts and tests that need a knob set it here (the Python harness maps PBR_* variables onto this call).
  *   "lds_slots"     cap of the node records a block stages in LDS (0 = none)
  *   "blocks_per_cu" run below the resident maximum
- *   "ph_park" / "ph_shade"  lane state machine thresholds; "park_eighths": the lock-step walk's park share
+ *   "ph_park" / "ph_shade"  lane state machine thresholds (phased-dual: ph_park counts walks of up to 128 per wave); "park_eighths": the lock-step walk's park share
  *   "drain_mode"    bit 0 / 1: scale ph_park / ph_shade with the lanes still at work once the queue is empty
  *   "refill_batch"  lock-step kernels: lanes of a wave that wait with a finished unit before they take their next units
  *                   together (1 = every lane at once, as up to round 2)
@@ -61,8 +61,8 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
  * Setting a knob rebuilds the plans and restarts the schedule tuner. */
 int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value );
 
-/* Render with plan 0..5 (the order of pbr_diag_last_plan's *tuned: refill-lean, refill-wide, phased-lean, phased-wide,
- * phased-mid, refill-mid) from now on, without tuning; -1 hands the choice back to the tuner.  For the ranks of a
+/* Render with plan 0..6 (the order of pbr_diag_last_plan's *tuned: refill-lean, refill-wide, phased-lean, phased-wide,
+ * phased-mid, refill-mid, phased-dual) from now on, without tuning; -1 hands the choice back to the tuner.  For the ranks of a
  * multi-GPU run: rank 0 tunes, broadcasts its *tuned, every rank pins it — all ranks then run the same schedule and
  * none is a straggler of the closing all-gather because its own timing noise picked a slower plan.  Survives
  * pbr_upload_scene / pbr_configure. */

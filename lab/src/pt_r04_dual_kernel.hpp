@@ -16,6 +16,7 @@
 // per slot behind the staged tree top (2 x 64 B x 1024 lanes = 128 KiB), and is in registers only while its slot is shaded.
 // Per path the sequence of visits, face tests and random draws is the reference's: same image, same debug image, same counters.
 #if defined( PBR_LAB ) && defined( PT_NODE_PHASE_ASM )
+namespace r04lab {      // the product's pathTracingDual (csrc/pt_dual.hpp) is the pipelined form of this one; the variants stay here
 struct DualSlot {
 	Ray ray;
 	f3 invDir;
@@ -39,33 +40,33 @@ struct DualSlot {
 #define PBR_DUAL_COLD_BYTES ( 1536 * 2 * 4 * 256 * 16 )
 __device__ float4 gColdState[PBR_DUAL_COLD_BYTES / 16];
 
-PT_DEV float4* coldPlane( const DevParams& P, int slot, int plane ) {
+PT_DEV float4* labColdPlane( const DevParams& P, int slot, int plane ) {
 	(void) P;
 	return gColdState + ( ( (int) blockIdx.x * 2 + slot ) * 4 + plane ) * PBR_DUAL_BLOCK + (int) threadIdx.x;
 }
 #else
-PT_DEV float4* coldPlane( const DevParams& P, int slot, int plane ) {
+PT_DEV float4* labColdPlane( const DevParams& P, int slot, int plane ) {
 	return (float4*) ( (char*) gHotNodes + P.slotBase ) + ( slot * 4 + plane ) * PBR_BLOCK + (int) threadIdx.x;
 }
 #endif
 
-PT_DEV void loadCold( const DevParams& P, int slot, PixelState& st ) {
-	const float4 a = *coldPlane( P, slot, 0 ), b = *coldPlane( P, slot, 1 ), c = *coldPlane( P, slot, 2 ), d = *coldPlane( P, slot, 3 );
+PT_DEV void labLoadCold( const DevParams& P, int slot, PixelState& st ) {
+	const float4 a = *labColdPlane( P, slot, 0 ), b = *labColdPlane( P, slot, 1 ), c = *labColdPlane( P, slot, 2 ), d = *labColdPlane( P, slot, 3 );
 	st.slot = __float_as_uint( a.x ); st.frame = __float_as_int( a.y ); st.sample = __float_as_int( a.z ); st.finalColor.x = a.w;
 	st.finalColor.y = b.x; st.finalColor.z = b.y; st.secondaryPaths = __float_as_uint( b.z ); st.focus = b.w;
 	st.seed = c.x; st.dbgNodes = __float_as_uint( c.y ); st.dbgTris = __float_as_uint( c.z ); st.color.x = c.w;
 	st.color.y = d.x; st.color.z = d.y; st.depth = __float_as_int( d.z ); st.depthAdded = __float_as_int( d.w );
 }
 
-PT_DEV void storeCold( const DevParams& P, int slot, const PixelState& st ) {
-	*coldPlane( P, slot, 0 ) = make_float4( __uint_as_float( st.slot ), __int_as_float( st.frame ), __int_as_float( st.sample ), st.finalColor.x );
-	*coldPlane( P, slot, 1 ) = make_float4( st.finalColor.y, st.finalColor.z, __uint_as_float( st.secondaryPaths ), st.focus );
-	*coldPlane( P, slot, 2 ) = make_float4( st.seed, __uint_as_float( st.dbgNodes ), __uint_as_float( st.dbgTris ), st.color.x );
-	*coldPlane( P, slot, 3 ) = make_float4( st.color.y, st.color.z, __int_as_float( st.depth ), __int_as_float( st.depthAdded ) );
+PT_DEV void labStoreCold( const DevParams& P, int slot, const PixelState& st ) {
+	*labColdPlane( P, slot, 0 ) = make_float4( __uint_as_float( st.slot ), __int_as_float( st.frame ), __int_as_float( st.sample ), st.finalColor.x );
+	*labColdPlane( P, slot, 1 ) = make_float4( st.finalColor.y, st.finalColor.z, __uint_as_float( st.secondaryPaths ), st.focus );
+	*labColdPlane( P, slot, 2 ) = make_float4( st.seed, __uint_as_float( st.dbgNodes ), __uint_as_float( st.dbgTris ), st.color.x );
+	*labColdPlane( P, slot, 3 ) = make_float4( st.color.y, st.color.z, __int_as_float( st.depth ), __int_as_float( st.depthAdded ) );
 }
 
 template<bool LIGHTS>
-PT_DEV void startWalkDual( const DevParams& P, DualSlot& s ) {
+PT_DEV void labStartWalkDual( const DevParams& P, DualSlot& s ) {
 	s.invDir = mk3( 1.0f / s.ray.dir.x, 1.0f / s.ray.dir.y, 1.0f / s.ray.dir.z );
 	s.cur = P.firstRef;
 	Hit h;
@@ -89,7 +90,7 @@ PT_DEV void startWalkDual( const DevParams& P, DualSlot& s ) {
 PT_DEV void swapWord( float& a, float& b ) { asm volatile( "v_swap_b32 %0, %1" : "+v"( a ), "+v"( b ) ); }
 PT_DEV void swapWord( int& a, int& b ) { asm volatile( "v_swap_b32 %0, %1" : "+v"( a ), "+v"( b ) ); }
 PT_DEV void swapWord( unsigned& a, unsigned& b ) { asm volatile( "v_swap_b32 %0, %1" : "+v"( a ), "+v"( b ) ); }
-PT_DEV void swapSlots( DualSlot& a, DualSlot& b ) {
+PT_DEV void labSwapSlots( DualSlot& a, DualSlot& b ) {
 	swapWord( a.ray.origin.x, b.ray.origin.x ); swapWord( a.ray.origin.y, b.ray.origin.y ); swapWord( a.ray.origin.z, b.ray.origin.z );
 	swapWord( a.ray.dir.x, b.ray.dir.x ); swapWord( a.ray.dir.y, b.ray.dir.y ); swapWord( a.ray.dir.z, b.ray.dir.z );
 	swapWord( a.invDir.x, b.invDir.x ); swapWord( a.invDir.y, b.invDir.y ); swapWord( a.invDir.z, b.invDir.z );
@@ -135,8 +136,8 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual(
 			beginPixel( P, st, slot, cnt, frame );
 			DualSlot& S = ( k == 0 ) ? A : B;
 			S.ray = st.ray;
-			startWalkDual<LIGHTS>( P, S );
-			storeCold( P, k, st );
+			labStartWalkDual<LIGHTS>( P, S );
+			labStoreCold( P, k, st );
 		}
 	}
 
@@ -144,7 +145,7 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual(
 #ifdef PBR_DUAL_SWAP
 		// ---- node phase: the lane's walkable path, A before B ------------------------------------------
 		if( A.mode != MODE_NODE && B.mode == MODE_NODE ) {
-			swapSlots( A, B );
+			labSwapSlots( A, B );
 			flip ^= 1;
 		}
 
@@ -246,7 +247,7 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual(
 				const bool useB = !shadeA;
 				const int which = useB ? ( flip ^ 1 ) : flip;
 				PixelState st;
-				loadCold( P, which, st );
+				labLoadCold( P, which, st );
 				st.ray.origin = useB ? B.ray.origin : A.ray.origin;
 				st.ray.dir = useB ? B.ray.dir : A.ray.dir;
 				st.dbgNodes += useB ? B.nodes : A.nodes;
@@ -275,15 +276,15 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual(
 					}
 				}
 
-				storeCold( P, which, st );
+				labStoreCold( P, which, st );
 
 				if( useB ) {
 					B.nodes = 0; B.tris = 0; B.ray = st.ray;
-					if( more ) { startWalkDual<LIGHTS>( P, B ); } else { B.mode = MODE_DONE; B.cur = -1; }
+					if( more ) { labStartWalkDual<LIGHTS>( P, B ); } else { B.mode = MODE_DONE; B.cur = -1; }
 				}
 				else {
 					A.nodes = 0; A.tris = 0; A.ray = st.ray;
-					if( more ) { startWalkDual<LIGHTS>( P, A ); } else { A.mode = MODE_DONE; A.cur = -1; }
+					if( more ) { labStartWalkDual<LIGHTS>( P, A ); } else { A.mode = MODE_DONE; A.cur = -1; }
 				}
 			}
 		}
@@ -291,5 +292,5 @@ __global__ __launch_bounds__( PBR_BLOCK, 4 ) void pathTracingDual(
 
 	flushCounters( P, cnt );
 }
+}   // namespace r04lab
 #endif
-

@@ -347,131 +347,7 @@ PT_DEV void nodePhaseDual(
 	);
 }
 
-// nodePhaseDual, software-pipelined (lab, -DPBR_DUAL_PIPE): walk A's next fetch is issued as soon as A's slab test is done, then
-// B's records are waited for and tested while A's are in flight, and so on — each wait covers one walk's requests, and the other
-// walk's slab test runs behind it.  Waits are COUNTED (s_waitcnt vmcnt(2) lgkmcnt(2): the other walk's two loads of each kind
-// may stay in flight) only when that other fetch issued both kinds (an instruction with an empty EXEC may or may not count);
-// otherwise everything is waited for.  The cursors live in v72 / v73: a prefetched record overwrites v53 / v71.  When enough
-// lanes have left, nothing more is requested for B and walk A takes the visit its prefetch is for: the phase ends with nothing in flight.
-#define PT_DUAL_FETCH( walk, cur, n0, n1lo, n1hi, flag, skip ) \
-		"s_mov_b64 exec, " walk "\n" \
-		"s_mov_b32 " flag ", 0\n" \
-		"s_cbranch_execz " skip "f\n" \
-		"v_cmp_gt_i32 vcc, %[numHotBytes], " cur "\n" \
-		"s_and_saveexec_b64 s[94:95], vcc\n" \
-		"s_cselect_b32 s82, 1, 0\n" \
-		"ds_read_b128 v[" n0 "], " cur "\n" \
-		"ds_read_b128 v[" n1lo ":" n1hi "], " cur " offset:16\n" \
-		"s_xor_b64 exec, exec, s[94:95]\n" \
-		"s_cselect_b32 s83, 1, 0\n" \
-		"global_load_dwordx4 v[" n0 "], " cur ", %[nodes]\n" \
-		"global_load_dwordx4 v[" n1lo ":" n1hi "], " cur ", %[nodes] offset:16\n" \
-		"s_and_b32 " flag ", s82, s83\n" \
-	skip ":\n"
-#define PT_DUAL_WAIT( otherFlag, full, go ) \
-		"s_cmp_eq_u32 " otherFlag ", 1\n" \
-		"s_cbranch_scc0 " full "f\n" \
-		"s_waitcnt vmcnt(2) lgkmcnt(2)\n" \
-		"s_branch " go "f\n" \
-	full ":\n" \
-		"s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
-	go ":\n"
-
-template<int DUMMY = 0>
-PT_DEV void nodePhaseDualPipe(
-	const DevParams& P,
-	const f2v oxyA, const f2v ozzA, const f2v ixyA, const f2v izzA, float rayTA,
-	const f2v oxyB, const f2v ozzB, const f2v ixyB, const f2v izzB, float rayTB,
-	int keep, int& refA, int& refB, unsigned& visitsA, unsigned& visitsB,
-	int& leafWordA, float& tNearA, int& leafWordB, float& tNearB
-) {
-	const float eps = EPSILON5;
-	keep = __builtin_amdgcn_readfirstlane( keep );
-
-	asm volatile(
-		"s_waitcnt lgkmcnt(0)\n"
-		"s_mov_b64 s[84:85], exec\n"
-		"v_cmp_le_i32 s[86:87], 0, %[refA]\n"
-		"v_cmp_le_i32 s[88:89], 0, %[refB]\n"
-		"s_mov_b64 s[90:91], 0\n"
-		"s_mov_b64 s[92:93], 0\n"
-		"v_mov_b32 v72, %[refA]\n"
-		"v_mov_b32 v73, %[refB]\n"
-		"s_mov_b32 s79, 0\n"                                 // 1: the phase is ending — walk A takes the visit its prefetch is for, nothing new is requested
-		PT_DUAL_FETCH( "s[86:87]", "v72", "46:49", "50", "53", "s80", "10" )
-		PT_DUAL_FETCH( "s[88:89]", "v73", "64:67", "68", "71", "s81", "11" )
-	"1:\n"
-		// ---- walk A: its records (B's fetch, issued after them, may stay in flight)
-		PT_DUAL_WAIT( "s81", "12", "13" )
-		"s_mov_b64 exec, s[86:87]\n"
-		"s_cbranch_execz 4f\n"
-		"v_add_u32 %[visitsA], 1, %[visitsA]\n"
-		PT_DUAL_SLAB( "46", "47", "48", "49", "50", "51", "%[oxyA]", "%[ozzA]", "%[ixyA]", "%[izzA]" )
-		"v_cmpx_lt_f32 %[eps], v61\n"
-		"v_cmpx_gt_f32 %[rayTA], v60\n"
-		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_gt_i32 vcc, 0, v52\n"
-		"v_cndmask_b32 v53, v52, v53, vcc\n"
-		"s_or_b64 s[90:91], s[90:91], vcc\n"
-		"s_mov_b64 exec, vcc\n"
-		"v_mov_b32 %[leafWordA], v52\n"
-		"v_mov_b32 %[tNearA], v60\n"
-		"s_mov_b64 exec, s[86:87]\n"
-		"v_mov_b32 v72, v53\n"                                // the cursor, where the prefetch below cannot reach it
-		"v_cmp_le_i32 s[94:95], 0, v72\n"
-		"s_andn2_b64 s[86:87], s[94:95], s[90:91]\n"
-	"4:\n"
-		"s_cmp_eq_u32 s79, 1\n"
-		"s_cbranch_scc1 6f\n"
-		PT_DUAL_FETCH( "s[86:87]", "v72", "46:49", "50", "53", "s80", "14" )
-		// ---- walk B
-		PT_DUAL_WAIT( "s80", "15", "16" )
-		"s_mov_b64 exec, s[88:89]\n"
-		"s_cbranch_execz 5f\n"
-		"v_add_u32 %[visitsB], 1, %[visitsB]\n"
-		PT_DUAL_SLAB( "64", "65", "66", "67", "68", "69", "%[oxyB]", "%[ozzB]", "%[ixyB]", "%[izzB]" )
-		"v_cmpx_lt_f32 %[eps], v61\n"
-		"v_cmpx_gt_f32 %[rayTB], v60\n"
-		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_gt_i32 vcc, 0, v70\n"
-		"v_cndmask_b32 v71, v70, v71, vcc\n"
-		"s_or_b64 s[92:93], s[92:93], vcc\n"
-		"s_mov_b64 exec, vcc\n"
-		"v_mov_b32 %[leafWordB], v70\n"
-		"v_mov_b32 %[tNearB], v60\n"
-		"s_mov_b64 exec, s[88:89]\n"
-		"v_mov_b32 v73, v71\n"
-		"v_cmp_le_i32 s[94:95], 0, v73\n"
-		"s_andn2_b64 s[88:89], s[94:95], s[92:93]\n"
-	"5:\n"
-		"s_bcnt1_i32_b64 s96, s[86:87]\n"
-		"s_bcnt1_i32_b64 s97, s[88:89]\n"
-		"s_add_i32 s96, s96, s97\n"
-		"s_cmp_gt_i32 s96, %[keep]\n"
-		"s_cbranch_scc0 18f\n"
-		PT_DUAL_FETCH( "s[88:89]", "v73", "64:67", "68", "71", "s81", "17" )
-		"s_branch 1b\n"
-	"18:\n"                                                   // enough lanes have left: no request for B; A's prefetched records are
-		"s_mov_b32 s79, 1\n"                                 // not dropped — walk A takes that visit (a node phase may always run
-		"s_mov_b32 s81, 0\n"                                 // one visit longer), then the phase ends with nothing in flight
-		"s_branch 1b\n"
-	"6:\n"
-		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-		"s_mov_b64 exec, s[84:85]\n"
-		"v_mov_b32 %[refA], v72\n"
-		"v_mov_b32 %[refB], v73\n"
-		: [refA] "+v"( refA ), [refB] "+v"( refB ), [visitsA] "+v"( visitsA ), [visitsB] "+v"( visitsB ),
-		  [leafWordA] "+v"( leafWordA ), [tNearA] "+v"( tNearA ), [leafWordB] "+v"( leafWordB ), [tNearB] "+v"( tNearB )
-		: [oxyA] "v"( oxyA ), [ozzA] "v"( ozzA ), [ixyA] "v"( ixyA ), [izzA] "v"( izzA ), [rayTA] "v"( rayTA ),
-		  [oxyB] "v"( oxyB ), [ozzB] "v"( ozzB ), [ixyB] "v"( ixyB ), [izzB] "v"( izzB ), [rayTB] "v"( rayTB ),
-		  [keep] "s"( keep ), [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps )
-		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
-		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
-		  "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc"
-	);
-}
-#undef PT_DUAL_FETCH
-#undef PT_DUAL_WAIT
+// (nodePhaseDualPipe, the software-pipelined form of nodePhaseDual, became the product's: csrc/pt_dual.hpp.)
 #undef PT_DUAL_SLAB
 #endif
 

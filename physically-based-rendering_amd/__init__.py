@@ -493,7 +493,7 @@ class Device:
         self._check(hip.pbr_diag_last_plan(self._ctx, name, 48, ctypes.byref(tuned)))
         return name.value.decode(), int(tuned.value)
 
-    PLAN_NAMES = ("refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid")
+    PLAN_NAMES = ("refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid", "phased-dual")
 
     def pin_plan(self, plan):
         """Render with schedule `plan` (index into PLAN_NAMES) without tuning; -1 = let the tuner choose."""

@@ -101,7 +101,7 @@ struct pbr_ctx {
 	// schedule auto-tuning (launch()): per scene + configuration, the candidates are timed on the first
 	// frames that are rendered anyway, then the fastest one is kept
 	int tunedPlan = -1;
-	Plan plans[6];                                  // the tuner's candidates; valid while plansBuilt (reset by pbr_upload_scene / pbr_configure / pbr_diag_set_knob)
+	Plan plans[7];                                  // the tuner's candidates; valid while plansBuilt (reset by pbr_upload_scene / pbr_configure / pbr_diag_set_knob)
 	Plan phongPlan;                                 // the Phong-tessellation build of the refill kernel (takes the place of plans[1])
 
 	bool plansBuilt = false, phongPlanBuilt = false;
@@ -112,13 +112,13 @@ struct pbr_ctx {
 	int pinnedPlan = -1;                            // pbr_diag_pin_plan: >= 0 renders with this plan, no tuning (ranks of a multi-GPU run: all the same)
 	uint32_t tuneRenderFrames = 0;                  // the longest render (frames per call) this context has been asked for
 	uint32_t tunedAtFrames = 0;                     // the render length tunedPlan was chosen for
-	double tuneMs[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
-	uint32_t tuneFrames[6] = { 0, 0, 0, 0, 0, 0 };
-	uint32_t tuneLaunches[6] = { 0, 0, 0, 0, 0, 0 };
+	double tuneMs[7] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };      // screening: kTuneFrames frames per plan
+	uint32_t tuneFrames[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	uint32_t tuneLaunches[7] = { 0, 0, 0, 0, 0, 0, 0 };
 	int refineCount = 0;                            // refinement: the plans within 10 % of the fastest (at least two) again, on longer chunks
-	int refinePlan[6] = { -1, -1, -1, -1, -1, -1 };
+	int refinePlan[7] = { -1, -1, -1, -1, -1, -1, -1 };
 	uint32_t refineChunks = 0;                      // chunks rendered so far in the refinement
-	double refineFit[6][5] = {};                    // per finalist, over its refinement launches: sums of 1, n, n^2, ms, n * ms (n = frames of the launch)
+	double refineFit[7][5] = {};                    // per finalist, over its refinement launches: sums of 1, n, n^2, ms, n * ms (n = frames of the launch)
 	char lastPlan[48] = "";        // name of the plan that rendered the largest chunk of the last render
 	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
 	uint32_t lastTraceLaunches = 0; // ... and how many there were (frame-parallel renders are chunked)
@@ -281,7 +281,7 @@ KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) 
 #if defined( PBR_LAB ) && defined( PBR_DUAL_LEAN )
 	if( !wide ) {      // lab: two paths per lane in the place of phased-lean (pt_kernel.hpp, pathTracingDual)
 		(void) brdf; (void) shadow; (void) lights;
-		return ptk::pathTracingDual<1, false, false>;
+		return ptk::r04lab::pathTracingDual<1, false, false>;
 	}
 #endif
 	return wide ? pickKernelPhasedMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelPhasedMode<PBR_LEAN_MINW, kWalkLean>( brdf, shadow, lights );
@@ -303,6 +303,35 @@ KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
 }
 
 KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights );
+
+// two paths per lane (pt_dual.hpp).  Its node phase is hand-scheduled only: builds without PT_NODE_PHASE_ASM (PBR_GUARD,
+// PBR_NODE_PHASE_CXX) render the plan with the 6-waves state machine — same bits, every loop bounded.
+KernelFn pickKernelDual( uint32_t brdf, bool shadow, bool lights ) {
+#if defined( PT_NODE_PHASE_ASM ) && !defined( PBR_LAB )
+	if( brdf == 0 ) {
+		if( lights ) {
+			return shadow ? ptk::pathTracingDual<0, true, true> : ptk::pathTracingDual<0, false, true>;
+		}
+		return ptk::pathTracingDual<0, false, false>;
+	}
+
+	if( lights ) {
+		return shadow ? ptk::pathTracingDual<1, true, true> : ptk::pathTracingDual<1, false, true>;
+	}
+	return ptk::pathTracingDual<1, false, false>;
+#elif defined( PT_NODE_PHASE_ASM )
+	(void) brdf; (void) shadow; (void) lights;      // lab builds: only the kernel variants the bench scenes run
+	return ptk::pathTracingDual<1, false, false>;
+#else
+	return pickKernelPhasedMid( brdf, shadow, lights );
+#endif
+}
+const bool kDualIsDual =
+#ifdef PT_NODE_PHASE_ASM
+	true;
+#else
+	false;
+#endif
 
 // Scenes whose tree does not fit the staged LDS prefix ("large": the walk is most of a bounce) and those whose tree
 // does ("small": shading is): the lock-step walk's park share and refill batch differ between the two.
@@ -507,7 +536,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// split between the blocks the register budget admits.  The experiment knobs (PBR_BLOCKS_PER_CU, PBR_LDS_SLOTS,
 	// PBR_PH_PARK, PBR_PH_SHADE, PBR_PARK_EIGHTHS, PBR_DRAIN_MODE) are read when the plans are built — once per
 	// scene + configuration — not per launch.
-	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK, bool async = false ) -> int {
+	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK, bool async = false, size_t pathSlotBytes = 0 ) -> int {
 		int blocksPerCU = 0;
 		HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, blockThreads, 0 ) );
 		blocksPerCU = ( blocksPerCU < 1 ) ? 1 : blocksPerCU;
@@ -521,11 +550,11 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		const size_t share = ldsPerCU / (size_t) blocksPerCU - 256;
 		// (lab variants keep per-lane state behind the staged prefix: the asynchronous node phase 32 B per lane of record slots,
 		// two paths per lane 2 slots x 4 planes x 16 B of path state)
-		size_t slotBytes = 0;
+		size_t slotBytes = pathSlotBytes;     // two paths per lane: 2 slots x 4 planes x 16 B of path state per lane behind the staged prefix
 #if defined( PBR_LAB ) && defined( PBR_DUAL_LEAN )
-		slotBytes = ( plan == &ctx->plans[2] ) ? (size_t) 2 * 4 * 16 * PBR_BLOCK : 0;
+		slotBytes = ( plan == &ctx->plans[2] ) ? (size_t) 2 * 4 * 16 * PBR_BLOCK : slotBytes;
 #elif defined( PBR_LAB )
-		slotBytes = async ? (size_t) 2 * PT_SLOT_PLANE : 0;
+		slotBytes = async ? (size_t) 2 * PT_SLOT_PLANE : slotBytes;
 #endif
 		(void) async;
 		size_t slots = ( share - slotBytes ) / 32;
@@ -573,8 +602,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		const unsigned blocks = (unsigned) std::min<size_t>( (size_t) plan.blocks, needed );
 		P.numHot = plan.numHot;
 		P.numHotBytes = plan.numHot * 32;
-#ifdef PBR_LAB
 		P.slotBase = plan.numHot * 32;
+#ifdef PBR_LAB
 		P.nodes = ( plan.pair && ctx->dNodesPair != nullptr ) ? ctx->dNodesPair : ctx->dNodes;
 		// measured (profiles/r04/experiments/async_node_phase.txt): the share of the walking lanes an iteration waits for
 		P.asyncEighths = ( knobs.asyncEighths >= 1 ) ? std::min( 8, knobs.asyncEighths ) : 6;
@@ -613,7 +642,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// fixed cost from its per-frame cost, and every plan's short launches and its long launches are centred on the same
 	// moment, so the drift of the clocks — the GPU ramps up from idle during exactly these launches, which biased a
 	// one-sided order by 5 % in the per-frame cost — cancels in both.
-	const int kPlans = 6;
+	const int kPlans = 7;
 	// Lengths in 1080p-frame equivalents: a rank of an 8-GPU run (or a small image) has 1/8 of the pixels per frame, and
 	// launches of a few hundred microseconds say little about a long render (measured at 1/8 of the tiles: the tuner
 	// kept a plan 26 % slower than the best).  So the chunk lengths grow as the frame shrinks.
@@ -633,6 +662,11 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 48, &plans[3] );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhasedMid( brdf, shadow, lights ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads, kAsyncMid );
 		status = ( status != PBR_OK ) ? status : makePlan( pickKernelMid( brdf, shadow, lights ), "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
+		// 28 of a wave's up to 128 walks leave a node phase before it ends; a shade phase waits for 48 lanes (measured:
+		// profiles/r04/experiments/two_paths_per_lane.txt).  Without the hand-scheduled node phase: phased-mid's kernel and thresholds.
+		status = ( status != PBR_OK ) ? status : ( kDualIsDual
+			? makePlan( pickKernelDual( brdf, shadow, lights ), "phased-dual", 28, 48, &plans[6], PBR_BLOCK, false, (size_t) 2 * 4 * 16 * PBR_BLOCK )
+			: makePlan( pickKernelDual( brdf, shadow, lights ), "phased-dual", 16, 40, &plans[6], kMidBlockThreads, kAsyncMid ) );
 
 		if( status != PBR_OK ) {
 			return status;
@@ -855,7 +889,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			if( screened( kPlans - 1 ) ) {
 				// screening done: every plan within 10 % of the fastest — at least the two fastest — goes on to the refinement
 				auto perFrame = [&]( int k ) { return ctx->tuneMs[k] / ctx->tuneFrames[k]; };
-				int order[kPlans] = { 0, 1, 2, 3, 4, 5 };
+				int order[kPlans] = { 0, 1, 2, 3, 4, 5, 6 };
 				std::sort( order, order + kPlans, [&]( int x, int y ) { return perFrame( x ) < perFrame( y ); } );
 				ctx->refineCount = 0;
 
@@ -2277,8 +2311,8 @@ int pbr_diag_tune_budget( pbr_ctx* ctx, uint32_t* frames ) {
 		return fail( ctx, PBR_ESTATE, "tune budget before pbr_configure" );
 	}
 
-	// screening: 6 plans x 2; refinement: up to 3 finalists x 2 x ( 4 + 12 ); all in 1080p-frame equivalents
-	*frames = ( 6u * 2u + 3u * 2u * ( 4u + 12u ) ) * tuneScaleOf( (size_t) ctx->numLocalTiles * 64 );
+	// screening: 7 plans x 2; refinement: up to 3 finalists x 2 x ( 4 + 12 ); all in 1080p-frame equivalents
+	*frames = ( 7u * 2u + 3u * 2u * ( 4u + 12u ) ) * tuneScaleOf( (size_t) ctx->numLocalTiles * 64 );
 	return PBR_OK;
 }
 
@@ -2327,8 +2361,8 @@ int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value ) {
 }
 
 int pbr_diag_pin_plan( pbr_ctx* ctx, int plan ) {
-	if( ctx == nullptr || plan < -1 || plan > 5 ) {
-		return fail( ctx, PBR_EINVAL, "diag_pin_plan: plan must be -1 (auto-tune) or 0..5" );
+	if( ctx == nullptr || plan < -1 || plan > 6 ) {
+		return fail( ctx, PBR_EINVAL, "diag_pin_plan: plan must be -1 (auto-tune) or 0..6" );
 	}
 
 	ctx->pinnedPlan = plan;

@@ -14,8 +14,9 @@
 //     for the lanes parked on hit leaves (traverse, nodePhaseAsm);
 //   * triangles are pre-gathered per face as {a, b-a, c-a, material} = 48 B, removing the
 //     facesV -> vertices indirection of pt_intersect.cl:146-149;
-//   * two ways to keep lanes busy: pathTracing (lock step per bounce) and pathTracingPhased (a lane
-//     state machine); the host times both on the scene and keeps the faster (pbr_hip.hip, launch()).
+//   * three ways to keep lanes busy: pathTracing (lock step per bounce), pathTracingPhased (a lane
+//     state machine) and pathTracingDual (the state machine with two paths per lane, pt_dual.hpp);
+//     the host times them on the scene and keeps the fastest (pbr_hip.hip, launch()).
 // Per-pixel results are bit-identical to the per-frame reference schedule: a pixel's value
 // depends only on (seed_k, scene, its own previous value), pathtracing.cl:28,255,332.
 #pragma once
@@ -137,8 +138,8 @@ struct DevParams {
 	int numHot;             // records [0, numHot) of the node stream are resident in LDS
 	int numHotBytes;        // = numHot * 32: a record reference (byte offset) below this is resident
 	int firstRef;           // reference (byte offset) of node 1's record, where every walk starts
+	int slotBase;           // LDS byte address of the per-lane state behind the staged prefix (= numHotBytes): pathTracingDual's path slots
 #ifdef PBR_LAB             // round-4 lab variants (lab/src/pt_r04_*.hpp)
-	int slotBase;           // LDS byte address of the per-lane state behind the staged prefix (= numHotBytes): nodePhaseAsync, pathTracingDual
 	int asyncEighths;       // nodePhaseAsync: the share of the walking lanes (in eighths) that must be ready before an iteration starts
 #endif
 	int nFrames, firstCount;
@@ -984,9 +985,10 @@ PT_DEV void nodePhaseAsm(
 #undef PT_NODE_PHASE_OPERANDS
 }
 
-// Round 4 measured three more node phases — the adjacent record fetched along (nodePhasePair), two walks per lane
-// (nodePhaseDual) and polled LDS-DMA slots (nodePhaseAsync) — all bit-identical, none faster than this one: lab/src/pt_r04_node_phases.hpp,
-// profiles/r04/experiments/{pair_fetch,two_paths_per_lane,async_node_phase}.txt.  Lab builds (-DPBR_LAB) compile them in; the product does not.
+// Round 4 measured more node phases — the adjacent record fetched along (nodePhasePair), paired half-record fetches
+// (nodePhaseHalves), polled LDS-DMA slots (nodePhaseAsync) and two walks per lane (nodePhaseDual) — all bit-identical; for ONE walk
+// per lane none is faster than this one (lab/src/pt_r04_node_phases.hpp, profiles/r04/experiments/; lab builds, -DPBR_LAB, compile
+// them in, the product does not).  Two walks per lane with their node phases software-pipelined became plan 6: pt_dual.hpp.
 #ifdef PBR_LAB
 #include "pt_r04_node_phases.hpp"
 #endif
@@ -2341,8 +2343,10 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 }
 
 
+#include "pt_dual.hpp"               // pathTracingDual: the lane state machine with two paths per lane (plan 6, "phased-dual")
+
 #if defined( PBR_LAB ) && defined( PT_NODE_PHASE_ASM )
-#include "pt_r04_dual_kernel.hpp"   // pathTracingDual: two paths per lane (lab)
+#include "pt_r04_dual_kernel.hpp"   // r04lab::pathTracingDual: the variants of it that were measured and not kept (lab)
 #endif
 
 // ---------------------------------------------------------------------------------------

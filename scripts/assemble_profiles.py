@@ -25,7 +25,7 @@ def last_line_json(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
-PLAN_NAMES = ["refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid"]
+PLAN_NAMES = ["refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid", "phased-dual"]
 
 
 def library_stamp():

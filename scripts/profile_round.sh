@@ -13,7 +13,7 @@ for key in $loads; do
   [ $key = hairball_4k ] && { size="--width 3840 --height 2160"; steps=16; }
   timeout 600 python3 bench.py --scene $s $size --steps $steps > $out/bench_$key.json 2> $out/bench_$key.err
   # the profiled runs pin the schedule the tuner settled on in the plain run (--plan: no tuning launches under the profiler)
-  plan=$(python3 -c "import json,sys; n=json.loads(open('$out/bench_$key.json').read().strip().splitlines()[-1]).get('schedule','refill-lean'); print(['refill-lean','refill-wide','phased-lean','phased-wide','phased-mid','refill-mid'].index(n))")
+  plan=$(python3 -c "import json,sys; n=json.loads(open('$out/bench_$key.json').read().strip().splitlines()[-1]).get('schedule','refill-lean'); print(['refill-lean','refill-wide','phased-lean','phased-wide','phased-mid','refill-mid','phased-dual'].index(n))")
   cd /tmp
   # warm-up as long as the timed render: every launch of the path-tracing kernel in kernel_stats.csv is then the same
   # work, and their average is comparable with the timed launch the bench line reports

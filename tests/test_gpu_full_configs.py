@@ -30,7 +30,7 @@ FULL = {
     "sponza": ("sponza", 2, 260000, 1920, 1080, 3),
     "hairball": ("hairball", 3, 2000000, 3840, 2160, 3),
 }
-PLANS = ["refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid"]
+PLANS = ["refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid", "phased-dual"]
 
 _scenes = {}
 
@@ -71,7 +71,7 @@ def oracle_whole_frames(pbr, oracle, name):
 @pytest.mark.parametrize("name", sorted(FULL))
 def test_whole_frame_against_the_oracle_in_every_schedule(pbr, oracle, device, name):
     """The parity unit at full size is the whole frame: every pixel of the image and of the debug image and the launch's
-    counters equal the oracle's for the state machine (phased-mid); each of the five other plans then equals that frame
+    counters equal the oracle's for the state machine (phased-mid); each of the six other plans then equals that frame
     bit for bit — and so the oracle's, everywhere."""
     sc, cfg, cam, px, w, h = full_scene(pbr, name)
     assert sc.info["faces"] > 0.95 * FULL[name][2]

@@ -25,12 +25,12 @@ def device(pbr, gpu_device):
     dev.close()
 
 
-# the six plans launch() chooses from, as pbr_diag_pin_plan numbers them
-PLANS = {"refill-lean": 0, "refill-wide": 1, "phased-lean": 2, "phased-wide": 3, "phased-mid": 4, "refill-mid": 5}
+# the seven plans launch() chooses from, as pbr_diag_pin_plan numbers them
+PLANS = {"refill-lean": 0, "refill-wide": 1, "phased-lean": 2, "phased-wide": 3, "phased-mid": 4, "refill-mid": 5, "phased-dual": 6}
 
 
 def force_schedule(device, plan):
-    """Pin one of the six plans (by name) for this test's device; None leaves the choice to the tuner.  The library reads
+    """Pin one of the seven plans (by name) for this test's device; None leaves the choice to the tuner.  The library reads
     no environment variable: tests steer it through pbr_diag_pin_plan / pbr_diag_set_knob."""
     if plan is not None:
         device.pin_plan(PLANS[plan])
@@ -163,7 +163,7 @@ def test_brdf_and_new_ray_bit_exact(pbr, oracle, device, brdf, materials):
 # whole images
 # ----------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("schedule", ["refill-lean", "refill-mid", "phased-lean", "phased-mid", None])
+@pytest.mark.parametrize("schedule", ["refill-lean", "refill-mid", "phased-lean", "phased-mid", "phased-dual", None])
 @pytest.mark.parametrize("cfg", [
     {"render.max_depth": 4},
     {"render.max_depth": 4, "render.brdf": 0},
@@ -182,7 +182,7 @@ def test_cornell_image_bit_exact(pbr, oracle, device, schedule, cfg):
 
 
 @pytest.mark.parametrize("kind,triangles,w,h", [("sponza", 20000, 96, 56), ("dragon", 20000, 64, 64), ("hairball", 20000, 64, 64)])
-@pytest.mark.parametrize("schedule", ["refill-wide", "refill-lean", "refill-mid", "phased-wide", "phased-lean", "phased-mid"])
+@pytest.mark.parametrize("schedule", ["refill-wide", "refill-lean", "refill-mid", "phased-wide", "phased-lean", "phased-mid", "phased-dual"])
 def test_larger_scenes_bit_exact(pbr, oracle, device, kind, triangles, w, h, schedule):
     """Both schedules (pt_kernel.hpp: lock-step / lane state machine) and the three register budgets, with the tree top
     staged in LDS, against the oracle."""
@@ -194,15 +194,15 @@ def test_larger_scenes_bit_exact(pbr, oracle, device, kind, triangles, w, h, sch
     assert device.counters() == ref.counter_dict()
 
 
-@pytest.mark.parametrize("plan,name", [(0, "refill-lean"), (1, "refill-wide"), (2, "phased-lean"), (3, "phased-wide"), (4, "phased-mid"), (5, "refill-mid")])
+@pytest.mark.parametrize("plan,name", [(0, "refill-lean"), (1, "refill-wide"), (2, "phased-lean"), (3, "phased-wide"), (4, "phased-mid"), (5, "refill-mid"), (6, "phased-dual")])
 @pytest.mark.parametrize("kind,triangles,cfg", [
     ("cornell", 0, {"render.max_depth": 5, "render.max_added_depth": 2}),
     ("dragon", 12000, {"render.max_depth": 3, "render.brdf": 0}),
     ("hairball", 9000, {"render.max_depth": 3, "render.samples": 2}),
 ])
 def test_every_tuner_candidate_bit_exact(pbr, oracle, device, plan, name, kind, triangles, cfg):
-    """The six plans launch() chooses from (pbr_diag_pin_plan pins one): 4, 6 and 8 waves per SIMD of the lock-step kernel and of
-    the lane state machine, 768- and 1024-thread blocks — each against the oracle, images, debug image and counters."""
+    """The seven plans launch() chooses from (pbr_diag_pin_plan pins one): 4, 6 and 8 waves per SIMD of the lock-step kernel and of
+    the lane state machine, 768- and 1024-thread blocks, and the state machine with two paths per lane — each against the oracle, images, debug image and counters."""
     device.pin_plan(plan)
     sc = make_scene(pbr, kind, 7, triangles, **cfg)
     got, want, ref = both_render(pbr, oracle, device, sc, 88, 56, 6)
@@ -213,7 +213,7 @@ def test_every_tuner_candidate_bit_exact(pbr, oracle, device, plan, name, kind, 
 
 
 def test_schedule_tuner_through_a_viewer_then_a_batch(pbr, oracle, device):
-    """No schedule forced: launch() screens its six plans, times the finalists and keeps one (pbr_hip.hip) — on
+    """No schedule forced: launch() screens its seven plans, times the finalists and keeps one (pbr_hip.hip) — on
     frame-by-frame calls first, as the reference's viewer renders (PathTracer.cpp:60-68), which cannot separate a
     launch's fixed cost from its per-frame cost; the first long render then times the finalists again.  Whatever
     it picks, the accumulated image is the oracle's."""
@@ -302,9 +302,11 @@ def lit_scene(pbr, brdf):
     return sc, desc, lights
 
 
+@pytest.mark.parametrize("schedule", [None, "phased-dual"])
 @pytest.mark.parametrize("brdf", [1, 0])
 @pytest.mark.parametrize("shadow", [0, 1])
-def test_lights_and_shadow_rays_bit_exact(pbr, oracle, device, brdf, shadow):
+def test_lights_and_shadow_rays_bit_exact(pbr, oracle, device, brdf, shadow, schedule):
+    force_schedule(device, schedule)
     sc, desc, keep = lit_scene(pbr, brdf)
     cfg = sc.config(64, 64)
     cfg.shadow_rays = shadow
@@ -676,6 +678,8 @@ def test_random_configurations_bit_exact(pbr, oracle, device, seed):
         "render.antialiasing": float(rng.choice([0.0, 0.7, 1.5])),
     }
     schedule = [None, "refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid"][rng.integers(7)]
+    if seed % 5 == 4:       # (added in round 4 without moving the other draws of a seed: the soak logs stay comparable)
+        schedule = "phased-dual"
     force_schedule(device, schedule)
     if rng.integers(3) == 0:
         device.set_knob("lds_slots", int(rng.integers(0, 200)))
@@ -727,7 +731,7 @@ def test_guard_build_with_the_cxx_node_phase_gives_the_same_bits(pbr, device, tm
         "assert dev.guard_trips() == [0, 0, 0], dev.guard_trips()\n"
         "first = dev.read_output()\n"
         "np.save(%r, first)\n"
-        "for plan, mode in ((4, 3), (2, 0), (5, 1), (3, 2)):\n"           # the other schedules and how their launches end, every loop bounded
+        "for plan, mode in ((4, 3), (2, 0), (5, 1), (3, 2), (6, 1)):\n"           # the other schedules and how their launches end, every loop bounded
         "    dev.pin_plan(plan); dev.set_knob('drain_mode', mode); dev.reset_accum()\n"
         "    dev.render(0, pbr.frame_seeds(0, 3), pbr.pixel_dimension(%d, %d), sc.camera())\n"
         "    assert dev.guard_trips() == [0, 0, 0], (plan, dev.guard_trips())\n"
@@ -901,7 +905,7 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
 
 
 def pbr_plan_name(index):
-    return ("refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid")[index]
+    return ("refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid", "phased-dual")[index]
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
@@ -987,14 +991,14 @@ def test_bench_full_scale_shape_rehearsed_on_one_device(tmp_path):
 import make_reference_scenes  # noqa: E402
 
 
-@pytest.mark.parametrize("plan", [None, 0, 3, 4])
+@pytest.mark.parametrize("plan", [None, 0, 3, 4, 6])
 @pytest.mark.parametrize("name", sorted(make_reference_scenes.CASES))
 def test_hip_renders_the_reference_scenes(pbr, device, name, plan):
     """reference-authored geometry, material sets (glass d = 0 in pillars / spheres — K13 on whole
     images —, the nu = nv = 100000 lobes of suzanne.mtl, `light` flags) and suzanne.lights with shadow rays, BRDF 0 and
     1.  Inputs = the seven wire-format arrays + kernel constants + camera stored in tests/golden/ref_*.npz (made from
     the reference's files by make_reference_scenes.py; nothing is read from /root/reference here); expected = the
-    oracle's image, debug image, counters and a 4096-ray closest-hit batch.  Tuner (None) and three forced plans."""
+    oracle's image, debug image, counters and a 4096-ray closest-hit batch.  Tuner (None) and four forced plans."""
     if plan is not None:
         device.pin_plan(plan)
     data = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
@@ -1022,7 +1026,7 @@ def test_pinned_plan_is_the_plan_that_renders(pbr, oracle, device):
     w, h = 72, 48
     cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
     want = oracle.Renderer(sc.desc, cfg, threads=8).render(0, pbr.frame_seeds(0, 5), px, cam)
-    for plan in (2, 5):
+    for plan in (2, 5, 6):
         device.pin_plan(plan)
         device.upload_scene(sc.desc)
         device.configure(cfg)
