@@ -10,7 +10,7 @@ kind, seed, tris, depth = SCENES[name]
 pbr.cfg_reset(); pbr.cfg_set(**{"render.max_depth": depth})
 sc = pbr.HostScene.generate(kind, seed, tris)
 cam, px = sc.camera(), pbr.pixel_dimension(W, H)
-for plan in range(6):
+for plan in range(7):
     os.environ["PBR_PLAN"] = str(plan)
     cfg = sc.config(W, H); cfg.tile_world, cfg.tile_rank = world, 0
     dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(cfg)
