@@ -414,7 +414,7 @@ def main():
         dev.pin_plan(args.plan)
     setup_frames, t_setup = 0, time.perf_counter()
     if not forced:
-        budget = dev.tune_budget()                             # 110 frames at 1080p on one GPU, N x as many on a rank of N (1/N of the pixels each)
+        budget = dev.tune_budget()                             # 206 frames at 1080p on one GPU (the upper bound: a close call between two plans is timed twice), N x as many on a rank of N (1/N of the pixels each)
         while setup_frames < budget or dev.last_plan()[1] < 0:
             n = max(1, min(args.steps, 4 * budget - setup_frames))
             dev.render(setup_frames, pbr.frame_seeds(setup_frames, n), px, cam)

@@ -118,6 +118,7 @@ struct pbr_ctx {
 	int refineCount = 0;                            // refinement: the plans within 10 % of the fastest (at least two) again, on longer chunks
 	int refinePlan[7] = { -1, -1, -1, -1, -1, -1, -1 };
 	uint32_t refineChunks = 0;                      // chunks rendered so far in the refinement
+	uint32_t refineRounds = 1;                      // 1; 2 once a close call (best two within 5 %) has been given a second palindrome
 	double refineFit[7][5] = {};                    // per finalist, over its refinement launches: sums of 1, n, n^2, ms, n * ms (n = frames of the launch)
 	char lastPlan[48] = "";        // name of the plan that rendered the largest chunk of the last render
 	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
@@ -179,6 +180,7 @@ void resetTuning( pbr_ctx* ctx ) {
 	std::memset( ctx->tuneLaunches, 0, sizeof( ctx->tuneLaunches ) );
 	ctx->refineCount = 0;
 	ctx->refineChunks = 0;
+	ctx->refineRounds = 1;
 	std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
 }
 
@@ -641,7 +643,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// in the palindromic order A B C (short) C B A (long) A B C (long) C B A (short): two lengths separate a launch's
 	// fixed cost from its per-frame cost, and every plan's short launches and its long launches are centred on the same
 	// moment, so the drift of the clocks — the GPU ramps up from idle during exactly these launches, which biased a
-	// one-sided order by 5 % in the per-frame cost — cancels in both.
+	// one-sided order by 5 % in the per-frame cost — cancels in both.  When the two best end within 5 % of each other the palindrome
+	// is run a second time before the decision (the fits accumulate): a fit over four launches carries 1 - 5 % of noise.
 	const int kPlans = 7;
 	// Lengths in 1080p-frame equivalents: a rank of an 8-GPU run (or a small image) has 1/8 of the pixels per frame, and
 	// launches of a few hundred microseconds say little about a long render (measured at 1/8 of the tiles: the tuner
@@ -744,10 +747,11 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// both: least squares over each finalist's refinement launches, then the cost of a render of `frames` frames.
 	// Launches of one length only (a caller rendering frame by frame) cannot separate the two: a = 0, `separable` false.
 	bool separable = true;
+	double runnerUp = 0.0;       // cost of the second-best finalist relative to the best's, as decide() last saw them
 	auto decide = [&]( uint32_t renderFrames ) -> int {
 		const double frames = (double) std::max<uint32_t>( renderFrames, 1u );
 		int best = -1;
-		double bestCost = 0.0;
+		double bestCost = 0.0, secondCost = 0.0;
 		separable = true;
 
 		for( int k = 0; k < ctx->refineCount; k++ ) {
@@ -775,11 +779,16 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			}
 
 			if( best < 0 || cost < bestCost ) {
+				secondCost = ( best < 0 ) ? 0.0 : bestCost;
 				best = k;
 				bestCost = cost;
 			}
+			else if( secondCost == 0.0 || cost < secondCost ) {
+				secondCost = cost;
+			}
 		}
 
+		runnerUp = ( bestCost > 0.0 && secondCost > 0.0 ) ? secondCost / bestCost : 0.0;
 		return ctx->refinePlan[best];
 	};
 
@@ -796,6 +805,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		else if( nFrames >= 4u * kRefineLong ) {
 			ctx->tunedPlan = -1;
 			ctx->refineChunks = 0;
+			ctx->refineRounds = 1;
 			std::memset( ctx->refineFit, 0, sizeof( ctx->refineFit ) );
 		}
 	}
@@ -841,7 +851,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			n = std::min<uint32_t>( n, kTuneFrames - ctx->tuneFrames[choice] );
 		}
 		if( refining >= 0 ) {
-			const uint32_t pass = ctx->refineChunks / (uint32_t) ctx->refineCount;
+			const uint32_t pass = ( ctx->refineChunks / (uint32_t) ctx->refineCount ) % kRefinePasses;
 			const bool longPass = ( pass == 1u || pass == 2u );
 			n = std::min<uint32_t>( n, longPass ? kRefineLong : kRefineShort );
 		}
@@ -910,9 +920,19 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 			fit[4] += (double) n * (double) ms;
 			ctx->refineChunks++;
 
-			if( ctx->refineChunks >= kRefinePasses * (uint32_t) ctx->refineCount ) {
-				ctx->tunedPlan = decide( ctx->tuneRenderFrames );
-				ctx->tunedAtFrames = ctx->tuneRenderFrames;
+			if( ctx->refineChunks >= ctx->refineRounds * kRefinePasses * (uint32_t) ctx->refineCount ) {
+				const int best = decide( ctx->tuneRenderFrames );
+
+				// A close call — the runner-up within 5 % (phased-mid and phased-dual on a Sponza-class scene are 3 % apart, and a
+				// fit over four launches per plan carries 1 - 5 % of noise in its per-frame cost: measured, one wrong pick in a dozen
+				// runs) — gets a second palindrome of launches before the decision; the fits accumulate.
+				if( runnerUp > 0.0 && runnerUp < 1.05 && ctx->refineRounds < 2u ) {
+					ctx->refineRounds = 2u;
+				}
+				else {
+					ctx->tunedPlan = best;
+					ctx->tunedAtFrames = ctx->tuneRenderFrames;
+				}
 			}
 		}
 
@@ -2311,8 +2331,9 @@ int pbr_diag_tune_budget( pbr_ctx* ctx, uint32_t* frames ) {
 		return fail( ctx, PBR_ESTATE, "tune budget before pbr_configure" );
 	}
 
-	// screening: 7 plans x 2; refinement: up to 3 finalists x 2 x ( 4 + 12 ); all in 1080p-frame equivalents
-	*frames = ( 7u * 2u + 3u * 2u * ( 4u + 12u ) ) * tuneScaleOf( (size_t) ctx->numLocalTiles * 64 );
+	// screening: 7 plans x 2; refinement: up to 3 finalists x 2 x ( 4 + 12 ), twice when the best two are within 5 %; all in
+	// 1080p-frame equivalents
+	*frames = ( 7u * 2u + 2u * 3u * 2u * ( 4u + 12u ) ) * tuneScaleOf( (size_t) ctx->numLocalTiles * 64 );
 	return PBR_OK;
 }
 

@@ -4,9 +4,9 @@
 // the lane's OTHER path: every lane carries two path slots A and B (128 paths per wave at 4 waves per SIMD), and the node
 // phase of the two walks is software-pipelined — A's next records are requested, then B's records are waited for and tested
 // while A's are in flight, and the other way round.  Built in round 4 and measured against the six
-// other plans, all bit-identical: 1.01 - 1.02x of phased-mid on the Sponza-class scene (2072 - 2090 against 2040 - 2053 Msamples/s at
-// 1080p; through `bench.py --steps 20` 2046 - 2054 against 2012 - 2018), 0.97x on the Dragon-class scene, 0.89x on the
-// hairball — the tuner takes it where it wins (profiles/r04/experiments/two_paths_per_lane.txt).
+// other plans, all bit-identical: 1.02 - 1.03x of phased-mid on the Sponza-class scene (2099 - 2102 against 2048 - 2053 Msamples/s at
+// 1080p in 32-frame launches, same box), 0.97x on the Dragon-class scene, 0.89x on the hairball — the tuner takes it where it
+// wins (profiles/r04/experiments/two_paths_per_lane.txt).
 //
 //   node phase   nodePhaseDualPipe (below)
 //   leaf phase   POOLED: a lane tests the leaf of whichever of its slots stands on one (A first; the other in the next
@@ -28,7 +28,9 @@
 // each kind, which were issued later — only when that other fetch did issue both kinds (an instruction with an empty EXEC
 // may or may not count); otherwise everything is waited for.  When `keep` or fewer walks go on, nothing more is requested
 // for B and walk A takes the visit its prefetch is for (a node phase may always run one visit longer): the phase ends with
-// nothing in flight.  Per walk 22 vector instructions per visit as in nodePhaseAsm, ~15 scalar.
+// nothing in flight.  Per walk 25 vector instructions per visit (nodePhaseAsm: 22) and ~14 scalar ones; ONE taken branch per
+// iteration — the loop's own: the uncommon cases (a full wait, a walk without lanes) are out of line, and the first form, which
+// jumped over them in every iteration, was 1 % slower for its two taken branches.
 #define PT_DUAL_SLAB( n0a, n0b, n0c, n0d, n1a, n1b, oxy, ozz, ixy, izz ) \
 		"v_pk_add_f32 v[54:55], v[" n0a ":" n0b "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
 		"v_pk_add_f32 v[56:57], v[" n0c ":" n0d "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
@@ -46,27 +48,51 @@
 		"v_min3_f32 v61, v61, v62, v63\n"
 #define PT_DUAL_FETCH( walk, cur, n0, n1lo, n1hi, flag, skip ) \
 		"s_mov_b64 exec, " walk "\n" \
-		"s_mov_b32 " flag ", 0\n" \
-		"s_cbranch_execz " skip "f\n" \
+		"s_cbranch_execz " skip "9f\n" \
 		"v_cmp_gt_i32 vcc, %[numHotBytes], " cur "\n" \
 		"s_and_saveexec_b64 s[94:95], vcc\n" \
 		"s_cselect_b32 s82, 1, 0\n" \
 		"ds_read_b128 v[" n0 "], " cur "\n" \
 		"ds_read_b128 v[" n1lo ":" n1hi "], " cur " offset:16\n" \
 		"s_xor_b64 exec, exec, s[94:95]\n" \
-		"s_cselect_b32 s83, 1, 0\n" \
+		"s_cselect_b32 " flag ", s82, 0\n" \
 		"global_load_dwordx4 v[" n0 "], " cur ", %[nodes]\n" \
 		"global_load_dwordx4 v[" n1lo ":" n1hi "], " cur ", %[nodes] offset:16\n" \
-		"s_and_b32 " flag ", s82, s83\n" \
 	skip ":\n"
+// the counted wait; the uncommon case (the other fetch did not issue both kinds) waits for everything, out of line
 #define PT_DUAL_WAIT( otherFlag, full, go ) \
 		"s_cmp_eq_u32 " otherFlag ", 1\n" \
 		"s_cbranch_scc0 " full "f\n" \
 		"s_waitcnt vmcnt(2) lgkmcnt(2)\n" \
-		"s_branch " go "f\n" \
+	go ":\n"
+// a walk without lanes requests nothing: its flag says so (out of line)
+#define PT_DUAL_FETCH_NONE( flag, skip ) \
+	skip "9:\n" \
+		"s_mov_b32 " flag ", 0\n" \
+		"s_branch " skip "b\n"
+#define PT_DUAL_WAIT_FULL( full, go ) \
 	full ":\n" \
 		"s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
-	go ":\n"
+		"s_branch " go "b\n"
+// walk A's visit on the records in v[46:53] (used twice: in the loop and for the last visit of a phase)
+#define PT_DUAL_VISIT_A( skip ) \
+		"s_mov_b64 exec, s[86:87]\n" \
+		"s_cbranch_execz " skip "f\n" \
+		"v_add_u32 %[visitsA], 1, %[visitsA]\n" \
+		PT_DUAL_SLAB( "46", "47", "48", "49", "50", "51", "%[oxyA]", "%[ozzA]", "%[ixyA]", "%[izzA]" ) \
+		"v_cmpx_lt_f32 %[eps], v61\n" \
+		"v_cmpx_gt_f32 %[rayTA], v60\n" \
+		"v_cmpx_le_f32 v60, v61\n" \
+		"v_cmp_gt_i32 vcc, 0, v52\n" \
+		"v_cndmask_b32 v53, v52, v53, vcc\n" \
+		"s_or_b64 s[90:91], s[90:91], vcc\n" \
+		"v_cndmask_b32 %[leafWordA], %[leafWordA], v52, vcc\n"   /* EXEC = the lanes whose box is hit, vcc = those on a leaf */ \
+		"v_cndmask_b32 %[tNearA], %[tNearA], v60, vcc\n" \
+		"s_mov_b64 exec, s[86:87]\n" \
+		"v_mov_b32 v72, v53\n"                                /* the cursor, where the next prefetch cannot reach it */ \
+		"v_cmp_le_i32 s[94:95], 0, v72\n" \
+		"s_andn2_b64 s[86:87], s[94:95], s[90:91]\n" \
+	skip ":\n"
 
 // refA / refB: the walks' cursors (< 0: this slot sits the phase out).  A lane whose walk parks on a hit leaf gets the
 // leaf's word and tNear in leafWordA / tNearA (leafWordB / tNearB); the caller passes 0 in and reads != 0 as "parked".
@@ -89,32 +115,12 @@ PT_DEV void nodePhaseDualPipe(
 		"s_mov_b64 s[92:93], 0\n"
 		"v_mov_b32 v72, %[refA]\n"
 		"v_mov_b32 v73, %[refB]\n"
-		"s_mov_b32 s79, 0\n"                                 // 1: the phase is ending — walk A takes the visit its prefetch is for, nothing new is requested
 		PT_DUAL_FETCH( "s[86:87]", "v72", "46:49", "50", "53", "s80", "10" )
 		PT_DUAL_FETCH( "s[88:89]", "v73", "64:67", "68", "71", "s81", "11" )
 	"1:\n"
 		// ---- walk A: its records (B's fetch, issued after them, may stay in flight)
 		PT_DUAL_WAIT( "s81", "12", "13" )
-		"s_mov_b64 exec, s[86:87]\n"
-		"s_cbranch_execz 4f\n"
-		"v_add_u32 %[visitsA], 1, %[visitsA]\n"
-		PT_DUAL_SLAB( "46", "47", "48", "49", "50", "51", "%[oxyA]", "%[ozzA]", "%[ixyA]", "%[izzA]" )
-		"v_cmpx_lt_f32 %[eps], v61\n"
-		"v_cmpx_gt_f32 %[rayTA], v60\n"
-		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_gt_i32 vcc, 0, v52\n"
-		"v_cndmask_b32 v53, v52, v53, vcc\n"
-		"s_or_b64 s[90:91], s[90:91], vcc\n"
-		"s_mov_b64 exec, vcc\n"
-		"v_mov_b32 %[leafWordA], v52\n"
-		"v_mov_b32 %[tNearA], v60\n"
-		"s_mov_b64 exec, s[86:87]\n"
-		"v_mov_b32 v72, v53\n"                                // the cursor, where the prefetch below cannot reach it
-		"v_cmp_le_i32 s[94:95], 0, v72\n"
-		"s_andn2_b64 s[86:87], s[94:95], s[90:91]\n"
-	"4:\n"
-		"s_cmp_eq_u32 s79, 1\n"
-		"s_cbranch_scc1 6f\n"
+		PT_DUAL_VISIT_A( "4" )
 		PT_DUAL_FETCH( "s[86:87]", "v72", "46:49", "50", "53", "s80", "14" )
 		// ---- walk B
 		PT_DUAL_WAIT( "s80", "15", "16" )
@@ -128,9 +134,8 @@ PT_DEV void nodePhaseDualPipe(
 		"v_cmp_gt_i32 vcc, 0, v70\n"
 		"v_cndmask_b32 v71, v70, v71, vcc\n"
 		"s_or_b64 s[92:93], s[92:93], vcc\n"
-		"s_mov_b64 exec, vcc\n"
-		"v_mov_b32 %[leafWordB], v70\n"
-		"v_mov_b32 %[tNearB], v60\n"
+		"v_cndmask_b32 %[leafWordB], %[leafWordB], v70, vcc\n"
+		"v_cndmask_b32 %[tNearB], %[tNearB], v60, vcc\n"
 		"s_mov_b64 exec, s[88:89]\n"
 		"v_mov_b32 v73, v71\n"
 		"v_cmp_le_i32 s[94:95], 0, v73\n"
@@ -143,12 +148,15 @@ PT_DEV void nodePhaseDualPipe(
 		"s_cbranch_scc0 18f\n"
 		PT_DUAL_FETCH( "s[88:89]", "v73", "64:67", "68", "71", "s81", "17" )
 		"s_branch 1b\n"
+		PT_DUAL_WAIT_FULL( "12", "13" )
+		PT_DUAL_WAIT_FULL( "15", "16" )
+		PT_DUAL_FETCH_NONE( "s80", "10" )
+		PT_DUAL_FETCH_NONE( "s81", "11" )
+		PT_DUAL_FETCH_NONE( "s80", "14" )
+		PT_DUAL_FETCH_NONE( "s81", "17" )
 	"18:\n"                                                   // enough walks have left: no request for B; A's prefetched records are
-		"s_mov_b32 s79, 1\n"                                 // not dropped — walk A takes that visit, then the phase ends with
-		"s_mov_b32 s81, 0\n"                                 // nothing in flight
-		"s_branch 1b\n"
-	"6:\n"
-		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"                     // not dropped — walk A takes that visit (a node phase may always run one
+		PT_DUAL_VISIT_A( "6" )                                // visit longer), and the phase ends with nothing in flight
 		"s_mov_b64 exec, s[84:85]\n"
 		"v_mov_b32 %[refA], v72\n"
 		"v_mov_b32 %[refB], v73\n"
@@ -159,11 +167,14 @@ PT_DEV void nodePhaseDualPipe(
 		  [keep] "s"( keep ), [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps )
 		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
 		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
-		  "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc"
+		  "s80", "s81", "s82", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc"
 	);
 }
 #undef PT_DUAL_FETCH
 #undef PT_DUAL_WAIT
+#undef PT_DUAL_WAIT_FULL
+#undef PT_DUAL_FETCH_NONE
+#undef PT_DUAL_VISIT_A
 #undef PT_DUAL_SLAB
 
 // ---- a path slot: what a path keeps in registers while it is not being shaded ----------------------------------------
