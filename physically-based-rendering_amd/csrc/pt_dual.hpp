@@ -28,9 +28,12 @@
 // each kind, which were issued later — only when that other fetch did issue both kinds (an instruction with an empty EXEC
 // may or may not count); otherwise everything is waited for.  When `keep` or fewer walks go on, nothing more is requested
 // for B and walk A takes the visit its prefetch is for (a node phase may always run one visit longer): the phase ends with
-// nothing in flight.  Per walk 25 vector instructions per visit (nodePhaseAsm: 22) and ~14 scalar ones; ONE taken branch per
-// iteration — the loop's own: the uncommon cases (a full wait, a walk without lanes) are out of line, and the first form, which
-// jumped over them in every iteration, was 1 % slower for its two taken branches.
+// nothing in flight.  Per walk 24 vector instructions per visit (nodePhaseAsm: 22) and ~13 scalar ones.  What the loop's shape is
+// worth, measured step by step on the Sponza-class scene (profiles/r04/experiments/two_paths_per_lane.txt, 7.): the uncommon
+// cases (a full wait, a walk without lanes) out of line, ONE taken branch per iteration instead of three: +1.1 %; everything that
+// does not need the records (EXEC, the visit counter) in front of the wait instead of behind it: +0.9 %; walk A's next request
+// issued straight from the two masks, its bookkeeping behind the loads, and the parked lanes' leaf words collected once, when
+// the phase ends: +0.3 %.  The loop is bound by the length of its dependent chain, not by instruction issue.
 #define PT_DUAL_SLAB( n0a, n0b, n0c, n0d, n1a, n1b, oxy, ozz, ixy, izz ) \
 		"v_pk_add_f32 v[54:55], v[" n0a ":" n0b "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
 		"v_pk_add_f32 v[56:57], v[" n0c ":" n0d "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
@@ -74,24 +77,52 @@
 	full ":\n" \
 		"s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
 		"s_branch " go "b\n"
-// walk A's visit on the records in v[46:53] (used twice: in the loop and for the last visit of a phase)
-#define PT_DUAL_VISIT_A( skip ) \
+// walk A's visit on the records in v[46:53]: what does not need the records stands in front of the wait; behind it the slab
+// test, the hit chain, and s[98:99] = the lanes that stand on a hit leaf.  A parked lane's leaf word stays in v52 (no later
+// fetch of walk A includes the lane) and is collected when the phase ends; its tNear is a slab temporary and is kept at once.
+#define PT_DUAL_VISIT_A_CORE( skip, wait ) \
 		"s_mov_b64 exec, s[86:87]\n" \
 		"s_cbranch_execz " skip "f\n" \
 		"v_add_u32 %[visitsA], 1, %[visitsA]\n" \
+		wait \
 		PT_DUAL_SLAB( "46", "47", "48", "49", "50", "51", "%[oxyA]", "%[ozzA]", "%[ixyA]", "%[izzA]" ) \
 		"v_cmpx_lt_f32 %[eps], v61\n" \
 		"v_cmpx_gt_f32 %[rayTA], v60\n" \
 		"v_cmpx_le_f32 v60, v61\n" \
-		"v_cmp_gt_i32 vcc, 0, v52\n" \
-		"v_cndmask_b32 v53, v52, v53, vcc\n" \
-		"s_or_b64 s[90:91], s[90:91], vcc\n" \
-		"v_cndmask_b32 %[leafWordA], %[leafWordA], v52, vcc\n"   /* EXEC = the lanes whose box is hit, vcc = those on a leaf */ \
-		"v_cndmask_b32 %[tNearA], %[tNearA], v60, vcc\n" \
+		"v_cmp_gt_i32 s[98:99], 0, v52\n" \
+		"v_cndmask_b32 v53, v52, v53, s[98:99]\n" \
+		"v_cndmask_b32 %[tNearA], %[tNearA], v60, s[98:99]\n" \
 		"s_mov_b64 exec, s[86:87]\n" \
 		"v_mov_b32 v72, v53\n"                                /* the cursor, where the next prefetch cannot reach it */ \
-		"v_cmp_le_i32 s[94:95], 0, v72\n" \
-		"s_andn2_b64 s[86:87], s[94:95], s[90:91]\n" \
+		"v_cmp_le_i32 s[94:95], 0, v72\n"
+// ... and, in the loop, the request for its next records at once: the lanes that go on are EXEC straight from the two masks,
+// the bookkeeping (walk mask, parked mask) follows the loads
+#define PT_DUAL_VISIT_A_AND_FETCH( skip, wait, none, resume ) \
+		PT_DUAL_VISIT_A_CORE( skip, wait ) \
+		"s_andn2_b64 exec, s[94:95], s[98:99]\n" \
+		"s_cbranch_scc0 " none "f\n" \
+		"v_cmp_gt_i32 vcc, %[numHotBytes], v72\n" \
+		"s_and_saveexec_b64 s[94:95], vcc\n" \
+		"s_cselect_b32 s82, 1, 0\n" \
+		"ds_read_b128 v[46:49], v72\n" \
+		"ds_read_b128 v[50:53], v72 offset:16\n" \
+		"s_xor_b64 exec, exec, s[94:95]\n" \
+		"s_cselect_b32 s80, s82, 0\n" \
+		"global_load_dwordx4 v[46:49], v72, %[nodes]\n" \
+		"global_load_dwordx4 v[50:53], v72, %[nodes] offset:16\n" \
+		"s_mov_b64 s[86:87], s[94:95]\n" \
+	resume ":\n" \
+		"s_or_b64 s[90:91], s[90:91], s[98:99]\n" \
+	skip ":\n"
+#define PT_DUAL_VISIT_A_NONE( none, resume ) \
+	none ":\n" \
+		"s_mov_b32 s80, 0\n" \
+		"s_mov_b64 s[86:87], 0\n" \
+		"s_branch " resume "b\n"
+#define PT_DUAL_VISIT_A_LAST( skip, wait ) \
+		PT_DUAL_VISIT_A_CORE( skip, wait ) \
+		"s_andn2_b64 s[86:87], s[94:95], s[98:99]\n" \
+		"s_or_b64 s[90:91], s[90:91], s[98:99]\n" \
 	skip ":\n"
 
 // refA / refB: the walks' cursors (< 0: this slot sits the phase out).  A lane whose walk parks on a hit leaf gets the
@@ -119,27 +150,24 @@ PT_DEV void nodePhaseDualPipe(
 		PT_DUAL_FETCH( "s[88:89]", "v73", "64:67", "68", "71", "s81", "11" )
 	"1:\n"
 		// ---- walk A: its records (B's fetch, issued after them, may stay in flight)
-		PT_DUAL_WAIT( "s81", "12", "13" )
-		PT_DUAL_VISIT_A( "4" )
-		PT_DUAL_FETCH( "s[86:87]", "v72", "46:49", "50", "53", "s80", "14" )
+		PT_DUAL_VISIT_A_AND_FETCH( "4", PT_DUAL_WAIT( "s81", "12", "13" ), "14", "19" )
 		// ---- walk B
-		PT_DUAL_WAIT( "s80", "15", "16" )
 		"s_mov_b64 exec, s[88:89]\n"
 		"s_cbranch_execz 5f\n"
 		"v_add_u32 %[visitsB], 1, %[visitsB]\n"
+		PT_DUAL_WAIT( "s80", "15", "16" )
 		PT_DUAL_SLAB( "64", "65", "66", "67", "68", "69", "%[oxyB]", "%[ozzB]", "%[ixyB]", "%[izzB]" )
 		"v_cmpx_lt_f32 %[eps], v61\n"
 		"v_cmpx_gt_f32 %[rayTB], v60\n"
 		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_gt_i32 vcc, 0, v70\n"
-		"v_cndmask_b32 v71, v70, v71, vcc\n"
-		"s_or_b64 s[92:93], s[92:93], vcc\n"
-		"v_cndmask_b32 %[leafWordB], %[leafWordB], v70, vcc\n"
-		"v_cndmask_b32 %[tNearB], %[tNearB], v60, vcc\n"
+		"v_cmp_gt_i32 s[98:99], 0, v70\n"
+		"v_cndmask_b32 v71, v70, v71, s[98:99]\n"
+		"v_cndmask_b32 %[tNearB], %[tNearB], v60, s[98:99]\n"
 		"s_mov_b64 exec, s[88:89]\n"
 		"v_mov_b32 v73, v71\n"
 		"v_cmp_le_i32 s[94:95], 0, v73\n"
-		"s_andn2_b64 s[88:89], s[94:95], s[92:93]\n"
+		"s_andn2_b64 s[88:89], s[94:95], s[98:99]\n"
+		"s_or_b64 s[92:93], s[92:93], s[98:99]\n"
 	"5:\n"
 		"s_bcnt1_i32_b64 s96, s[86:87]\n"
 		"s_bcnt1_i32_b64 s97, s[88:89]\n"
@@ -152,11 +180,15 @@ PT_DEV void nodePhaseDualPipe(
 		PT_DUAL_WAIT_FULL( "15", "16" )
 		PT_DUAL_FETCH_NONE( "s80", "10" )
 		PT_DUAL_FETCH_NONE( "s81", "11" )
-		PT_DUAL_FETCH_NONE( "s80", "14" )
+		PT_DUAL_VISIT_A_NONE( "14", "19" )
 		PT_DUAL_FETCH_NONE( "s81", "17" )
 	"18:\n"                                                   // enough walks have left: no request for B; A's prefetched records are
-		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"                     // not dropped — walk A takes that visit (a node phase may always run one
-		PT_DUAL_VISIT_A( "6" )                                // visit longer), and the phase ends with nothing in flight
+		PT_DUAL_VISIT_A_LAST( "6", "s_waitcnt vmcnt(0) lgkmcnt(0)\n" )   // not dropped — walk A takes that visit (a node phase may always
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"                     // run one visit longer), and the phase ends with nothing in flight
+		"s_mov_b64 exec, s[90:91]\n"                          // the leaf words of the lanes that parked in this phase
+		"v_mov_b32 %[leafWordA], v52\n"
+		"s_mov_b64 exec, s[92:93]\n"
+		"v_mov_b32 %[leafWordB], v70\n"
 		"s_mov_b64 exec, s[84:85]\n"
 		"v_mov_b32 %[refA], v72\n"
 		"v_mov_b32 %[refB], v73\n"
@@ -167,14 +199,17 @@ PT_DEV void nodePhaseDualPipe(
 		  [keep] "s"( keep ), [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps )
 		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
 		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
-		  "s80", "s81", "s82", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc"
+		  "s80", "s81", "s82", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "vcc", "scc"
 	);
 }
 #undef PT_DUAL_FETCH
 #undef PT_DUAL_WAIT
 #undef PT_DUAL_WAIT_FULL
 #undef PT_DUAL_FETCH_NONE
-#undef PT_DUAL_VISIT_A
+#undef PT_DUAL_VISIT_A_CORE
+#undef PT_DUAL_VISIT_A_AND_FETCH
+#undef PT_DUAL_VISIT_A_NONE
+#undef PT_DUAL_VISIT_A_LAST
 #undef PT_DUAL_SLAB
 
 // ---- a path slot: what a path keeps in registers while it is not being shaded ----------------------------------------
