@@ -26,14 +26,15 @@
 // s[90:91] / s[92:93] = the lanes that parked on a hit leaf, s80 / s81 = "A's / B's last fetch issued loads of both kinds".
 // A wait in front of a slab test is COUNTED — s_waitcnt vmcnt(2) lgkmcnt(2): everything but the other walk's two loads of
 // each kind, which were issued later — only when that other fetch did issue both kinds (an instruction with an empty EXEC
-// may or may not count); otherwise everything is waited for.  When `keep` or fewer walks go on, nothing more is requested
-// for B and walk A takes the visit its prefetch is for (a node phase may always run one visit longer): the phase ends with
-// nothing in flight.  Per walk 24 vector instructions per visit (nodePhaseAsm: 22) and ~13 scalar ones.  What the loop's shape is
-// worth, measured step by step on the Sponza-class scene (profiles/r04/experiments/two_paths_per_lane.txt, 7.): the uncommon
-// cases (a full wait, a walk without lanes) out of line, ONE taken branch per iteration instead of three: +1.1 %; everything that
-// does not need the records (EXEC, the visit counter) in front of the wait instead of behind it: +0.9 %; walk A's next request
-// issued straight from the two masks, its bookkeeping behind the loads, and the parked lanes' leaf words collected once, when
-// the phase ends: +0.3 %.  The loop is bound by the length of its dependent chain, not by instruction issue.
+// may or may not count); otherwise everything is waited for.  A walk's next records are requested as soon as its visit has
+// decided which lanes go on — the exit test runs under the requests; when `keep` or fewer walks go on, each walk takes the visit
+// its request is for (a node phase may always run one visit longer) and the phase ends with nothing in flight.
+// Per walk 24 vector instructions per visit (nodePhaseAsm: 22) and ~13 scalar ones.  What the loop's shape is worth, measured
+// step by step on the Sponza-class scene (profiles/r04/experiments/two_paths_per_lane.txt, 7.): the uncommon cases (a full
+// wait, a walk without lanes) out of line, ONE taken branch per iteration instead of three: +1.1 %; everything that does not
+// need the records (EXEC, the visit counter) in front of the wait instead of behind it: +0.9 %; the next request issued
+// straight from the two masks, its bookkeeping behind the loads, and the parked lanes' leaf words collected once, when the
+// phase ends: +0.3 %.  The loop is bound by the length of its dependent chain, not by instruction issue.
 #define PT_DUAL_SLAB( n0a, n0b, n0c, n0d, n1a, n1b, oxy, ozz, ixy, izz ) \
 		"v_pk_add_f32 v[54:55], v[" n0a ":" n0b "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
 		"v_pk_add_f32 v[56:57], v[" n0c ":" n0d "], " oxy " neg_lo:[0,1] neg_hi:[0,1]\n" \
@@ -77,53 +78,59 @@
 	full ":\n" \
 		"s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
 		"s_branch " go "b\n"
-// walk A's visit on the records in v[46:53]: what does not need the records stands in front of the wait; behind it the slab
-// test, the hit chain, and s[98:99] = the lanes that stand on a hit leaf.  A parked lane's leaf word stays in v52 (no later
-// fetch of walk A includes the lane) and is collected when the phase ends; its tNear is a slab temporary and is kept at once.
-#define PT_DUAL_VISIT_A_CORE( skip, wait ) \
-		"s_mov_b64 exec, s[86:87]\n" \
+// One walk's visit: what does not need the records stands in front of the wait; behind it the slab test, the hit chain, and
+// s[98:99] = the lanes that stand on a hit leaf.  A parked lane's leaf word stays in the record's register (v52 / v70: no
+// later fetch of that walk includes the lane) and is collected when the phase ends; its tNear is a slab temporary, kept at once.
+// W = "A" / "B"; walk, park = the walk's mask pairs; r0..r7 = the eight record registers; cur = its cursor register.
+#define PT_DUAL_VISIT_CORE( ... ) PT_DUAL_VISIT_CORE_( __VA_ARGS__ )      /* (the register lists are macros: expanded before the call) */
+#define PT_DUAL_VISIT_CORE_( skip, wait, W, walk, r0, r1, r2, r3, r4, r5, r6, r7, cur ) \
+		"s_mov_b64 exec, " walk "\n" \
 		"s_cbranch_execz " skip "f\n" \
-		"v_add_u32 %[visitsA], 1, %[visitsA]\n" \
+		"v_add_u32 %[visits" W "], 1, %[visits" W "]\n" \
 		wait \
-		PT_DUAL_SLAB( "46", "47", "48", "49", "50", "51", "%[oxyA]", "%[ozzA]", "%[ixyA]", "%[izzA]" ) \
+		PT_DUAL_SLAB( r0, r1, r2, r3, r4, r5, "%[oxy" W "]", "%[ozz" W "]", "%[ixy" W "]", "%[izz" W "]" ) \
 		"v_cmpx_lt_f32 %[eps], v61\n" \
-		"v_cmpx_gt_f32 %[rayTA], v60\n" \
+		"v_cmpx_gt_f32 %[rayT" W "], v60\n" \
 		"v_cmpx_le_f32 v60, v61\n" \
-		"v_cmp_gt_i32 s[98:99], 0, v52\n" \
-		"v_cndmask_b32 v53, v52, v53, s[98:99]\n" \
-		"v_cndmask_b32 %[tNearA], %[tNearA], v60, s[98:99]\n" \
-		"s_mov_b64 exec, s[86:87]\n" \
-		"v_mov_b32 v72, v53\n"                                /* the cursor, where the next prefetch cannot reach it */ \
-		"v_cmp_le_i32 s[94:95], 0, v72\n"
+		"v_cmp_gt_i32 s[98:99], 0, v" r6 "\n" \
+		"v_cndmask_b32 v" r7 ", v" r6 ", v" r7 ", s[98:99]\n" \
+		"v_cndmask_b32 %[tNear" W "], %[tNear" W "], v60, s[98:99]\n" \
+		"s_mov_b64 exec, " walk "\n" \
+		"v_mov_b32 " cur ", v" r7 "\n"                        /* the cursor, where the next prefetch cannot reach it */ \
+		"v_cmp_le_i32 s[94:95], 0, " cur "\n"
 // ... and, in the loop, the request for its next records at once: the lanes that go on are EXEC straight from the two masks,
 // the bookkeeping (walk mask, parked mask) follows the loads
-#define PT_DUAL_VISIT_A_AND_FETCH( skip, wait, none, resume ) \
-		PT_DUAL_VISIT_A_CORE( skip, wait ) \
+#define PT_DUAL_VISIT_AND_FETCH( ... ) PT_DUAL_VISIT_AND_FETCH_( __VA_ARGS__ )
+#define PT_DUAL_VISIT_AND_FETCH_( skip, wait, none, resume, W, walk, park, flag, r0, r1, r2, r3, r4, r5, r6, r7, cur ) \
+		PT_DUAL_VISIT_CORE( skip, wait, W, walk, r0, r1, r2, r3, r4, r5, r6, r7, cur ) \
 		"s_andn2_b64 exec, s[94:95], s[98:99]\n" \
 		"s_cbranch_scc0 " none "f\n" \
-		"v_cmp_gt_i32 vcc, %[numHotBytes], v72\n" \
+		"v_cmp_gt_i32 vcc, %[numHotBytes], " cur "\n" \
 		"s_and_saveexec_b64 s[94:95], vcc\n" \
 		"s_cselect_b32 s82, 1, 0\n" \
-		"ds_read_b128 v[46:49], v72\n" \
-		"ds_read_b128 v[50:53], v72 offset:16\n" \
+		"ds_read_b128 v[" r0 ":" r3 "], " cur "\n" \
+		"ds_read_b128 v[" r4 ":" r7 "], " cur " offset:16\n" \
 		"s_xor_b64 exec, exec, s[94:95]\n" \
-		"s_cselect_b32 s80, s82, 0\n" \
-		"global_load_dwordx4 v[46:49], v72, %[nodes]\n" \
-		"global_load_dwordx4 v[50:53], v72, %[nodes] offset:16\n" \
-		"s_mov_b64 s[86:87], s[94:95]\n" \
+		"s_cselect_b32 " flag ", s82, 0\n" \
+		"global_load_dwordx4 v[" r0 ":" r3 "], " cur ", %[nodes]\n" \
+		"global_load_dwordx4 v[" r4 ":" r7 "], " cur ", %[nodes] offset:16\n" \
+		"s_mov_b64 " walk ", s[94:95]\n" \
 	resume ":\n" \
-		"s_or_b64 s[90:91], s[90:91], s[98:99]\n" \
+		"s_or_b64 " park ", " park ", s[98:99]\n" \
 	skip ":\n"
-#define PT_DUAL_VISIT_A_NONE( none, resume ) \
+#define PT_DUAL_VISIT_NONE( none, resume, walk, flag ) \
 	none ":\n" \
-		"s_mov_b32 s80, 0\n" \
-		"s_mov_b64 s[86:87], 0\n" \
+		"s_mov_b32 " flag ", 0\n" \
+		"s_mov_b64 " walk ", 0\n" \
 		"s_branch " resume "b\n"
-#define PT_DUAL_VISIT_A_LAST( skip, wait ) \
-		PT_DUAL_VISIT_A_CORE( skip, wait ) \
-		"s_andn2_b64 s[86:87], s[94:95], s[98:99]\n" \
-		"s_or_b64 s[90:91], s[90:91], s[98:99]\n" \
+#define PT_DUAL_VISIT_LAST( ... ) PT_DUAL_VISIT_LAST_( __VA_ARGS__ )
+#define PT_DUAL_VISIT_LAST_( skip, W, walk, park, r0, r1, r2, r3, r4, r5, r6, r7, cur ) \
+		PT_DUAL_VISIT_CORE( skip, "s_waitcnt vmcnt(0) lgkmcnt(0)\n", W, walk, r0, r1, r2, r3, r4, r5, r6, r7, cur ) \
+		"s_andn2_b64 " walk ", s[94:95], s[98:99]\n" \
+		"s_or_b64 " park ", " park ", s[98:99]\n" \
 	skip ":\n"
+#define PT_DUAL_REGS_A "46", "47", "48", "49", "50", "51", "52", "53", "v72"
+#define PT_DUAL_REGS_B "64", "65", "66", "67", "68", "69", "70", "71", "v73"
 
 // refA / refB: the walks' cursors (< 0: this slot sits the phase out).  A lane whose walk parks on a hit leaf gets the
 // leaf's word and tNear in leafWordA / tNearA (leafWordB / tNearB); the caller passes 0 in and reads != 0 as "parked".
@@ -149,42 +156,19 @@ PT_DEV void nodePhaseDualPipe(
 		PT_DUAL_FETCH( "s[86:87]", "v72", "46:49", "50", "53", "s80", "10" )
 		PT_DUAL_FETCH( "s[88:89]", "v73", "64:67", "68", "71", "s81", "11" )
 	"1:\n"
-		// ---- walk A: its records (B's fetch, issued after them, may stay in flight)
-		PT_DUAL_VISIT_A_AND_FETCH( "4", PT_DUAL_WAIT( "s81", "12", "13" ), "14", "19" )
-		// ---- walk B
-		"s_mov_b64 exec, s[88:89]\n"
-		"s_cbranch_execz 5f\n"
-		"v_add_u32 %[visitsB], 1, %[visitsB]\n"
-		PT_DUAL_WAIT( "s80", "15", "16" )
-		PT_DUAL_SLAB( "64", "65", "66", "67", "68", "69", "%[oxyB]", "%[ozzB]", "%[ixyB]", "%[izzB]" )
-		"v_cmpx_lt_f32 %[eps], v61\n"
-		"v_cmpx_gt_f32 %[rayTB], v60\n"
-		"v_cmpx_le_f32 v60, v61\n"
-		"v_cmp_gt_i32 s[98:99], 0, v70\n"
-		"v_cndmask_b32 v71, v70, v71, s[98:99]\n"
-		"v_cndmask_b32 %[tNearB], %[tNearB], v60, s[98:99]\n"
-		"s_mov_b64 exec, s[88:89]\n"
-		"v_mov_b32 v73, v71\n"
-		"v_cmp_le_i32 s[94:95], 0, v73\n"
-		"s_andn2_b64 s[88:89], s[94:95], s[98:99]\n"
-		"s_or_b64 s[92:93], s[92:93], s[98:99]\n"
-	"5:\n"
+		// walk A on its records (B's request, issued after them, may stay in flight), and A's next request; then B the same way
+		PT_DUAL_VISIT_AND_FETCH( "4", PT_DUAL_WAIT( "s81", "12", "13" ), "14", "19", "A", "s[86:87]", "s[90:91]", "s80", PT_DUAL_REGS_A )
+		PT_DUAL_VISIT_AND_FETCH( "5", PT_DUAL_WAIT( "s80", "15", "16" ), "17", "20", "B", "s[88:89]", "s[92:93]", "s81", PT_DUAL_REGS_B )
 		"s_bcnt1_i32_b64 s96, s[86:87]\n"
 		"s_bcnt1_i32_b64 s97, s[88:89]\n"
 		"s_add_i32 s96, s96, s97\n"
 		"s_cmp_gt_i32 s96, %[keep]\n"
-		"s_cbranch_scc0 18f\n"
-		PT_DUAL_FETCH( "s[88:89]", "v73", "64:67", "68", "71", "s81", "17" )
-		"s_branch 1b\n"
-		PT_DUAL_WAIT_FULL( "12", "13" )
-		PT_DUAL_WAIT_FULL( "15", "16" )
-		PT_DUAL_FETCH_NONE( "s80", "10" )
-		PT_DUAL_FETCH_NONE( "s81", "11" )
-		PT_DUAL_VISIT_A_NONE( "14", "19" )
-		PT_DUAL_FETCH_NONE( "s81", "17" )
-	"18:\n"                                                   // enough walks have left: no request for B; A's prefetched records are
-		PT_DUAL_VISIT_A_LAST( "6", "s_waitcnt vmcnt(0) lgkmcnt(0)\n" )   // not dropped — walk A takes that visit (a node phase may always
-		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"                     // run one visit longer), and the phase ends with nothing in flight
+		"s_cbranch_scc1 1b\n"
+		// enough walks have left.  The records that are on their way are not dropped: each walk takes that visit (a node phase
+		// may always run one visit longer), and the phase ends with nothing in flight
+		PT_DUAL_VISIT_LAST( "6", "A", "s[86:87]", "s[90:91]", PT_DUAL_REGS_A )
+		PT_DUAL_VISIT_LAST( "7", "B", "s[88:89]", "s[92:93]", PT_DUAL_REGS_B )
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"
 		"s_mov_b64 exec, s[90:91]\n"                          // the leaf words of the lanes that parked in this phase
 		"v_mov_b32 %[leafWordA], v52\n"
 		"s_mov_b64 exec, s[92:93]\n"
@@ -192,6 +176,14 @@ PT_DEV void nodePhaseDualPipe(
 		"s_mov_b64 exec, s[84:85]\n"
 		"v_mov_b32 %[refA], v72\n"
 		"v_mov_b32 %[refB], v73\n"
+		"s_branch 21f\n"
+		PT_DUAL_WAIT_FULL( "12", "13" )
+		PT_DUAL_WAIT_FULL( "15", "16" )
+		PT_DUAL_FETCH_NONE( "s80", "10" )
+		PT_DUAL_FETCH_NONE( "s81", "11" )
+		PT_DUAL_VISIT_NONE( "14", "19", "s[86:87]", "s80" )
+		PT_DUAL_VISIT_NONE( "17", "20", "s[88:89]", "s81" )
+	"21:\n"
 		: [refA] "+v"( refA ), [refB] "+v"( refB ), [visitsA] "+v"( visitsA ), [visitsB] "+v"( visitsB ),
 		  [leafWordA] "+v"( leafWordA ), [tNearA] "+v"( tNearA ), [leafWordB] "+v"( leafWordB ), [tNearB] "+v"( tNearB )
 		: [oxyA] "v"( oxyA ), [ozzA] "v"( ozzA ), [ixyA] "v"( ixyA ), [izzA] "v"( izzA ), [rayTA] "v"( rayTA ),
@@ -206,10 +198,15 @@ PT_DEV void nodePhaseDualPipe(
 #undef PT_DUAL_WAIT
 #undef PT_DUAL_WAIT_FULL
 #undef PT_DUAL_FETCH_NONE
-#undef PT_DUAL_VISIT_A_CORE
-#undef PT_DUAL_VISIT_A_AND_FETCH
-#undef PT_DUAL_VISIT_A_NONE
-#undef PT_DUAL_VISIT_A_LAST
+#undef PT_DUAL_VISIT_CORE
+#undef PT_DUAL_VISIT_CORE_
+#undef PT_DUAL_VISIT_AND_FETCH
+#undef PT_DUAL_VISIT_AND_FETCH_
+#undef PT_DUAL_VISIT_LAST_
+#undef PT_DUAL_VISIT_NONE
+#undef PT_DUAL_VISIT_LAST
+#undef PT_DUAL_REGS_A
+#undef PT_DUAL_REGS_B
 #undef PT_DUAL_SLAB
 
 // ---- a path slot: what a path keeps in registers while it is not being shaded ----------------------------------------

@@ -860,9 +860,9 @@ PT_DEV Cursor firstNode( const DevParams& P ) {
 #if !defined( PBR_GUARD ) && !defined( PBR_NODE_PHASE_CXX )
 #define PT_NODE_PHASE_ASM 1
 
-// PARKED_ONLY (round 4, lab: VERDICT r03 item 6): the phase ends once `keep` lanes have PARKED on a leaf — lanes whose
-// walk has ended leave the loop without counting — or nobody is left walking; the default ends it once `keep` or fewer lanes go on.
-template<bool ANYHIT, bool PARKED_ONLY = false>
+// (Round 4's PARKED_ONLY variant — the phase ends once `keep` lanes have PARKED; measured slower, profiles/r04/experiments/leaf_phase.txt —
+// lived here as a second loop tail until the loop was pipelined; it is in the history of this file.)
+template<bool ANYHIT>
 PT_DEV void nodePhaseAsm(
 	const DevParams& P, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep,
 	int& ref, unsigned& visits, int& leafWord, float& leafTNear, float& leafTFar, int& parked
@@ -872,11 +872,13 @@ PT_DEV void nodePhaseAsm(
 	unsigned long long saved, active, parkMask, mA;
 	int count;
 
-#define PT_NODE_PHASE_HEAD \
-		"s_mov_b64 %[saved], exec\n" \
-		"s_mov_b64 %[parkMask], 0\n" \
-		"v_mov_b32 v53, %[ref]\n" \
-	"1:\n" \
+	// The loop is software-pipelined (round 4): as soon as a visit has decided which lanes go on, their next records are
+	// requested — the exit test runs under that request, not in front of it.  What stands between a record's arrival and the
+	// next request is what bounds the walk (profiles/r04/experiments/padding_sensitivity.txt: an instruction behind the wait
+	// costs three times what one in front of it costs; pt_dual.hpp gained 2 % from the same reordering), and the exit test was
+	// three scalar instructions and the loop's taken branch of it.  When the phase ends with a request on its way, the lanes it
+	// is for take that visit too (a node phase may always run one visit longer: per lane the sequence of visits is the same).
+#define PT_NODE_PHASE_FETCH \
 		"v_cmp_gt_i32 vcc, %[numHotBytes], v53\n" \
 		"s_and_saveexec_b64 %[active], vcc\n" \
 		"ds_read_b128 v[46:49], v53\n" \
@@ -884,7 +886,16 @@ PT_DEV void nodePhaseAsm(
 		"s_xor_b64 exec, exec, %[active]\n" \
 		"global_load_dwordx4 v[46:49], v53, %[nodes]\n" \
 		"global_load_dwordx4 v[50:53], v53, %[nodes] offset:16\n" \
-		"s_mov_b64 exec, %[active]\n" \
+		"s_mov_b64 exec, %[active]\n"
+	// EXEC = the lanes whose box is hit.  A hit container continues at w0, everything else at w1;
+	// the lanes on a hit leaf park; then the lanes that go on: alive and not parked.
+	// Round 3: the cursor lives in v53 for the whole phase — the record's last word IS the reference to continue at
+	// unless the box is a hit container, so the load that fetches a record also advances the cursor (a load may
+	// overwrite its own address register), and the per-visit copy of w1 is gone; and tFar is min3 of the three slab
+	// exits as they stand: pt_intersect.cl's fmin( ., INFINITY ) on the third only matters when all three are NaN, and
+	// then tNear is NaN too and the box is missed either way (the C++ statement below keeps the reference's form).
+	// 22 vector + 8 scalar instructions per visit.
+#define PT_NODE_PHASE_VISIT( cull ) \
 		"v_add_u32 %[visits], 1, %[visits]\n" \
 		"s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
 		"v_pk_add_f32 v[54:55], v[46:47], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n" \
@@ -901,34 +912,28 @@ PT_DEV void nodePhaseAsm(
 		"v_max_f32 v63, v58, v59\n" \
 		"v_max_f32 v62, v55, v57\n" \
 		"v_min3_f32 v61, v61, v62, v63\n" \
-		"v_cmpx_lt_f32 %[eps], v61\n"
-
-	// EXEC = the lanes whose box is hit.  A hit container continues at w0, everything else at w1;
-	// the lanes on a hit leaf park; then the lanes that go on: alive and not parked.
-	// Round 3: the cursor lives in v53 for the whole phase — the record's last word IS the reference to continue at
-	// unless the box is a hit container, so the load that fetches a record also advances the cursor (a load may
-	// overwrite its own address register), and the per-visit copy of w1 is gone; and tFar is min3 of the three slab
-	// exits as they stand: pt_intersect.cl's fmin( ., INFINITY ) on the third only matters when all three are NaN, and
-	// then tNear is NaN too and the box is missed either way (the C++ statement below keeps the reference's form).
-	// 22 vector + 8 scalar instructions per visit.
-#define PT_NODE_PHASE_TAIL_BEGIN \
+		"v_cmpx_lt_f32 %[eps], v61\n" \
+		cull \
 		"v_cmp_gt_i32 vcc, 0, v52\n" \
 		"v_cndmask_b32 v53, v52, v53, vcc\n" \
 		"s_or_b64 %[parkMask], %[parkMask], vcc\n" \
 		"s_mov_b64 exec, %[active]\n" \
 		"v_cmp_le_i32 %[mA], 0, v53\n" \
 		"s_andn2_b64 exec, %[mA], vcc\n"
-#define PT_NODE_PHASE_LOOP_DEFAULT \
+#define PT_NODE_PHASE_LOOP( cull ) \
+		"s_mov_b64 %[saved], exec\n" \
+		"s_mov_b64 %[parkMask], 0\n" \
+		"v_mov_b32 v53, %[ref]\n" \
+		PT_NODE_PHASE_FETCH \
+	"1:\n" \
+		PT_NODE_PHASE_VISIT( cull ) \
+		"s_cbranch_scc0 3f\n"                                 /* nobody goes on: nothing to request */ \
+		PT_NODE_PHASE_FETCH \
 		"s_bcnt1_i32_b64 %[count], exec\n" \
 		"s_cmp_gt_i32 %[count], %[keep]\n" \
-		"s_cbranch_scc1 1b\n"
-#define PT_NODE_PHASE_LOOP_PARKED_ONLY \
-		"s_cbranch_execz 3f\n" \
-		"s_bcnt1_i32_b64 %[count], %[parkMask]\n" \
-		"s_cmp_lt_i32 %[count], %[keep]\n" \
 		"s_cbranch_scc1 1b\n" \
-	"3:\n"
-#define PT_NODE_PHASE_TAIL_END \
+		PT_NODE_PHASE_VISIT( cull )                            /* the phase ends; the records on their way are not dropped */ \
+	"3:\n" \
 		"s_mov_b64 exec, %[saved]\n" \
 		"v_mov_b32 %[ref], v53\n" \
 		"v_cndmask_b32 %[parked], 0, 1, %[parkMask]\n" \
@@ -946,42 +951,20 @@ PT_DEV void nodePhaseAsm(
 	if( ANYHIT ) {
 		// traverseShadows: no `ray.t > tNear` cull (pt_bvh.cl:151-154)
 		asm volatile(
-			PT_NODE_PHASE_HEAD
-			"v_cmpx_le_f32 v60, v61\n"
-			PT_NODE_PHASE_TAIL_BEGIN
-			PT_NODE_PHASE_LOOP_DEFAULT
-			PT_NODE_PHASE_TAIL_END
-			PT_NODE_PHASE_OPERANDS
-		);
-	}
-	else if( PARKED_ONLY ) {
-		asm volatile(
-			PT_NODE_PHASE_HEAD
-			"v_cmpx_gt_f32 %[rayT], v60\n"
-			"v_cmpx_le_f32 v60, v61\n"
-			PT_NODE_PHASE_TAIL_BEGIN
-			PT_NODE_PHASE_LOOP_PARKED_ONLY
-			PT_NODE_PHASE_TAIL_END
+			PT_NODE_PHASE_LOOP( "v_cmpx_le_f32 v60, v61\n" )
 			PT_NODE_PHASE_OPERANDS
 		);
 	}
 	else {
 		asm volatile(
-			PT_NODE_PHASE_HEAD
-			"v_cmpx_gt_f32 %[rayT], v60\n"
-			"v_cmpx_le_f32 v60, v61\n"
-			PT_NODE_PHASE_TAIL_BEGIN
-			PT_NODE_PHASE_LOOP_DEFAULT
-			PT_NODE_PHASE_TAIL_END
+			PT_NODE_PHASE_LOOP( "v_cmpx_gt_f32 %[rayT], v60\n" "v_cmpx_le_f32 v60, v61\n" )
 			PT_NODE_PHASE_OPERANDS
 		);
 	}
 
-#undef PT_NODE_PHASE_HEAD
-#undef PT_NODE_PHASE_TAIL_BEGIN
-#undef PT_NODE_PHASE_LOOP_DEFAULT
-#undef PT_NODE_PHASE_LOOP_PARKED_ONLY
-#undef PT_NODE_PHASE_TAIL_END
+#undef PT_NODE_PHASE_FETCH
+#undef PT_NODE_PHASE_VISIT
+#undef PT_NODE_PHASE_LOOP
 #undef PT_NODE_PHASE_OPERANDS
 }
 
@@ -2220,14 +2203,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				else
 #endif
 				{
-#ifdef PBR_EXP_PARKED_ONLY
-					// lab: the phase ends once parkNow lanes (at most half of those that entered) stand on a leaf
-					const int entered = keep + parkNow;
-					const int target = ( parkNow < ( entered + 1 ) / 2 ) ? parkNow : ( entered + 1 ) / 2;
-					nodePhaseAsm<false, true>( P, oxy, ozz, ixy, izz, w.hit.t, ( target < 1 ) ? 1 : target, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
-#else
 					nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
-#endif
 				}
 				st.dbgNodes += visits;
 				PT_LAB_PHASED_NODE_MID
