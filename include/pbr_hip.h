@@ -97,7 +97,30 @@ typedef struct {
 	 * order would hand a rank whole tile columns whenever tilesX is a multiple of tile_world, and columns do not cost
 	 * the same).  Local tile j of a rank is the tile at p = j * tile_world + tile_rank.  1 / 0 = everything, p = tile. */
 	uint32_t tile_world, tile_rank;
+	/* Two opt-in modes that are NOT reference constants; 0 / 0 (the value-initialised struct) is the reference's behaviour.
+	 * traversal  PBR_WALK_REFERENCE (0): the reference's walk — a hit continues at index + 1 (pt_bvh.cl:102,112), the
+	 *            child with the bigger surface area first whatever the ray (accelstructures/BVH.cpp:335-343).
+	 *            PBR_WALK_SIX_ORDERS (1): the same flat tree, same boxes, leaves and per-visit arithmetic, but the children
+	 *            of every container are visited in the order of their box centres along the ray direction's dominant axis
+	 *            (six successor sets, chosen once per ray; still stackless).  Closest hits are the same faces at the same t
+	 *            except where two faces tie exactly; the node / face-test counters and the debug image are this walk's own.
+	 *            PBR_WALK_EIGHT_ORDERS (2): likewise with eight successor sets, one per sign octant of the ray direction;
+	 *            every container orders its children along ITS axis (the one their centres spread furthest on).
+	 *            Both cost node memory (6 / 8 streams of 32-byte records instead of one).
+	 * arith      PBR_ARITH_EXACT (0): every builtin has one correctly rounded / fixed definition.
+	 *            PBR_ARITH_NATIVE (1): what the reference asks its device for — native_sin / native_cos / native_tan /
+	 *            native_recip / native_divide / native_sqrt (pt_utils.cl:39-44, pt_brdf.cl:306-321, pt_intersect.cl:104,
+	 *            pt_bvh.cl:83) as the gfx950 instructions, pow through v_log_f32 / v_exp_f32.  Images then agree with the
+	 *            exact mode statistically, not bit for bit. */
+	uint32_t traversal;
+	uint32_t arith;
 } pbr_config;
+
+#define PBR_WALK_REFERENCE 0u
+#define PBR_WALK_SIX_ORDERS 1u
+#define PBR_WALK_EIGHT_ORDERS 2u
+#define PBR_ARITH_EXACT 0u
+#define PBR_ARITH_NATIVE 1u
 
 /* Traversal counters (the reference's debugColor.y / .x, pt_bvh.cl:89,23, as exact integers,
  * plus shaded hits and camera paths) summed over everything rendered since the last reset. */

@@ -72,6 +72,7 @@ class OrcConfig(ctypes.Structure):
         ("shadow_rays", ctypes.c_int32), ("max_depth", ctypes.c_int32), ("max_added_depth", ctypes.c_int32),
         ("samples", ctypes.c_int32), ("num_nodes", ctypes.c_int32), ("num_lights", ctypes.c_int32),
         ("anti_aliasing", ctypes.c_float), ("sky_light", ctypes.c_float * 4), ("phong_tessellation", ctypes.c_float),
+        ("traversal", ctypes.c_int32),
     ]
 
 
@@ -81,6 +82,7 @@ class OrcScene(ctypes.Structure):
         ("materials", ctypes.c_void_p), ("lights", ctypes.c_void_p),
         ("num_faces", ctypes.c_uint32), ("num_vertices", ctypes.c_uint32), ("num_materials", ctypes.c_uint32),
         ("facesN", ctypes.c_void_p), ("normals", ctypes.c_void_p), ("num_normals", ctypes.c_uint32),
+        ("walk_links", ctypes.c_void_p), ("walk_first", ctypes.c_void_p),
     ]
 
 
@@ -130,6 +132,12 @@ def lib():
         _lib.orc_brdf_eval.restype = None
         _lib.orc_new_ray.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_int, _fp]
         _lib.orc_new_ray.restype = None
+        _lib.orc_walk_order_count.argtypes = [ctypes.c_int]
+        _lib.orc_walk_order_count.restype = ctypes.c_int
+        _lib.orc_build_walk_orders.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.orc_build_walk_orders.restype = ctypes.c_int
+        _lib.orc_debug_set_walk_max.argtypes = [ctypes.c_void_p]
+        _lib.orc_debug_set_walk_max.restype = None
     return _lib
 
 
@@ -162,7 +170,27 @@ def scene_and_config(desc, cfg):
     c.phong_tessellation = getattr(cfg, "phong_tessellation", 0.0)
     for k in range(4):
         c.sky_light[k] = cfg.sky_light[k]
+    c.traversal = int(getattr(cfg, "traversal", 0))
+    if c.traversal:
+        links, first = walk_orders(desc, c.traversal)
+        s.walk_links, s.walk_first = links.ctypes.data, first.ctypes.data
+        s._walk = (links, first)          # the scene struct keeps the tables alive
     return s, c
+
+
+def walk_orders(desc, scheme):
+    """The successor tables of the product's opt-in ray-ordered walk (pt_oracle.c, "Ray-ordered walk"): (links, first),
+    links[k, node] = (hit, miss).  Not a reference algorithm; see the C source."""
+    k = lib().orc_walk_order_count(int(scheme))
+    if k <= 0:
+        raise ValueError("unknown traversal scheme %r" % (scheme,))
+    n = int(desc.num_nodes)
+    links = np.full((k, n, 2), -1, np.int32)
+    first = np.full(k, -1, np.int32)
+    bvh = desc.bvh if isinstance(desc.bvh, int) else ctypes.cast(desc.bvh, ctypes.c_void_p).value
+    if lib().orc_build_walk_orders(bvh, n, int(scheme), links.ctypes.data, first.ctypes.data) != 0:
+        raise ValueError("orc_build_walk_orders failed")
+    return links, first
 
 
 class Renderer:

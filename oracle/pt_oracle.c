@@ -14,6 +14,7 @@
 
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -1146,15 +1147,26 @@ void orc_debug_set_visit_log( int32_t* log, uint64_t capacity, uint64_t* count )
 }
 
 /* traverse, pt_bvh.cl:82-123 */
+static void traverseOrdered( ctx_t* c, ray4* ray );
+static void traverseShadowsOrdered( ctx_t* c, ray4* ray );
+static inline void noteWalk( uint32_t visits );
+
 static void traverse( ctx_t* c, ray4* ray ) {
+	if( c->cfg->traversal != 0 ) {
+		traverseOrdered( c, ray );   /* the product's opt-in ray-ordered walk, not the reference's: see below */
+		return;
+	}
+
 	const v3 invDir = V3( det_rcp( ray->dir.x ), det_rcp( ray->dir.y ), det_rcp( ray->dir.z ) );
 	const int numNodes = c->cfg->num_nodes;
 	int index = 1;
+	uint32_t walkVisits = 0;   /* analysis aid only (orc_debug_set_walk_max) */
 
 	traverseLights( c, ray );
 
 	do {
 		c->dbg_nodes += 1.0f;
+		walkVisits++;
 		if( g_node_hist ) {
 			__atomic_fetch_add( &g_node_hist[index], 1u, __ATOMIC_RELAXED );
 		}
@@ -1184,10 +1196,17 @@ static void traverse( ctx_t* c, ray4* ray ) {
 			intersectFaces( c, ray, &node, tNear, tFar );
 		}
 	} while( index > 0 && index < numNodes );
+
+	noteWalk( walkVisits );
 }
 
 /* traverseShadows, pt_bvh.cl:133-177 (the bbMin.w == -2 branch is kept although the host never emits -2) */
 static void traverseShadows( ctx_t* c, ray4* ray ) {
+	if( c->cfg->traversal != 0 ) {
+		traverseShadowsOrdered( c, ray );
+		return;
+	}
+
 	const float tLight = ray->t;
 	const v3 invDir = V3( det_rcp( ray->dir.x ), det_rcp( ray->dir.y ), det_rcp( ray->dir.z ) );
 	const int numNodes = c->cfg->num_nodes;
@@ -1227,6 +1246,268 @@ static void traverseShadows( ctx_t* c, ray4* ray ) {
 			}
 		}
 	} while( index > 0 && index < numNodes );
+}
+
+
+/* ------------------------------------------------------------------------- */
+/* Ray-ordered walk — NOT in the reference                                   */
+/* ------------------------------------------------------------------------- */
+
+/* The reference walks its flat tree in ONE order: a hit continues at index + 1 (pt_bvh.cl:102,112) and the builder
+ * puts the child with the bigger surface area there, whatever the ray (accelstructures/BVH.cpp:335-343).  The product
+ * has an opt-in mode (pbr_config.traversal) that walks the SAME flat tree — same boxes, same leaves, same arithmetic per
+ * visit (intersectBox, the hit condition of pt_bvh.cl:107-110, intersectFaces) — with the children of every container
+ * ordered along the ray.  This is its CPU statement, so that the HIP path has something to be bit-identical to; what it
+ * owes the reference is checked separately (tests: the image against the reference-order image within SURVEY 8(c)'s
+ * tolerance; only exact ties of the closest hit can differ, because intersectFace keeps the first of two equal t).
+ *
+ * The tree behind the flat array: a leaf ends at index + 1; a container i ends at its miss link when that is > i, else
+ * where its parent ends (the root: N); its children are c0 = i + 1, c1 = end( c0 ), ... while < end( i ) (the flattening
+ * drops nodes, PathTracer.cpp:250-256, so a container can have more than two).
+ *
+ * Scheme 1 (six orders): order k = 2 * axis + negative, axis = the ray direction's dominant axis (x before y before z
+ * on ties), negative = dir[axis] < 0.  A child's key on an axis is bbMin[axis] + bbMax[axis] in binary32.  Order
+ * ( axis, + ): insertion sort of the DFS child list, a child moves in front of its predecessor while its key is SMALLER;
+ * ( axis, - ): while its key is GREATER.  (Stated as an algorithm so that NaN keys and ties have one outcome.)
+ * Scheme 2 (eight orders): k = sign bits of dir ( x | y << 1 | z << 2 ); every container sorts on ITS axis — the one on
+ * which its children's keys spread furthest (max - min; x before y before z on ties) — ascending if that sign bit is 0.
+ *
+ * Links of order k: hit( container ) = its first child in that order; next( child j ) = child j + 1, the last child's
+ * next = next( parent ); next( root ) = -1 (end).  A missed container and every leaf continue at next.
+ * links[( k * N + i ) * 2 + {0 hit, 1 miss}], first[k] = hit_k( root ). */
+int orc_walk_order_count( int scheme ) {
+	return ( scheme == 1 ) ? 6 : ( scheme == 2 ) ? 8 : 0;
+}
+
+static inline float nodeKey( const orc_bvh_node* n, int axis ) {
+	const float lo = ( axis == 0 ) ? n->bbMin.x : ( axis == 1 ) ? n->bbMin.y : n->bbMin.z;
+	const float hi = ( axis == 0 ) ? n->bbMax.x : ( axis == 1 ) ? n->bbMax.y : n->bbMax.z;
+	return lo + hi;
+}
+
+int orc_build_walk_orders( const orc_bvh_node* bvh, int numNodes, int scheme, int32_t* links, int32_t* first ) {
+	const int K = orc_walk_order_count( scheme );
+	const size_t N = (size_t) numNodes;
+
+	if( K == 0 || numNodes < 2 ) {
+		return -1;
+	}
+
+	int32_t* end = (int32_t*) malloc( sizeof( int32_t ) * N );
+	int32_t* stack = (int32_t*) malloc( sizeof( int32_t ) * N );
+	int32_t* kids = (int32_t*) malloc( sizeof( int32_t ) * N );
+	int32_t* sorted = (int32_t*) malloc( sizeof( int32_t ) * N );
+	int32_t* rootNext = (int32_t*) malloc( sizeof( int32_t ) * (size_t) K );
+	int top = 0;
+
+	/* end( i ): one pass with the open containers on a stack */
+	for( int i = 0; i < numNodes; i++ ) {
+		while( top > 0 && i >= end[stack[top - 1]] ) {
+			top--;
+		}
+
+		if( bvh[i].bbMin.w >= 0.0f ) {
+			end[i] = i + 1;
+		}
+		else {
+			const int link = (int) bvh[i].bbMax.w;
+			end[i] = ( link > i ) ? link : ( ( top > 0 ) ? end[stack[top - 1]] : numNodes );
+			stack[top++] = i;
+		}
+	}
+
+	for( int k = 0; k < K; k++ ) {
+		rootNext[k] = -1;
+	}
+
+	for( int i = 0; i < numNodes; i++ ) {
+		if( bvh[i].bbMin.w >= 0.0f ) {
+			for( int k = 0; k < K; k++ ) {
+				int32_t* L = links + ( (size_t) k * N + (size_t) i ) * 2;
+				L[0] = L[1];   /* a leaf continues at next whether it is hit or not; next was written by its parent */
+			}
+			continue;
+		}
+
+		int n = 0;
+
+		for( int c = i + 1; c < end[i]; c = end[c] ) {
+			kids[n++] = c;
+		}
+
+		/* scheme 2: the axis on which the children's keys spread furthest */
+		int ownAxis = 0;
+
+		if( scheme == 2 ) {
+			float best = -1.0f;
+
+			for( int a = 0; a < 3; a++ ) {
+				float lo = ORC_INF, hi = -ORC_INF;
+
+				for( int j = 0; j < n; j++ ) {
+					const float key = nodeKey( &bvh[kids[j]], a );
+					lo = ( key < lo ) ? key : lo;
+					hi = ( key > hi ) ? key : hi;
+				}
+
+				const float spread = hi - lo;
+
+				if( spread > best ) {
+					best = spread;
+					ownAxis = a;
+				}
+			}
+		}
+
+		for( int k = 0; k < K; k++ ) {
+			const int axis = ( scheme == 1 ) ? ( k >> 1 ) : ownAxis;
+			const int descending = ( scheme == 1 ) ? ( k & 1 ) : ( ( k >> ownAxis ) & 1 );
+
+			for( int j = 0; j < n; j++ ) {
+				const float key = nodeKey( &bvh[kids[j]], axis );
+				int at = j;
+
+				while( at > 0 ) {
+					const float prev = nodeKey( &bvh[sorted[at - 1]], axis );
+
+					if( !( descending ? ( key > prev ) : ( key < prev ) ) ) {
+						break;
+					}
+
+					sorted[at] = sorted[at - 1];
+					at--;
+				}
+
+				sorted[at] = kids[j];
+			}
+
+			int32_t* L = links + ( (size_t) k * N + (size_t) i ) * 2;
+			const int32_t next = ( i == 0 ) ? rootNext[k] : L[1];
+
+			L[0] = ( n > 0 ) ? sorted[0] : next;
+			L[1] = next;
+
+			for( int j = 0; j < n; j++ ) {
+				links[( (size_t) k * N + (size_t) sorted[j] ) * 2 + 1] = ( j + 1 < n ) ? sorted[j + 1] : next;
+			}
+
+			if( i == 0 ) {
+				first[k] = L[0];
+			}
+		}
+	}
+
+	free( end ); free( stack ); free( kids ); free( sorted ); free( rootNext );
+	return 0;
+}
+
+static inline int walkOrderOf( int scheme, v3 d ) {
+	if( scheme == 2 ) {
+		return ( d.x < 0.0f ) | ( ( d.y < 0.0f ) << 1 ) | ( ( d.z < 0.0f ) << 2 );
+	}
+
+	const float ax = fabsf( d.x ), ay = fabsf( d.y ), az = fabsf( d.z );
+	const int axis = ( ax >= ay && ax >= az ) ? 0 : ( ( ay >= az ) ? 1 : 2 );
+	const float along = ( axis == 0 ) ? d.x : ( axis == 1 ) ? d.y : d.z;
+	return 2 * axis + ( along < 0.0f );
+}
+
+/* Analysis aid: the longest single walk (node visits) seen since it was set; NULL = off. */
+static uint32_t* g_walk_max = 0;
+void orc_debug_set_walk_max( uint32_t* slot ) { g_walk_max = slot; }
+
+static inline void noteWalk( uint32_t visits ) {
+	if( g_walk_max ) {
+		uint32_t seen = __atomic_load_n( g_walk_max, __ATOMIC_RELAXED );
+
+		while( visits > seen && !__atomic_compare_exchange_n( g_walk_max, &seen, visits, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED ) ) {
+		}
+	}
+}
+
+/* traverse (pt_bvh.cl:82-123) with the successors of the ray's order: per visit the reference's statements */
+static void traverseOrdered( ctx_t* c, ray4* ray ) {
+	const v3 invDir = V3( det_rcp( ray->dir.x ), det_rcp( ray->dir.y ), det_rcp( ray->dir.z ) );
+	const size_t N = (size_t) c->cfg->num_nodes;
+	const int k = walkOrderOf( c->cfg->traversal, ray->dir );
+	const int32_t* L = c->scene->walk_links + (size_t) k * N * 2;
+	int index = c->scene->walk_first[k];
+	uint32_t visits = 0;
+
+	traverseLights( c, ray );
+
+	while( index > 0 ) {
+		c->dbg_nodes += 1.0f;
+		visits++;
+		if( g_node_hist ) {
+			__atomic_fetch_add( &g_node_hist[(size_t) k * N + (size_t) index], 1u, __ATOMIC_RELAXED );
+		}
+		const orc_bvh_node node = c->scene->bvh[index];
+		const int currentIndex = index;
+
+		index = L[2 * currentIndex + 1];
+
+		float tNear = 0.0f;
+		float tFar = ORC_INF;
+
+		const int isNodeHit = (
+			intersectBox( ray, &invDir, node.bbMin, node.bbMax, &tNear, &tFar ) &&
+			tFar > EPSILON5 && ray->t > tNear
+		);
+
+		if( !isNodeHit ) {
+			continue;
+		}
+
+		index = L[2 * currentIndex];
+
+		if( node.bbMin.w >= 0.0f ) {
+			intersectFaces( c, ray, &node, tNear, tFar );
+		}
+	}
+
+	noteWalk( visits );
+}
+
+/* traverseShadows (pt_bvh.cl:133-177) likewise */
+static void traverseShadowsOrdered( ctx_t* c, ray4* ray ) {
+	const float tLight = ray->t;
+	const v3 invDir = V3( det_rcp( ray->dir.x ), det_rcp( ray->dir.y ), det_rcp( ray->dir.z ) );
+	const size_t N = (size_t) c->cfg->num_nodes;
+	const int k = walkOrderOf( c->cfg->traversal, ray->dir );
+	const int32_t* L = c->scene->walk_links + (size_t) k * N * 2;
+	int index = c->scene->walk_first[k];
+
+	traverseLights( c, ray );
+
+	while( index > 0 ) {
+		const orc_bvh_node node = c->scene->bvh[index];
+		const int currentIndex = index;
+
+		index = L[2 * currentIndex + 1];
+
+		float tNear = 0.0f;
+		float tFar = ORC_INF;
+
+		const int isNodeHit = (
+			intersectBox( ray, &invDir, node.bbMin, node.bbMax, &tNear, &tFar ) &&
+			tFar > EPSILON5
+		);
+
+		if( !isNodeHit ) {
+			continue;
+		}
+
+		index = L[2 * currentIndex];
+
+		if( node.bbMin.w >= 0.0f ) {
+			intersectFaces( c, ray, &node, tNear, tFar );
+
+			if( ray->t < tLight ) {
+				break;
+			}
+		}
+	}
 }
 
 

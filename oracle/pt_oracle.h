@@ -77,6 +77,9 @@ typedef struct {
 	float anti_aliasing;        /* ANTI_ALIASING */
 	float sky_light[4];         /* SKY_LIGHT */
 	float phong_tessellation;   /* PHONGTESS_ALPHA; PHONGTESS = ( > 0 ) as CL::setValues derives it (CL.cpp:651) */
+	int32_t traversal;          /* NOT a reference constant.  0: the reference's walk (pt_bvh.cl:82-123).  1 / 2: the product's
+	                             * opt-in ray-ordered walk over the same flat tree, six / eight orders (pt_oracle.c, "Ray-ordered
+	                             * walk"); needs scene.walk_links / walk_first */
 } orc_config;
 
 typedef struct {
@@ -89,6 +92,8 @@ typedef struct {
 	const orc_uint4* facesN;    /* normal indices per face; only read when cfg.phong_tessellation > 0 */
 	const orc_float4* normals;
 	uint32_t num_normals;
+	const int32_t* walk_links;  /* cfg.traversal != 0 only: orc_build_walk_orders' successor table, K x num_nodes x {hit, miss} */
+	const int32_t* walk_first;  /* ... and the K first nodes */
 } orc_scene;
 
 /* Traversal counters summed over the rendered pixels:
@@ -110,6 +115,16 @@ void orc_render_frame(
 void orc_trace_rays(
 	const orc_scene* scene, const orc_config* cfg, const float* rays, int n,
 	float* out_t, int32_t* out_face, float* out_normal, uint32_t* out_counts );
+
+/* The product's opt-in ray-ordered walk (NOT the reference's algorithm — the reference has one fixed order): successor
+ * tables over the reference's flat node array.  scheme 1: six orders (dominant axis x sign), 2: eight (sign octant, each
+ * container sorted on its own axis).  links: orc_walk_order_count( scheme ) x numNodes x 2 int32, first: one per order.
+ * Returns 0, or -1 for an unknown scheme. */
+int orc_walk_order_count( int scheme );
+int orc_build_walk_orders( const orc_bvh_node* bvh, int numNodes, int scheme, int32_t* links, int32_t* first );
+
+/* Analysis aids (not part of any parity claim): longest single closest-hit walk in node visits. */
+void orc_debug_set_walk_max( uint32_t* slot );
 
 /* Deterministic math layer, elementwise over n values (for ULP tests).
  * op: 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 pow(x,y), 6 rand-hash fract(sin(x)*43758.5453123) */

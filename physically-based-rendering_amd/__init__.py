@@ -62,6 +62,7 @@ class Config(ctypes.Structure):
         ("shadow_rays", ctypes.c_uint32), ("max_depth", ctypes.c_uint32), ("max_added_depth", ctypes.c_uint32),
         ("samples", ctypes.c_uint32), ("anti_aliasing", ctypes.c_float), ("phong_tessellation", ctypes.c_float),
         ("sky_light", ctypes.c_float * 4), ("tile_world", ctypes.c_uint32), ("tile_rank", ctypes.c_uint32),
+        ("traversal", ctypes.c_uint32), ("arith", ctypes.c_uint32),
     ]
 
 

@@ -82,6 +82,14 @@ struct pbr_ctx {
 	float4* dLights = nullptr;
 	uint32_t numHotAvail = 0;      // records at the head of the node stream that are ranked for LDS staging
 	int firstRef = 0;              // record of node 1
+	// ray-ordered walk (pbr_config.traversal != 0): one stream of records per order, built on first use from a host copy of the flat tree
+	std::vector<pbr_bvh_node> hostNodes;
+	std::vector<int> hostFace0s, hostLinks;   // per node: first face or -1; second face / miss link (checkScene)
+	std::vector<uint32_t> hostRanked;         // the nodes ranked for LDS staging, most visited first
+	float4* dNodesWalk = nullptr;
+	uint32_t walkBuilt = 0;        // the scheme dNodesWalk holds (0: none)
+	uint32_t walkHotAvail = 0;     // records at the head of dNodesWalk that are ranked for LDS staging (all orders interleaved)
+	int walkFirst[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	uint32_t numNodes = 0, numFaces = 0, numMaterials = 0, numLights = 0;
 	uint32_t sceneBrdf = 1;
 
@@ -156,6 +164,9 @@ int fail( pbr_ctx* ctx, int code, const char* fmt, ... ) {
 
 void freeScene( pbr_ctx* ctx ) {
 	(void) hipFree( ctx->dNodes );
+	(void) hipFree( ctx->dNodesWalk );
+	ctx->dNodesWalk = nullptr;
+	ctx->walkBuilt = 0;
 #ifdef PBR_LAB
 	(void) hipFree( ctx->dNodesPair );
 	ctx->dNodesPair = nullptr;
@@ -382,6 +393,240 @@ void invariantDivisor( unsigned d, unsigned out[2] ) {
 }
 
 // The schedule tuner's chunk lengths are in 1080p-frame equivalents (launch()): how many of this context's frames make one.
+// ---- the ray-ordered walk's node streams (pbr_config.traversal, include/pbr_hip.h) --------------------------------
+// Not a reference structure: the reference walks its flat tree in one fixed order (a hit continues at index + 1,
+// pt_bvh.cl:102,112; the child with the bigger surface area sits there, accelstructures/BVH.cpp:335-343).  The records of
+// the node stream name their successors explicitly (pt_kernel.hpp, decodeNode), so another visiting order is another set
+// of successor words over the same boxes and leaf words — the kernels do not change, a walk only starts somewhere else.
+//
+// The tree behind the flat array: a leaf ends at index + 1, a container i at its miss link when that is > i, else where
+// its parent ends (the root: N); its children are c0 = i + 1, c1 = end( c0 ), ... below end( i ) — the flattening drops
+// nodes (PathTracer.cpp:250-256), so there can be more than two.
+// A child's key on an axis: bbMin[axis] + bbMax[axis] (binary32).  A container's children in an order = the DFS child
+// list insertion-sorted — a child moves in front of its predecessor while its key is smaller (ascending) / greater
+// (descending); as an algorithm, so that ties and NaN keys have one outcome.
+//   scheme 1, six orders   order 2 * a + neg sorts EVERY container on axis a, descending when neg; a ray takes the order of
+//                          its direction's dominant axis and that component's sign (walkOrderOf, pt_kernel.hpp)
+//   scheme 2, eight orders order k = sign bits of the direction; a container sorts on ITS axis — the one its children's keys
+//                          spread furthest on (max - min, x before y before z on ties) — descending when that bit of k is set
+// Successors in an order: a hit container continues at its first child; child j's next is child j + 1, the last child's
+// is its parent's next, the root's is "end"; a missed container and every leaf continue at next.
+//
+// Layout: [ the ranked nodes, rank by rank, all orders of a rank next to each other (any prefix a block stages in LDS
+// serves every order alike) ][ order 0's other nodes in that order's depth-first sequence ][ order 1's ] ...
+int buildWalkStreams( pbr_ctx* ctx, uint32_t scheme ) {
+	const int K = ( scheme == 1 ) ? 6 : 8;
+	const uint32_t N = ctx->numNodes;
+	const std::vector<pbr_bvh_node>& bvh = ctx->hostNodes;
+	const std::vector<int>& face0s = ctx->hostFace0s;
+
+	if( bvh.size() != N || N < 2 ) {
+		return fail( ctx, PBR_ESTATE, "ray-ordered walk: no host copy of the scene's tree" );
+	}
+	if( (size_t) K * N * 32 >= ( (size_t) 1 << 31 ) ) {
+		return fail( ctx, PBR_EINVAL, "ray-ordered walk: %d streams of %u records exceed 2 GiB (record references are 31-bit byte offsets)", K, N );
+	}
+
+	// where every subtree ends
+	std::vector<uint32_t> end( N );
+	{
+		std::vector<uint32_t> open;
+
+		for( uint32_t i = 0; i < N; i++ ) {
+			while( !open.empty() && i >= end[open.back()] ) {
+				open.pop_back();
+			}
+
+			if( face0s[i] >= 0 ) {
+				end[i] = i + 1;
+			}
+			else {
+				end[i] = ( ctx->hostLinks[i] > (int) i ) ? (uint32_t) ctx->hostLinks[i] : ( open.empty() ? N : end[open.back()] );
+				open.push_back( i );
+			}
+		}
+	}
+
+	auto key = [&]( uint32_t node, int axis ) {
+		const pbr_bvh_node& n = bvh[node];
+		return ( axis == 0 ) ? n.bbMin.x + n.bbMax.x : ( axis == 1 ) ? n.bbMin.y + n.bbMax.y : n.bbMin.z + n.bbMax.z;
+	};
+
+	// per order and node: the node to go to when it is a hit container, and the node to go to otherwise (-1: end)
+	std::vector<int> onHit( (size_t) K * N, -1 ), onNext( (size_t) K * N, -1 );
+	std::vector<uint32_t> children, inOrder;
+
+	for( uint32_t i = 0; i < N; i++ ) {
+		if( face0s[i] >= 0 ) {
+			continue;
+		}
+
+		children.clear();
+
+		for( uint32_t c = i + 1; c < end[i]; c = end[c] ) {
+			children.push_back( c );
+		}
+
+		int ownAxis = 0;
+
+		if( scheme == 2 ) {
+			float widest = -1.0f;
+
+			for( int axis = 0; axis < 3; axis++ ) {
+				float lo = INFINITY, hi = -INFINITY;
+
+				for( uint32_t c : children ) {
+					const float k = key( c, axis );
+					lo = ( k < lo ) ? k : lo;
+					hi = ( k > hi ) ? k : hi;
+				}
+
+				if( hi - lo > widest ) {
+					widest = hi - lo;
+					ownAxis = axis;
+				}
+			}
+		}
+
+		for( int k = 0; k < K; k++ ) {
+			const int axis = ( scheme == 1 ) ? k / 2 : ownAxis;
+			const bool descending = ( scheme == 1 ) ? ( k & 1 ) != 0 : ( ( k >> ownAxis ) & 1 ) != 0;
+			inOrder.clear();
+
+			for( uint32_t c : children ) {
+				const float mine = key( c, axis );
+				size_t at = inOrder.size();
+				inOrder.push_back( c );
+
+				while( at > 0 ) {
+					const float before = key( inOrder[at - 1], axis );
+
+					if( !( descending ? ( mine > before ) : ( mine < before ) ) ) {
+						break;
+					}
+
+					inOrder[at] = inOrder[at - 1];
+					at--;
+				}
+
+				inOrder[at] = c;
+			}
+
+			const size_t base = (size_t) k * N;
+			const int next = ( i == 0 ) ? -1 : onNext[base + i];   // written when i's parent was handled (parents come first)
+			onHit[base + i] = inOrder.empty() ? next : (int) inOrder[0];
+
+			for( size_t j = 0; j < inOrder.size(); j++ ) {
+				onNext[base + inOrder[j]] = ( j + 1 < inOrder.size() ) ? (int) inOrder[j + 1] : next;
+			}
+		}
+	}
+
+	// records: the ranked nodes interleaved, then every order's remaining nodes along its own depth-first sequence
+	const uint32_t maxHot = ( 160 * 1024 - 256 ) / 32;
+	const uint32_t hotPerOrder = (uint32_t) std::min<size_t>( ctx->hostRanked.size(), maxHot / (uint32_t) K );
+	std::vector<int> recordOf( (size_t) K * N, -1 );
+	size_t nextRecord = 0;
+
+	for( uint32_t r = 0; r < hotPerOrder; r++ ) {
+		for( int k = 0; k < K; k++ ) {
+			recordOf[(size_t) k * N + ctx->hostRanked[r]] = (int) nextRecord++;
+		}
+	}
+
+	for( int k = 0; k < K; k++ ) {
+		const size_t base = (size_t) k * N;
+		size_t seen = 0;
+
+		for( int node = onHit[base]; node > 0; node = ( face0s[node] < 0 ) ? onHit[base + node] : onNext[base + node] ) {
+			if( ++seen >= N ) {
+				return fail( ctx, PBR_ESTATE, "ray-ordered walk: order %d does not visit every node once", k );
+			}
+			if( recordOf[base + node] < 0 ) {
+				recordOf[base + node] = (int) nextRecord++;
+			}
+		}
+
+		if( seen != N - 1 ) {
+			return fail( ctx, PBR_ESTATE, "ray-ordered walk: order %d reaches %zu of %u nodes", k, seen, N - 1 );
+		}
+	}
+
+	// 32 bytes of header — the eight first references, where firstNode() reads them — then the records; the last one is
+	// padding, as in the reference-order stream
+	const size_t numRecords = nextRecord + 1;
+	std::vector<float4> storage( ( numRecords + 1 ) * 2, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );
+	float4* const nodes = storage.data() + 2;
+
+	for( int k = 0; k < K; k++ ) {
+		const size_t base = (size_t) k * N;
+		auto refOf = [&]( int node ) { return ( node > 0 ) ? recordOf[base + (size_t) node] * 32 : -1; };
+
+		for( uint32_t i = 1; i < N; i++ ) {
+			const pbr_bvh_node& n = bvh[i];
+			int w0, w1;
+
+			if( face0s[i] < 0 ) {
+				w0 = refOf( onHit[base + i] );
+				w1 = refOf( onNext[base + i] );
+			}
+			else {
+				w0 = (int) ( 0x80000000u | ( ( ctx->hostLinks[i] >= 0 ) ? 0x40000000u : 0u ) | (uint32_t) face0s[i] );
+				w1 = refOf( onNext[base + i] );
+			}
+
+			const size_t r = (size_t) recordOf[base + i];
+			nodes[r * 2 + 0] = make_float4( n.bbMin.x, n.bbMin.y, n.bbMax.x, n.bbMax.y );
+			nodes[r * 2 + 1] = make_float4( n.bbMin.z, n.bbMax.z, __builtin_bit_cast( float, w0 ), __builtin_bit_cast( float, w1 ) );
+		}
+
+		ctx->walkFirst[k] = refOf( onHit[base] );
+	}
+
+	for( int k = K; k < 8; k++ ) {
+		ctx->walkFirst[k] = ctx->walkFirst[0];
+	}
+
+	std::memcpy( storage.data(), ctx->walkFirst, sizeof( ctx->walkFirst ) );
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	(void) hipFree( ctx->dNodesWalk );
+	ctx->dNodesWalk = nullptr;
+	ctx->walkBuilt = 0;
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dNodesWalk, sizeof( float4 ) * storage.size() ) );
+	HIP_TRY( ctx, hipMemcpy( ctx->dNodesWalk, storage.data(), sizeof( float4 ) * storage.size(), hipMemcpyHostToDevice ) );
+	ctx->walkHotAvail = hotPerOrder * (uint32_t) K;
+	ctx->walkBuilt = scheme;
+	return PBR_OK;
+}
+
+// The node stream, its ranked prefix and the first record(s) for the configured traversal.
+int applyWalk( pbr_ctx* ctx, DevParams* P, uint32_t* hotAvail ) {
+	const uint32_t scheme = ctx->configured ? ctx->cfg.traversal : 0u;
+	P->nodes = ctx->dNodes;
+	P->firstRef = ctx->firstRef;
+	P->walkScheme = 0;
+	*hotAvail = ctx->numHotAvail;
+
+	if( scheme == 0 ) {
+		return PBR_OK;
+	}
+
+	if( ctx->walkBuilt != scheme ) {
+		const int built = buildWalkStreams( ctx, scheme );
+
+		if( built != PBR_OK ) {
+			return built;
+		}
+	}
+
+	P->nodes = ctx->dNodesWalk + 2;   // behind the 32-byte header
+	P->firstRef = ctx->walkFirst[0];
+	P->walkScheme = (int) scheme;
+	*hotAvail = ctx->walkHotAvail;
+	return PBR_OK;
+}
+
 uint32_t tuneScaleOf( size_t localPixels ) {
 	const size_t reference = (size_t) 1920 * 1080;
 	const size_t scale = ( reference + localPixels / 2 ) / std::max<size_t>( localPixels, 1 );
@@ -447,8 +692,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	DevParams P;
 	std::memset( &P, 0, sizeof( P ) );
 	P.parkEighths = 4;
-	P.nodes = ctx->dNodes;
-	P.firstRef = ctx->firstRef;
+	uint32_t hotAvail = 0;
+	{
+		const int walk = applyWalk( ctx, &P, &hotAvail );   // P.nodes, P.firstRef / walkFirst for the configured traversal
+
+		if( walk != PBR_OK ) {
+			return walk;
+		}
+	}
 	P.tris = ctx->dTris;
 	P.triPN = ctx->dTriPN;
 	P.faceN = ctx->dFaceN;
@@ -560,7 +811,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 #endif
 		(void) async;
 		size_t slots = ( share - slotBytes ) / 32;
-		slots = std::min<size_t>( slots, ctx->numHotAvail );
+		slots = std::min<size_t>( slots, hotAvail );
 
 		if( knobs.ldsSlots >= 0 ) {
 			slots = std::min<size_t>( slots, (size_t) knobs.ldsSlots );
@@ -606,7 +857,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.numHotBytes = plan.numHot * 32;
 		P.slotBase = plan.numHot * 32;
 #ifdef PBR_LAB
-		P.nodes = ( plan.pair && ctx->dNodesPair != nullptr ) ? ctx->dNodesPair : ctx->dNodes;
+		P.nodes = ( plan.pair && ctx->dNodesPair != nullptr ) ? ctx->dNodesPair : P.nodes;
 		// measured (profiles/r04/experiments/async_node_phase.txt): the share of the walking lanes an iteration waits for
 		P.asyncEighths = ( knobs.asyncEighths >= 1 ) ? std::min( 8, knobs.asyncEighths ) : 6;
 
@@ -1409,6 +1660,10 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 
 	ctx->numHotAvail = numHot;
 	ctx->firstRef = recordOf[1] * 32;
+	ctx->hostNodes.assign( s->bvh, s->bvh + N );
+	ctx->hostFace0s.swap( face0s );
+	ctx->hostLinks.swap( links );
+	ctx->hostRanked.assign( ranked.begin(), ranked.begin() + numHot );
 	ctx->numNodes = s->num_nodes;
 	ctx->numFaces = s->num_faces;
 	ctx->numMaterials = s->num_materials;
@@ -1439,6 +1694,12 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	}
 	if( cfg->phong_tessellation > 0.0f && ctx->hasScene && ctx->dTriPN == nullptr ) {
 		return fail( ctx, PBR_EINVAL, "Phong tessellation needs vertex normals: the uploaded scene's facesN / normals are missing or out of range" );
+	}
+	if( cfg->traversal > 2 || cfg->arith > 1 ) {
+		return fail( ctx, PBR_EINVAL, "traversal must be 0 (the reference's walk), 1 (six orders) or 2 (eight orders); arith 0 (exact) or 1 (native)" );
+	}
+	if( cfg->arith != 0 ) {
+		return fail( ctx, PBR_EINVAL, "arith = native is not built yet" );
 	}
 	if( cfg->tile_world == 0 || cfg->tile_rank >= cfg->tile_world ) {
 		return fail( ctx, PBR_EINVAL, "tile_rank must be < tile_world, tile_world >= 1" );

@@ -137,7 +137,11 @@ struct DevParams {
 	int numNodes, numLights, maxDepth, maxAddedDepth, samples;
 	int numHot;             // records [0, numHot) of the node stream are resident in LDS
 	int numHotBytes;        // = numHot * 32: a record reference (byte offset) below this is resident
-	int firstRef;           // reference (byte offset) of node 1's record, where every walk starts
+	int firstRef;           // reference (byte offset) of node 1's record, where every walk starts (walkScheme 0)
+	int walkScheme;         // pbr_config.traversal: 0 the reference's one order; 1 six orders (dominant axis x sign of the ray direction),
+	                        // 2 eight (sign octant): `nodes` then holds one stream of records per order and a walk starts at walkFirst[order]
+	                        // — the eight references sit in the 32 bytes IN FRONT of `nodes` (as kernel arguments they were
+	                        // eight more live registers in every kernel: scalar values the compiler keeps in vector registers)
 	int slotBase;           // LDS byte address of the per-lane state behind the staged prefix (= numHotBytes): pathTracingDual's path slots
 #ifdef PBR_LAB             // round-4 lab variants (lab/src/pt_r04_*.hpp)
 	int asyncEighths;       // nodePhaseAsync: the share of the walking lanes (in eighths) that must be ready before an iteration starts
@@ -818,10 +822,29 @@ PT_DEV NodeLinks decodeNode( const float4 n1 ) {
 	return n;
 }
 
-PT_DEV Cursor firstNode( const DevParams& P ) {
-	// the walk starts at node 1 (pt_bvh.cl:84)
+// Which of the successor sets a ray walks (pbr_config.traversal; the statement both ends follow is in pbr_upload's
+// buildWalkStreams and in the oracle's "Ray-ordered walk").  Scheme 1: 2 * dominant axis (x before y before z on ties)
+// + ( dir[axis] < 0 ).  Scheme 2: the sign bits x | y << 1 | z << 2.
+PT_DEV int walkOrderOf( int scheme, const f3 d ) {
+	if( scheme == 2 ) {
+		return ( ( d.x < 0.0f ) ? 1 : 0 ) | ( ( d.y < 0.0f ) ? 2 : 0 ) | ( ( d.z < 0.0f ) ? 4 : 0 );
+	}
+
+	const float ax = __builtin_fabsf( d.x ), ay = __builtin_fabsf( d.y ), az = __builtin_fabsf( d.z );
+	const int axis = ( ax >= ay && ax >= az ) ? 0 : ( ( ay >= az ) ? 1 : 2 );
+	const float along = ( axis == 0 ) ? d.x : ( ( axis == 1 ) ? d.y : d.z );
+	return 2 * axis + ( ( along < 0.0f ) ? 1 : 0 );
+}
+
+PT_DEV Cursor firstNode( const DevParams& P, const f3 dir ) {
+	// the walk starts at node 1 (pt_bvh.cl:84) — or, with a ray-ordered walk, at the root's first child in the ray's order
 	Cursor c;
 	c.ref = P.firstRef;
+
+	if( P.walkScheme != 0 ) {   // wave-uniform: a kernel argument
+		c.ref = ( (const int*) P.nodes )[walkOrderOf( P.walkScheme, dir ) - 8];   // one 4-byte load per walk, an L1 hit
+	}
+
 	return c;
 }
 
@@ -995,7 +1018,7 @@ template<bool ANYHIT, bool LIGHTS, bool USE_LDS, bool PHONG = false, bool EAGER 
 PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
 	const f3 invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
 	const float tLight = hit.t;
-	Cursor cur = firstNode( P );
+	Cursor cur = firstNode( P, ray.dir );
 #ifdef PBR_GUARD_TRAV
 	const int numNodes = P.numNodes;
 	int guardSteps = 0;
@@ -2083,7 +2106,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 template<bool LIGHTS>
 PT_DEV int startWalk( const DevParams& P, const Ray& ray, WalkState& w ) {
 	w.invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
-	w.cur = firstNode( P );
+	w.cur = firstNode( P, ray.dir );
 	w.hit.t = inff();
 	w.hit.face = 0;
 	w.leafFace0 = -1;
