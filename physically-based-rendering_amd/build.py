@@ -111,19 +111,19 @@ HIP_FLAGS = [
 
 
 def hip_sources():
-    sources = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
+    sources = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp")) and os.path.isfile(os.path.join(CSRC, f))]
     return sources + [os.path.join(INCLUDE, f) for f in ("pbr_hip.h", "pbr_hip_diag.h")]
 
 
 def hip_digest():
     """What the product library is built from: sources + flags.  libpbrhip.so.srchash holds the digest of the build that is
     there; bench.py stamps profiles with it and refuses to price a run with counters of another build."""
-    return _digest(hip_sources(), " ".join(HIP_FLAGS))
+    return _digest(hip_sources(), " ".join(HIP_FLAGS + NATIVE_FLAGS))
 
 
 def build_hip(force=False, guard=False):
     sources = hip_sources()
-    flags = " ".join(HIP_FLAGS)
+    flags = " ".join(HIP_FLAGS + NATIVE_FLAGS)
     target = HIP_GUARD_LIB if guard else HIP_LIB
     if not force and (not _stale(target, sources, flags) or _keep_prebuilt(target, "hipcc")):
         return target
@@ -133,20 +133,60 @@ def build_hip(force=False, guard=False):
         return _build_hip_locked(target, sources, guard)
 
 
+# The path-tracing kernels are compiled as one translation unit per (flavour, group) — csrc/pt_instance.hip with
+# -DPT_FLAVOUR=f -DPT_GROUP=g, see csrc/pt_instances.hpp / pt_flavour.hpp — next to csrc/pbr_hip.hip (the C ABI, the
+# host side of the launches and every other kernel), in parallel, and linked into one shared library.
+#   flavour bit 0: ray-ordered walk (pbr_config.traversal)     bit 1: native arithmetic (pbr_config.arith)
+#   groups 0-2 pathTracing<.., 4 | 6 | 8>, 3 its Phong-tessellation build (flavour 0 only), 4-6 pathTracingPhased<.., 4 | 6 | 8>,
+#   7 pathTracingDual (not in PBR_GUARD builds: it has no C++ node phase)
+FLAVOURS = (0, 1, 2, 3)
+GROUPS = (0, 1, 2, 3, 4, 5, 6, 7)
+# what native arithmetic means to the compiler: `/` and sqrtf() become v_rcp_f32 / v_sqrt_f32 sequences without the
+# correction steps (the reference asks for native_divide / native_recip / native_sqrt); everything else is in pt_math.hpp
+NATIVE_FLAGS = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+
+
+def instance_units(guard):
+    units = []
+    for f in FLAVOURS:
+        for g in GROUPS:
+            if g == 3 and f != 0:
+                continue                 # Phong tessellation: reference walk + exact arithmetic only
+            if g == 7 and guard:
+                continue
+            units.append((f, g))
+    return units
+
+
+def hip_commands(target, guard=False, objdir=None):
+    """The compile commands (one per translation unit) and the link command of libpbrhip*.so."""
+    objdir = objdir or (target + ".obj")
+    common = [_hipcc(), *HIP_FLAGS, "-fPIC", "-I", INCLUDE, "-I", CSRC, *(["-DPBR_GUARD=1"] if guard else [])]
+    objects = [os.path.join(objdir, "pbr_hip.o")]
+    compiles = [common + ["-c", os.path.join(CSRC, "pbr_hip.hip"), "-o", objects[0]]]
+    for f, g in instance_units(guard):
+        obj = os.path.join(objdir, "inst_f%d_g%d.o" % (f, g))
+        objects.append(obj)
+        compiles.append(common + (NATIVE_FLAGS if f & 2 else []) + ["-DPT_FLAVOUR=%d" % f, "-DPT_GROUP=%d" % g, "-c", os.path.join(CSRC, "pt_instance.hip"), "-o", obj])
+    link = [_hipcc(), "--offload-arch=gfx950:xnack-", "-shared", "-fPIC", *objects, "-o"]
+    return compiles, link, objdir
+
+
 def _build_hip_locked(target, sources, guard):
+    from concurrent.futures import ThreadPoolExecutor
     tmp = "%s.%d.tmp" % (target, os.getpid())
-    cmd = [
-        _hipcc(), *HIP_FLAGS,
-        "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC, *(["-DPBR_GUARD=1"] if guard else []),
-        "-o", tmp, os.path.join(CSRC, "pbr_hip.hip"),
-    ]
+    compiles, link, objdir = hip_commands(target, guard, objdir="%s.obj.%d" % (target, os.getpid()))
+    os.makedirs(objdir, exist_ok=True)
     try:
-        _run(cmd)
+        with ThreadPoolExecutor(max_workers=max(1, min(len(compiles), os.cpu_count() or 4))) as pool:
+            list(pool.map(_run, compiles))
+        _run(link + [tmp])
         os.replace(tmp, target)         # a process that has the old file mapped keeps the old inode
     finally:
+        shutil.rmtree(objdir, ignore_errors=True)
         if os.path.exists(tmp):
             os.remove(tmp)
-    _stamp(target, sources, " ".join(HIP_FLAGS))
+    _stamp(target, sources, " ".join(HIP_FLAGS + NATIVE_FLAGS))
     return target
 
 

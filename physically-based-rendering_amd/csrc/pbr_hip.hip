@@ -14,7 +14,8 @@
 
 #include "pbr_hip.h"
 #include "pbr_hip_diag.h"
-#include "pt_kernel.hpp"
+#include "pt_aux.hpp"
+#include "pt_instances.hpp"
 // The schedules that were measured and rejected in rounds 1 - 2 (tile, batched, wavefront, pooled: DESIGN.md 5.1b / 5.1d)
 // are no longer part of this source; their kernels are kept for the record under lab/src/.
 #include "bvh_build.hpp"
@@ -23,9 +24,6 @@
 using ptk::DevParams;
 
 typedef void ( *KernelFn )( const ptk::DevParams );
-#ifdef PBR_LAB
-typedef void ( *KernelFn2 )( const ptk::DevParams, const float4*, unsigned, float2* );   // lab probe kernels
-#endif
 
 // A plan = kernel + persistent grid + LDS split (launch()).  Built once per scene + configuration and kept in the
 // context: six occupancy queries and six function-attribute calls are host time a frame-by-frame caller would pay
@@ -33,10 +31,6 @@ typedef void ( *KernelFn2 )( const ptk::DevParams, const float4*, unsigned, floa
 struct Plan {
 	KernelFn kernel = nullptr;
 	int blocks = 0, blockThreads = 0, numHot = 0, park = 0, shade = 0, parkEighths = 4;
-#ifdef PBR_LAB             // round-4 lab variants (lab/src/pt_r04_*.hpp)
-	bool async = false;     // the node phase polls per-lane LDS slots filled by LDS-DMA (nodePhaseAsync)
-	bool pair = false;      // the node phase fetches the adjacent record along: reads the flagged copy of the stream (nodePhasePair)
-#endif
 	size_t ldsBytes = 0;
 	const char* name = "";
 };
@@ -55,9 +49,6 @@ struct Knobs {
 	int bvhBuilder = -1;    // pbr_build_bvh: 1 = round 1's radix tree instead of the clustering builder
 	int plocRadius = -1;    // pbr_build_bvh: search radius of the clustering builder
 	int tuneLog = -1;       // 1 = the schedule tuner logs its launches to stderr
-#ifdef PBR_LAB
-	int asyncEighths = -1;  // lab, asynchronous node phase: eighths of the walking lanes that must be ready before an iteration starts
-#endif
 };
 
 struct pbr_ctx {
@@ -72,9 +63,6 @@ struct pbr_ctx {
 	// scene
 	bool hasScene = false;
 	float4* dNodes = nullptr;
-#ifdef PBR_LAB
-	float4* dNodesPair = nullptr;  // lab: the stream with `hit successor is the adjacent record` flags (nodePhasePair)
-#endif
 	float4* dTris = nullptr;
 	float4* dTriPN = nullptr;      // exact vertices + vertex normals per face (Phong tessellation); null if the normal indices are unusable
 	float4* dMats = nullptr;
@@ -167,10 +155,6 @@ void freeScene( pbr_ctx* ctx ) {
 	(void) hipFree( ctx->dNodesWalk );
 	ctx->dNodesWalk = nullptr;
 	ctx->walkBuilt = 0;
-#ifdef PBR_LAB
-	(void) hipFree( ctx->dNodesPair );
-	ctx->dNodesPair = nullptr;
-#endif
 	(void) hipFree( ctx->dTris );
 	(void) hipFree( ctx->dTriPN );
 	ctx->dTriPN = nullptr;
@@ -223,122 +207,35 @@ const size_t kFrameBufBytes = (size_t) 16 << 30;
 const size_t kCounterSlots = 16;
 
 
-// PBR_LAB (experiments only, scripts/lab.sh): instantiate just the variants the four bench scenes run,
-// so that an A/B build of the library takes seconds.  Never defined for the product build.
-template<int MINW, bool PHONG = false>
-KernelFn pickKernelMode( uint32_t brdf, bool shadow, bool lights ) {
-#ifdef PBR_LAB
-	(void) brdf; (void) shadow; (void) lights;
-	return ptk::pathTracing<1, false, false, MINW, PHONG>;
-#else
-	if( brdf == 0 ) {
-		if( lights ) {
-			return shadow ? ptk::pathTracing<0, true, true, MINW, PHONG> : ptk::pathTracing<0, false, true, MINW, PHONG>;
-		}
-		return ptk::pathTracing<0, false, false, MINW, PHONG>;
-	}
+// ---- the path-tracing kernels: one translation unit per plan and build flavour (pt_instances.hpp, pt_instance.hip) ----
+// A flavour is a build mode of the same kernel sources (pt_flavour.hpp): bit 0 the ray-ordered walk, bit 1 native
+// arithmetic.  A unit that was not linked in (PBR_GUARD builds have no two-paths-per-lane kernels; the Phong-tessellation
+// kernel exists in flavour 0 only) leaves its picker null.
+#define PTI_DECLARE( f, g ) extern "C" const void* PTI_NAME( f, g )( uint32_t, int, int ) __attribute__( ( weak ) );
+#define PTI_DECLARE_FLAVOUR( f ) \
+	PTI_DECLARE( f, 0 ) PTI_DECLARE( f, 1 ) PTI_DECLARE( f, 2 ) PTI_DECLARE( f, 3 ) PTI_DECLARE( f, 4 ) PTI_DECLARE( f, 5 ) PTI_DECLARE( f, 6 ) PTI_DECLARE( f, 7 )
+PTI_DECLARE_FLAVOUR( 0 )
+PTI_DECLARE_FLAVOUR( 1 )
+PTI_DECLARE_FLAVOUR( 2 )
+PTI_DECLARE_FLAVOUR( 3 )
+#define PTI_ROW( f ) { PTI_NAME( f, 0 ), PTI_NAME( f, 1 ), PTI_NAME( f, 2 ), PTI_NAME( f, 3 ), PTI_NAME( f, 4 ), PTI_NAME( f, 5 ), PTI_NAME( f, 6 ), PTI_NAME( f, 7 ) }
+const pti_picker kPickers[PTI_FLAVOURS][PTI_GROUPS] = { PTI_ROW( 0 ), PTI_ROW( 1 ), PTI_ROW( 2 ), PTI_ROW( 3 ) };
 
-	if( lights ) {
-		return shadow ? ptk::pathTracing<1, true, true, MINW, PHONG> : ptk::pathTracing<1, false, true, MINW, PHONG>;
-	}
-	return ptk::pathTracing<1, false, false, MINW, PHONG>;
-#endif
+KernelFn pickKernel( int flavour, int group, uint32_t brdf, bool shadow, bool lights ) {
+	const pti_picker pick = kPickers[flavour][group];
+	return ( pick != nullptr ) ? (KernelFn) pick( brdf, shadow ? 1 : 0, lights ? 1 : 0 ) : nullptr;
 }
 
-
-#ifndef PBR_LEAN_MINW
-#define PBR_LEAN_MINW 4
-#endif
-#ifndef PBR_WIDE_MINW
-#define PBR_WIDE_MINW 8
-#endif
-
-template<int MINW, int ASYNC = 0>
-KernelFn pickKernelPhasedMode( uint32_t brdf, bool shadow, bool lights ) {
-#ifdef PBR_LAB
-	(void) brdf; (void) shadow; (void) lights;
-	return ptk::pathTracingPhased<1, false, false, MINW, ASYNC>;
-#else
-	if( brdf == 0 ) {
-		if( lights ) {
-			return shadow ? ptk::pathTracingPhased<0, true, true, MINW, ASYNC> : ptk::pathTracingPhased<0, false, true, MINW, ASYNC>;
-		}
-		return ptk::pathTracingPhased<0, false, false, MINW, ASYNC>;
-	}
-
-	if( lights ) {
-		return shadow ? ptk::pathTracingPhased<1, true, true, MINW, ASYNC> : ptk::pathTracingPhased<1, false, true, MINW, ASYNC>;
-	}
-	return ptk::pathTracingPhased<1, false, false, MINW, ASYNC>;
-#endif
-}
-
-// Which node phase the two state-machine plans use: nodePhaseAsm (WALK_SYNC) in the product, always.
-// lab builds: -DPBR_ASYNC_LEAN / -DPBR_ASYNC_MID put the asynchronous node phase in the place of phased-lean / phased-mid
-// (-DPBR_PAIR_LEAN: the adjacent-record fetch in the place of phased-lean)
-#if defined( PBR_ASYNC_LEAN )
-const int kWalkLean = ptk::WALK_ASYNC;
-#elif defined( PBR_PAIR_LEAN )
-const int kWalkLean = ptk::WALK_PAIR;
-#else
-const int kWalkLean = ptk::WALK_SYNC;
-#endif
-#ifdef PBR_ASYNC_MID
-const int kWalkMid = ptk::WALK_ASYNC;
-#else
-const int kWalkMid = ptk::WALK_SYNC;
-#endif
-const bool kAsyncLean = ( kWalkLean == ptk::WALK_ASYNC ), kAsyncMid = ( kWalkMid == ptk::WALK_ASYNC );
-
-KernelFn pickKernelPhased( uint32_t brdf, bool shadow, bool lights, bool wide ) {
-#if defined( PBR_LAB ) && defined( PBR_DUAL_LEAN )
-	if( !wide ) {      // lab: two paths per lane in the place of phased-lean (pt_kernel.hpp, pathTracingDual)
-		(void) brdf; (void) shadow; (void) lights;
-		return ptk::r04lab::pathTracingDual<1, false, false>;
-	}
-#endif
-	return wide ? pickKernelPhasedMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelPhasedMode<PBR_LEAN_MINW, kWalkLean>( brdf, shadow, lights );
+// the flavour a configuration renders with
+int flavourOf( const pbr_config& cfg ) {
+	return ( ( cfg.traversal != 0 ) ? 1 : 0 ) | ( ( cfg.arith != 0 ) ? 2 : 0 );
 }
 
 // the "mid" budget: <= 80 VGPRs, launched as two 768-thread blocks per CU = 6 waves / SIMD
-#ifndef PBR_MID_WAVES   // lab builds only
-#define PBR_MID_WAVES 6
-#endif
-const int kMidMinWaves = PBR_MID_WAVES;
-#ifndef PBR_MID_THREADS   // lab builds only: other block shapes for the 6-waves kernels
-#define PBR_MID_THREADS 768
-#endif
-const int kMidBlockThreads = PBR_MID_THREADS;
-
-
-KernelFn pickKernelPhasedMid( uint32_t brdf, bool shadow, bool lights ) {
-	return pickKernelPhasedMode<kMidMinWaves, kWalkMid>( brdf, shadow, lights );
-}
-
-KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights );
+const int kMidBlockThreads = 768;
 
 // two paths per lane (pt_dual.hpp).  Its node phase is hand-scheduled only: builds without PT_NODE_PHASE_ASM (PBR_GUARD,
 // PBR_NODE_PHASE_CXX) render the plan with the 6-waves state machine — same bits, every loop bounded.
-KernelFn pickKernelDual( uint32_t brdf, bool shadow, bool lights ) {
-#if defined( PT_NODE_PHASE_ASM ) && !defined( PBR_LAB )
-	if( brdf == 0 ) {
-		if( lights ) {
-			return shadow ? ptk::pathTracingDual<0, true, true> : ptk::pathTracingDual<0, false, true>;
-		}
-		return ptk::pathTracingDual<0, false, false>;
-	}
-
-	if( lights ) {
-		return shadow ? ptk::pathTracingDual<1, true, true> : ptk::pathTracingDual<1, false, true>;
-	}
-	return ptk::pathTracingDual<1, false, false>;
-#elif defined( PT_NODE_PHASE_ASM )
-	(void) brdf; (void) shadow; (void) lights;      // lab builds: only the kernel variants the bench scenes run
-	return ptk::pathTracingDual<1, false, false>;
-#else
-	return pickKernelPhasedMid( brdf, shadow, lights );
-#endif
-}
 const bool kDualIsDual =
 #ifdef PT_NODE_PHASE_ASM
 	true;
@@ -356,26 +253,10 @@ const uint32_t kWideMinNodes = 2048;
 // 16 where the tree fits LDS and shading is most of a bounce, 32 where the walk is.
 const int kRefillBatchSmall = 16, kRefillBatchLarge = 32;
 
-
-KernelFn pickKernelMid( uint32_t brdf, bool shadow, bool lights ) {
-	return pickKernelMode<kMidMinWaves>( brdf, shadow, lights );
-}
-
 // PHONGTESS == 1: the lock-step kernel in the LEAN budget (round 4).  The long cubic solve spills in every budget — 336 B /
 // 272 B / 72 B of scratch per lane at 64 / 80 / 128 registers — and 4 waves with 8 spilled registers beat 8 waves with 208:
 // 4133 against 2731 Msamples/s on a 288-face sphere over a floor at 1080p, 2850 against 2015 on a 9 000-face one
 // (profiles/r04/experiments/phong_register_budget.txt; rounds 2-3 built it in the 64-register budget).
-#ifndef PBR_PHONG_MINW      // lab: other register budgets for the Phong-tessellation build
-#define PBR_PHONG_MINW PBR_LEAN_MINW
-#endif
-KernelFn pickKernelPhong( uint32_t brdf, bool shadow, bool lights ) {
-	return pickKernelMode<PBR_PHONG_MINW, true>( brdf, shadow, lights );
-}
-
-KernelFn pickKernel( uint32_t brdf, bool shadow, bool lights, bool refill, bool wide ) {
-	(void) refill;
-	return wide ? pickKernelMode<PBR_WIDE_MINW>( brdf, shadow, lights ) : pickKernelMode<PBR_LEAN_MINW>( brdf, shadow, lights );
-}
 
 
 // {magic, shifts} with which ptk::divInvariant divides any 32-bit n by d exactly (d = 0 is never divided by: as 1)
@@ -779,6 +660,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	const bool shadow = ( ctx->cfg.shadow_rays == 1 ) && lights;
 	const Knobs& knobs = ctx->knobs;
 	const bool phong = ( ctx->cfg.phong_tessellation > 0.0f );
+	const int flavour = flavourOf( ctx->cfg );
 
 	if( phong && ctx->dTriPN == nullptr ) {
 		return fail( ctx, PBR_EINVAL, "Phong tessellation needs a scene with usable vertex normals" );
@@ -789,7 +671,11 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// split between the blocks the register budget admits.  The experiment knobs (PBR_BLOCKS_PER_CU, PBR_LDS_SLOTS,
 	// PBR_PH_PARK, PBR_PH_SHADE, PBR_PARK_EIGHTHS, PBR_DRAIN_MODE) are read when the plans are built — once per
 	// scene + configuration — not per launch.
-	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK, bool async = false, size_t pathSlotBytes = 0 ) -> int {
+	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK, size_t pathSlotBytes = 0 ) -> int {
+		if( kernel == nullptr ) {
+			return fail( ctx, PBR_ESTATE, "plan %s: this library was built without that kernel (flavour %d)", name, flavour );
+		}
+
 		int blocksPerCU = 0;
 		HIP_TRY( ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor( &blocksPerCU, (const void*) kernel, blockThreads, 0 ) );
 		blocksPerCU = ( blocksPerCU < 1 ) ? 1 : blocksPerCU;
@@ -801,15 +687,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		// a block's share of the CU's 160 KB, for the staged tree top
 		const size_t ldsPerCU = 160 * 1024;
 		const size_t share = ldsPerCU / (size_t) blocksPerCU - 256;
-		// (lab variants keep per-lane state behind the staged prefix: the asynchronous node phase 32 B per lane of record slots,
-		// two paths per lane 2 slots x 4 planes x 16 B of path state)
-		size_t slotBytes = pathSlotBytes;     // two paths per lane: 2 slots x 4 planes x 16 B of path state per lane behind the staged prefix
-#if defined( PBR_LAB ) && defined( PBR_DUAL_LEAN )
-		slotBytes = ( plan == &ctx->plans[2] ) ? (size_t) 2 * 4 * 16 * PBR_BLOCK : slotBytes;
-#elif defined( PBR_LAB )
-		slotBytes = async ? (size_t) 2 * PT_SLOT_PLANE : slotBytes;
-#endif
-		(void) async;
+		const size_t slotBytes = pathSlotBytes;     // two paths per lane: 2 slots x 4 planes x 16 B of path state per lane behind the staged prefix
+
+		// (a toolchain that fitted such a kernel into fewer registers would report two blocks per CU, whose share
+		// is smaller than the path slots — the subtraction below is unsigned)
+		if( share < slotBytes + 32 ) {
+			return fail( ctx, PBR_ESTATE, "plan %s: %zu B of per-lane path state do not fit a block's %zu B share of LDS at %d blocks per CU", name, slotBytes, share, blocksPerCU );
+		}
+
 		size_t slots = ( share - slotBytes ) / 32;
 		slots = std::min<size_t>( slots, hotAvail );
 
@@ -826,15 +711,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		plan->blocks = ctx->numCUs * blocksPerCU;   // all that are resident at once; run() launches fewer when there is less work
 		plan->numHot = (int) slots;
 		plan->ldsBytes = slots * 32 + slotBytes;
-#ifdef PBR_LAB
-		plan->async = async;
-#endif
 		plan->park = park;
 		plan->shade = shade;
 		plan->parkEighths = ( ctx->numNodes >= kWideMinNodes ) ? 4 : 6;   // see traverse(), pt_kernel.hpp
 
 		if( knobs.phPark >= 0 ) {
-			plan->park = std::max( 1, std::min( 64, knobs.phPark ) );
+			plan->park = std::max( 1, std::min( ( pathSlotBytes != 0 ) ? 128 : 64, knobs.phPark ) );   // two paths per lane: walks of up to 128 per wave
 		}
 		if( knobs.phShade >= 0 ) {
 			plan->shade = std::max( 1, std::min( 64, knobs.phShade ) );
@@ -856,15 +738,6 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.numHot = plan.numHot;
 		P.numHotBytes = plan.numHot * 32;
 		P.slotBase = plan.numHot * 32;
-#ifdef PBR_LAB
-		P.nodes = ( plan.pair && ctx->dNodesPair != nullptr ) ? ctx->dNodesPair : P.nodes;
-		// measured (profiles/r04/experiments/async_node_phase.txt): the share of the walking lanes an iteration waits for
-		P.asyncEighths = ( knobs.asyncEighths >= 1 ) ? std::min( 8, knobs.asyncEighths ) : 6;
-
-		if( plan.async && ( plan.numHot < 1 || ctx->firstRef >= plan.numHot * 32 ) ) {
-			return fail( ctx, PBR_ESTATE, "asynchronous node phase: the walk's first record must be staged in LDS" );
-		}
-#endif
 
 		P.phPark = plan.park;
 		P.phShade = plan.shade;
@@ -907,20 +780,18 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	if( !ctx->plansBuilt ) {
 		const uint32_t brdf = ctx->cfg.brdf;
 		Plan* plans = ctx->plans;
-		int status = makePlan( pickKernel( brdf, shadow, lights, true, false ), "refill-lean", 0, 0, &plans[0] );
-		status = ( status != PBR_OK ) ? status : makePlan( pickKernel( brdf, shadow, lights, true, true ), "refill-wide", 0, 0, &plans[1] );
-		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, false ), "phased-lean", 16, 32, &plans[2], PBR_BLOCK, kAsyncLean );
-#ifdef PBR_LAB
-		plans[2].pair = ( kWalkLean == ptk::WALK_PAIR );
-#endif
-		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhased( brdf, shadow, lights, true ), "phased-wide", 16, 48, &plans[3] );
-		status = ( status != PBR_OK ) ? status : makePlan( pickKernelPhasedMid( brdf, shadow, lights ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads, kAsyncMid );
-		status = ( status != PBR_OK ) ? status : makePlan( pickKernelMid( brdf, shadow, lights ), "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
+		auto kernelOf = [&]( int group ) { return pickKernel( flavour, group, brdf, shadow, lights ); };
+		int status = makePlan( kernelOf( PTI_REFILL_LEAN ), "refill-lean", 0, 0, &plans[0] );
+		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_REFILL_WIDE ), "refill-wide", 0, 0, &plans[1] );
+		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_PHASED_LEAN ), "phased-lean", 16, 32, &plans[2] );
+		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_PHASED_WIDE ), "phased-wide", 16, 48, &plans[3] );
+		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_PHASED_MID ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads );
+		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_REFILL_MID ), "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
 		// 28 of a wave's up to 128 walks leave a node phase before it ends; a shade phase waits for 48 lanes (measured:
 		// profiles/r04/experiments/two_paths_per_lane.txt).  Without the hand-scheduled node phase: phased-mid's kernel and thresholds.
 		status = ( status != PBR_OK ) ? status : ( kDualIsDual
-			? makePlan( pickKernelDual( brdf, shadow, lights ), "phased-dual", 28, 48, &plans[6], PBR_BLOCK, false, (size_t) 2 * 4 * 16 * PBR_BLOCK )
-			: makePlan( pickKernelDual( brdf, shadow, lights ), "phased-dual", 16, 40, &plans[6], kMidBlockThreads, kAsyncMid ) );
+			? makePlan( kernelOf( PTI_DUAL ), "phased-dual", 28, 48, &plans[6], PBR_BLOCK, (size_t) 2 * 4 * 16 * PBR_BLOCK )
+			: makePlan( kernelOf( PTI_PHASED_MID ), "phased-dual", 16, 40, &plans[6], kMidBlockThreads ) );
 
 		if( status != PBR_OK ) {
 			return status;
@@ -954,7 +825,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	if( phong ) {
 		// one plan: the Phong-tessellation build of the lock-step kernel (lean budget), in the slot of plan 1
 		if( !ctx->phongPlanBuilt ) {
-			const int made = makePlan( pickKernelPhong( ctx->cfg.brdf, shadow, lights ), "refill-lean-phong", 0, 0, &ctx->phongPlan );
+			const int made = makePlan( pickKernel( flavour, PTI_REFILL_PHONG, ctx->cfg.brdf, shadow, lights ), "refill-lean-phong", 0, 0, &ctx->phongPlan );
 
 			if( made != PBR_OK ) {
 				return made;
@@ -1514,14 +1385,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 			w1 = refOf( (long long) i + 1 );
 		}
 
-#ifdef PBR_LAB
-		// lab (nodePhaseAsync): every NaN of a box is stored as THE quiet NaN 0x7FC00000 — the slab test only ever compares (a
-		// NaN's payload changes nothing), and an empty record slot is marked with the NaN 0xFFFFFFFF in a box word: a record
-		// must never look like an empty slot
-		auto boxWord = []( float x ) { return ( x != x ) ? __builtin_bit_cast( float, 0x7FC00000u ) : x; };
-#else
 		auto boxWord = []( float x ) { return x; };
-#endif
 		const size_t r = (size_t) recordOf[i];
 		nodes[r * 2 + 0] = make_float4( boxWord( n.bbMin.x ), boxWord( n.bbMin.y ), boxWord( n.bbMax.x ), boxWord( n.bbMax.y ) );
 		nodes[r * 2 + 1] = make_float4( boxWord( n.bbMin.z ), boxWord( n.bbMax.z ), __builtin_bit_cast( float, w0 ), __builtin_bit_cast( float, w1 ) );
@@ -1614,27 +1478,6 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dLights, sizeof( float4 ) * lights.size() ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dNodes, nodes.data(), sizeof( float4 ) * nodes.size(), hipMemcpyHostToDevice ) );
 
-#ifdef PBR_LAB
-	if( kWalkLean == ptk::WALK_PAIR ) {
-		// lab (nodePhasePair): bit 0 of a container's w0 = "my hit successor is the adjacent record", only behind the ranked
-		// prefix (every plan fetches those records from memory)
-		std::vector<float4> flagged( nodes );
-		size_t flags = 0;
-
-		for( size_t r = numHot; r + 1 < numRecords; r++ ) {
-			const int w0 = __builtin_bit_cast( int, flagged[r * 2 + 1].z );
-
-			if( w0 >= 0 && (size_t) w0 == ( r + 1 ) * 32 ) {
-				flagged[r * 2 + 1].z = __builtin_bit_cast( float, w0 | 1 );
-				flags++;
-			}
-		}
-
-		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dNodesPair, sizeof( float4 ) * flagged.size() ) );
-		HIP_TRY( ctx, hipMemcpy( ctx->dNodesPair, flagged.data(), sizeof( float4 ) * flagged.size(), hipMemcpyHostToDevice ) );
-		std::fprintf( stderr, "[pbr pair] %zu of %zu records carry the adjacent-successor flag\n", flags, numRecords );
-	}
-#endif
 	HIP_TRY( ctx, hipMemcpy( ctx->dTris, tris.data(), sizeof( float4 ) * tris.size(), hipMemcpyHostToDevice ) );
 
 	if( !triPN.empty() ) {
@@ -1698,8 +1541,8 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	if( cfg->traversal > 2 || cfg->arith > 1 ) {
 		return fail( ctx, PBR_EINVAL, "traversal must be 0 (the reference's walk), 1 (six orders) or 2 (eight orders); arith 0 (exact) or 1 (native)" );
 	}
-	if( cfg->arith != 0 ) {
-		return fail( ctx, PBR_EINVAL, "arith = native is not built yet" );
+	if( cfg->phong_tessellation > 0.0f && ( cfg->traversal != 0 || cfg->arith != 0 ) ) {
+		return fail( ctx, PBR_EINVAL, "Phong tessellation is built for the reference's walk and the exact arithmetic only" );
 	}
 	if( cfg->tile_world == 0 || cfg->tile_rank >= cfg->tile_world ) {
 		return fail( ctx, PBR_EINVAL, "tile_rank must be < tile_world, tile_world >= 1" );
@@ -2496,52 +2339,6 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 	return PBR_OK;
 }
 
-#if defined( PBR_LAB ) && !defined( PBR_GUARD )
-// lab builds only (scripts/trace_dual.py): the traversal-only probe at `waves` (4 | 8) per SIMD with one or two walks per lane
-extern "C" int pbr_lab_trace_stream_dual( pbr_ctx* ctx, int mode, int waves, int dual, const float* rays8, uint32_t n, int repeats, float* out2, double* ms_out ) {
-	if( ctx == nullptr || !ctx->hasScene || rays8 == nullptr || n == 0 || out2 == nullptr || ms_out == nullptr || ( waves != 4 && waves != 6 && waves != 8 ) || ( waves == 8 && dual ) ) {
-		return fail( ctx, PBR_EINVAL, "lab_trace_stream_dual: bad argument / no scene (waves 4 | 6 | 8; two walks per lane need more than 64 registers: not at 8)" );
-	}
-
-	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
-	DevBuf dRays, dOut;
-	HIP_TRY( ctx, dRays.alloc( sizeof( float ) * 8 * (size_t) n ) );
-	HIP_TRY( ctx, dOut.alloc( sizeof( float ) * 2 * (size_t) n ) );
-	HIP_TRY( ctx, hipMemcpy( dRays.p, rays8, sizeof( float ) * 8 * (size_t) n, hipMemcpyHostToDevice ) );
-	DevParams P = sceneParams( ctx );
-	P.workCounter = ctx->dWork;
-	P.counters = ctx->dCounters;
-	P.parkEighths = 4;
-	ctx->workClean = false;
-	double best = 1e30;
-	// 4: one 1024-thread block per CU; 6: two 768-thread blocks (the 4-waves kernels fit 80 registers); 8: two 1024-thread blocks
-	KernelFn2 kernel = ( waves == 8 ) ? ptk::diagTraceStreamDual<8, false> : ( dual ? ptk::diagTraceStreamDual<4, true> : ptk::diagTraceStreamDual<4, false> );
-	const int blocksPerCU = ( waves == 4 ) ? 1 : 2;
-	const unsigned blockThreads = ( waves == 6 ) ? 768u : (unsigned) PBR_BLOCK;
-	size_t slots = std::min<size_t>( (size_t) mode, ctx->numHotAvail );
-	slots = std::min<size_t>( slots, ( 160 * 1024 / (size_t) blocksPerCU - 256 ) / 32 );
-	slots = std::max<size_t>( slots, 1 );
-	P.numHot = (int) slots;
-	P.numHotBytes = (int) slots * 32;
-	HIP_TRY( ctx, hipFuncSetAttribute( (const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ( 160 * 1024 / blocksPerCU - 256 ) ) );
-
-	for( int r = 0; r < repeats; r++ ) {
-		HIP_TRY( ctx, hipMemsetAsync( ctx->dWork, 0, kWorkBytes, ctx->stream ) );
-		HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
-		hipLaunchKernelGGL( kernel, dim3( (unsigned) ( ctx->numCUs * blocksPerCU ) ), dim3( blockThreads ), slots * 32, ctx->stream, P, (const float4*) dRays.p, n, (float2*) dOut.p );
-		HIP_TRY( ctx, hipGetLastError() );
-		HIP_TRY( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
-		HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
-		float ms = 0.0f;
-		HIP_TRY( ctx, hipEventElapsedTime( &ms, ctx->evStart, ctx->evStop ) );
-		best = ( ms < best ) ? ms : best;
-	}
-
-	HIP_TRY( ctx, hipMemcpy( out2, dOut.p, sizeof( float ) * 2 * (size_t) n, hipMemcpyDeviceToHost ) );
-	*ms_out = best;
-	return PBR_OK;
-}
-#endif
 
 // Counter calibration: allocate a zero-filled table of table_bytes, read `reads` elements / records
 // in the given pattern (0 stream, 1 random 16 B, 2 random 32 B); reports the kernel time.  Run it
@@ -2623,9 +2420,6 @@ int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value ) {
 		{ "park_eighths", &k.parkEighths }, { "drain_mode", &k.drainMode }, { "refill_batch", &k.refillBatch },
 		{ "chunk_frames", &k.chunkFrames }, { "face_normals", &k.faceNormals }, { "bvh_builder", &k.bvhBuilder },
 		{ "ploc_radius", &k.plocRadius }, { "tune_log", &k.tuneLog },
-#ifdef PBR_LAB
-		{ "async_eighths", &k.asyncEighths },
-#endif
 	};
 
 	for( const auto& entry : table ) {

@@ -85,10 +85,6 @@ using namespace ptm;
 #ifndef PT_WALK_PRIO
 #define PT_WALK_PRIO 1
 #endif
-#ifdef PBR_LAB
-// lab, asynchronous node phase (nodePhaseAsync): bytes between the two halves of a lane's record slot in LDS: 1024 lanes x 16 B
-#define PT_SLOT_PLANE 16384
-#endif
 #ifndef PT_EAGER_REFILL_UP_TO
 #define PT_EAGER_REFILL_UP_TO 8
 #endif
@@ -143,9 +139,6 @@ struct DevParams {
 	                        // — the eight references sit in the 32 bytes IN FRONT of `nodes` (as kernel arguments they were
 	                        // eight more live registers in every kernel: scalar values the compiler keeps in vector registers)
 	int slotBase;           // LDS byte address of the per-lane state behind the staged prefix (= numHotBytes): pathTracingDual's path slots
-#ifdef PBR_LAB             // round-4 lab variants (lab/src/pt_r04_*.hpp)
-	int asyncEighths;       // nodePhaseAsync: the share of the walking lanes (in eighths) that must be ready before an iteration starts
-#endif
 	int nFrames, firstCount;
 	int useExplicitWeight;
 	float explicitWeight;
@@ -822,6 +815,21 @@ PT_DEV NodeLinks decodeNode( const float4 n1 ) {
 	return n;
 }
 
+// The node stream's base as a scalar register pair for the node phases' record loads.  It is a kernel argument and lives
+// in scalar registers already, where v_readfirstlane folds away; but in builds whose walk start reads the table in front
+// of the stream (PT_WALK_MODE 1) hipcc hands the assembly's "s" operand a VECTOR register pair — an invalid instruction —
+// unless the operand is scalar by construction.
+PT_DEV const float4* scalarBase( const float4* p ) {
+#if PT_WALK_MODE == 1
+	const unsigned long long bits = (unsigned long long) (size_t) p;
+	const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane( (int) (unsigned) bits );
+	const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane( (int) (unsigned) ( bits >> 32 ) );
+	return (const float4*) (size_t) ( ( (unsigned long long) hi << 32 ) | lo );
+#else
+	return p;
+#endif
+}
+
 // Which of the successor sets a ray walks (pbr_config.traversal; the statement both ends follow is in pbr_upload's
 // buildWalkStreams and in the oracle's "Ray-ordered walk").  Scheme 1: 2 * dominant axis (x before y before z on ties)
 // + ( dir[axis] < 0 ).  Scheme 2: the sign bits x | y << 1 | z << 2.
@@ -837,14 +845,25 @@ PT_DEV int walkOrderOf( int scheme, const f3 d ) {
 }
 
 PT_DEV Cursor firstNode( const DevParams& P, const f3 dir ) {
-	// the walk starts at node 1 (pt_bvh.cl:84) — or, with a ray-ordered walk, at the root's first child in the ray's order
+	// the walk starts at node 1 (pt_bvh.cl:84) — or, with a ray-ordered walk, at the root's first child in the ray's order:
+	// one 4-byte load per walk from the table in front of the stream, an L1 hit.  Which of the two is a property of the
+	// build flavour (pt_flavour.hpp): as a run-time branch it cost every kernel registers, the 80-register ones spills.
 	Cursor c;
+#if PT_WALK_MODE == 0
+	(void) dir;
+	c.ref = P.firstRef;
+#elif PT_WALK_MODE == 1
+	// (as an instruction: written in C++ the load takes P.nodes into vector registers, and the hand-scheduled node phases
+	// need it as the scalar base of their record loads — hipcc then hands their "s" operand a vector register pair)
+	const int tableOffset = walkOrderOf( P.walkScheme, dir ) * 4;
+	asm volatile( "global_load_dword %0, %1, %2 offset:-32\n\ts_waitcnt vmcnt(0)" : "=v"( c.ref ) : "v"( tableOffset ), "s"( scalarBase( P.nodes ) ) : "memory" );
+#else
 	c.ref = P.firstRef;
 
-	if( P.walkScheme != 0 ) {   // wave-uniform: a kernel argument
-		c.ref = ( (const int*) P.nodes )[walkOrderOf( P.walkScheme, dir ) - 8];   // one 4-byte load per walk, an L1 hit
+	if( P.walkScheme != 0 ) {
+		c.ref = ( (const int*) P.nodes )[walkOrderOf( P.walkScheme, dir ) - 8];
 	}
-
+#endif
 	return c;
 }
 
@@ -968,7 +987,7 @@ PT_DEV void nodePhaseAsm(
 		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [leafTFar] "=v"( leafTFar ), [parked] "=v"( parked ), \
 		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [count] "=&s"( count ) \
 		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ), \
-		  [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps ) \
+		  [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( scalarBase( P.nodes ) ), [eps] "s"( eps ) \
 		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc"
 
 	if( ANYHIT ) {
@@ -994,10 +1013,7 @@ PT_DEV void nodePhaseAsm(
 // Round 4 measured more node phases — the adjacent record fetched along (nodePhasePair), paired half-record fetches
 // (nodePhaseHalves), polled LDS-DMA slots (nodePhaseAsync) and two walks per lane (nodePhaseDual) — all bit-identical; for ONE walk
 // per lane none is faster than this one (lab/src/pt_r04_node_phases.hpp, profiles/r04/experiments/; lab builds, -DPBR_LAB, compile
-// them in, the product does not).  Two walks per lane with their node phases software-pipelined became plan 6: pt_dual.hpp.
-#ifdef PBR_LAB
-#include "pt_r04_node_phases.hpp"
-#endif
+// them in up to round 4's last commit; the product never did).  Two walks per lane with their node phases software-pipelined became plan 6: pt_dual.hpp.
 #endif
 
 // traverse (pt_bvh.cl:82-123) / traverseShadows (:133-177).  ANYHIT: the shadow variant — no
@@ -2120,27 +2136,11 @@ PT_DEV int startWalk( const DevParams& P, const Ray& ray, WalkState& w ) {
 	return MODE_NODE;
 }
 
-// WALK: which node phase — 0 nodePhaseAsm, 1 nodePhaseAsync (polled LDS-DMA slots), 2 nodePhasePair (adjacent record fetched along)
-enum { WALK_SYNC = 0, WALK_ASYNC = 1, WALK_PAIR = 2 };
-
-template<int BRDF, bool SHADOW, bool LIGHTS, int MINW, int WALK = WALK_SYNC>
+template<int BRDF, bool SHADOW, bool LIGHTS, int MINW>
 __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const DevParams P ) {
-	constexpr bool ASYNC = ( WALK == WALK_ASYNC );
-	(void) ASYNC;
 	const float4* lds = gHotNodes;
 	PT_LAB_WAVE_BEGIN
 	stageHotNodes( P, gHotNodes );
-#if defined( PT_NODE_PHASE_ASM ) && defined( PBR_LAB )
-	// lab, asynchronous node phase: every lane's slot starts out empty (marker in the last word of its second half);
-	// the slots of a wave are 1 KiB per half, lane-linear (nodePhaseAsync)
-	const int slotM0 = __builtin_amdgcn_readfirstlane( P.slotBase + (int) ( threadIdx.x >> 6 ) * 1024 );
-	int asyncErr = 0;
-
-	if( ASYNC ) {
-		*(volatile unsigned*) ( (char*) gHotNodes + P.slotBase + (int) threadIdx.x * 16 + 12 ) = 0xFFFFFFFFu;
-		*(volatile unsigned*) ( (char*) gHotNodes + P.slotBase + PT_SLOT_PLANE + (int) threadIdx.x * 16 + 12 ) = 1u;
-	}
-#endif
 
 	const unsigned total = (unsigned) P.numLocalTiles * 64u;   // bound of the PBR_GUARD loop limits
 	(void) total;
@@ -2212,22 +2212,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				int leafWord = 0, parkedFlag;
 				float unusedTFar;
 				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );   // through the leaf phase below
-#ifdef PBR_LAB      // the round-4 variants exist in lab builds only (lab/src/pt_r04_node_phases.hpp)
-				if( ASYNC ) {
-					(void) unusedTFar;
-					int phaseErr;
-					nodePhaseAsync( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, slotM0, w.cur.ref, visits, leafWord, w.leafTNear, parkedFlag, phaseErr );
-					asyncErr |= phaseErr;
-				}
-				else if( WALK == WALK_PAIR ) {
-					(void) unusedTFar;
-					nodePhasePair( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, parkedFlag );
-				}
-				else
-#endif
-				{
-					nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
-				}
+				nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
 				st.dbgNodes += visits;
 				PT_LAB_PHASED_NODE_MID
 
@@ -2327,357 +2312,11 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 	}
 
 	flushCounters( P, cnt );
-#if defined( PT_NODE_PHASE_ASM ) && defined( PBR_LAB )
-	if( ASYNC ) {
-		// every request has been consumed by the lane that made it; a block's LDS must not be handed on with a DMA in flight
-		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-
-		if( asyncErr != 0 && P.guard != nullptr ) {
-			atomicAdd( &P.guard[1], 1u );      // a slot never filled: the render is reported as failed (pbr_hip.hip, launch())
-		}
-	}
-#endif
 	PT_LAB_PHASED_END( P )
 	PT_LAB_WAVE_END_PHASED( P )
 }
 
 
 #include "pt_dual.hpp"               // pathTracingDual: the lane state machine with two paths per lane (plan 6, "phased-dual")
-
-#if defined( PBR_LAB ) && defined( PT_NODE_PHASE_ASM )
-#include "pt_r04_dual_kernel.hpp"   // r04lab::pathTracingDual: the variants of it that were measured and not kept (lab)
-#endif
-
-// ---------------------------------------------------------------------------------------
-// Frame-parallel launches: fold the frames into the running mean
-// ---------------------------------------------------------------------------------------
-// setColors (pt_rgb.cl:9-21) for frames firstCount .. firstCount + nFrames - 1 of every local pixel,
-// in frame order: exactly the arithmetic shadeStep applies when one lane walks a pixel through
-// all its frames.  imageOut.w = focus (first-hit distance) of the last frame.
-__global__ __launch_bounds__( 256 ) void foldFrames( const DevParams P, const float4* src, float4* dst ) {
-	const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-
-	// the path-tracing launch before this one has drained the queue: leave its heads at zero for the next launch
-	if( slot < (unsigned) PT_BANDS ) {
-		P.workCounter[slot * PT_BAND_STRIDE] = 0u;
-	}
-
-	if( slot >= P.frameStride ) {
-		return;
-	}
-
-	float4 acc = src[slot];
-
-	for( int k = 0; k < P.nFrames; k++ ) {
-		const float4 fc = P.frameBuf[frameBufIndex( P, slot, (unsigned) k )];
-		const unsigned n = (unsigned) ( P.firstCount + k );
-		const float w = P.useExplicitWeight ? P.explicitWeight : ( (float) n / (float) ( n + 1u ) );
-		acc.x = fc.x + ( acc.x - fc.x ) * w;
-		acc.y = fc.y + ( acc.y - fc.y ) * w;
-		acc.z = fc.z + ( acc.z - fc.z ) * w;
-		acc.w = fc.w;
-	}
-
-	dst[slot] = acc;
-}
-
-// ---------------------------------------------------------------------------------------
-// Scene preparation (pbr_upload_scene): per-face and per-material values the shading would otherwise
-// recompute on every hit — evaluated here by the same device functions, so the bits are the same
-// ---------------------------------------------------------------------------------------
-__global__ void prepareFaceNormals( DevParams P, float4* faceN, int numFaces ) {
-	const int face = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
-
-	if( face >= numFaces ) {
-		return;
-	}
-
-	int material;
-	const f3 n = faceNormal<false>( P, face, &material );
-	faceN[face] = make_float4( n.x, n.y, n.z, __int_as_float( material ) );
-}
-
-// ---------------------------------------------------------------------------------------
-// Framebuffer layout helpers
-// ---------------------------------------------------------------------------------------
-
-// tile-major (local tiles of this rank) -> row-major W x H; pixels of other ranks' tiles = 0
-__global__ void untile( const float4* tiles, float4* rows, int width, int height, int tilesX, int tileWorld, int tileRank ) {
-	const int x = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
-	const int y = (int) ( blockIdx.y * blockDim.y + threadIdx.y );
-
-	if( x >= width || y >= height ) {
-		return;
-	}
-
-	const int tileGlobal = ( y >> 3 ) * tilesX + ( x >> 3 );
-	float4 v = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-
-	const int position = dealPositionOfTile( tileGlobal, tilesX, tileWorld );
-
-	if( position % tileWorld == tileRank ) {
-		const int tileLocal = position / tileWorld;
-		v = tiles[(size_t) tileLocal * 64 + (size_t) ( ( y & 7 ) * 8 + ( x & 7 ) )];
-	}
-
-	rows[(size_t) y * (size_t) width + (size_t) x] = v;
-}
-
-// The display step after the path: what shader/pathtracing.frag:11-15 puts on an
-// 8-bit GL framebuffer — the linear colour, clamped to [0, 1], alpha 1 — as RGBA8, value = floor( c * 255 + 0.5 ).
-// rowStep = +1: row 0 is the bottom of the image (GL, like pbr_read_output); -1: top row first (image files).
-__global__ void displayRGBA8( const float4* tiles, uchar4* rows, int width, int height, int tilesX, int tileWorld, int tileRank, int topRowFirst ) {
-	const int x = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
-	const int y = (int) ( blockIdx.y * blockDim.y + threadIdx.y );
-
-	if( x >= width || y >= height ) {
-		return;
-	}
-
-	const int tileGlobal = ( y >> 3 ) * tilesX + ( x >> 3 );
-	float4 v = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-
-	const int position = dealPositionOfTile( tileGlobal, tilesX, tileWorld );
-
-	if( position % tileWorld == tileRank ) {
-		const int tileLocal = position / tileWorld;
-		v = tiles[(size_t) tileLocal * 64 + (size_t) ( ( y & 7 ) * 8 + ( x & 7 ) )];
-	}
-
-	// fmax / fmin drop a NaN operand: NaN -> 0
-	const float r = fmin1( fmax1( v.x, 0.0f ), 1.0f );
-	const float g = fmin1( fmax1( v.y, 0.0f ), 1.0f );
-	const float b = fmin1( fmax1( v.z, 0.0f ), 1.0f );
-	const int outRow = topRowFirst ? ( height - 1 - y ) : y;
-	rows[(size_t) outRow * (size_t) width + (size_t) x] = make_uchar4(
-		(unsigned char) (int) __builtin_floorf( r * 255.0f + 0.5f ),
-		(unsigned char) (int) __builtin_floorf( g * 255.0f + 0.5f ),
-		(unsigned char) (int) __builtin_floorf( b * 255.0f + 0.5f ),
-		255 );
-}
-
-// row-major W x H -> tile-major local tiles
-__global__ void retile( const float4* rows, float4* tiles, int width, int numLocalTiles, int tilesX, int tileWorld, int tileRank ) {
-	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-
-	if( i >= (size_t) numLocalTiles * 64 ) {
-		return;
-	}
-
-	const int tileLocal = (int) ( i >> 6 );
-	const int lane = (int) ( i & 63 );
-	const int tileGlobal = tileAtDealPosition( tileLocal * tileWorld + tileRank, tilesX, tileWorld );
-	const int x = ( tileGlobal % tilesX ) * 8 + ( lane & 7 );
-	const int y = ( tileGlobal / tilesX ) * 8 + ( lane >> 3 );
-	tiles[i] = rows[(size_t) y * (size_t) width + (size_t) x];
-}
-
-// all-gather layout (tileWorld rank buffers of `perRank` tiles each) -> this context's full tile-major image
-__global__ void scatterGathered( const float4* all, float4* tiles, int numTiles, int perRank, int tileWorld, int tilesX ) {
-	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-
-	if( i >= (size_t) numTiles * 64 ) {
-		return;
-	}
-
-	const int tileGlobal = (int) ( i >> 6 );
-	const int lane = (int) ( i & 63 );
-	const int position = dealPositionOfTile( tileGlobal, tilesX, tileWorld );
-	const int rank = position % tileWorld;
-	const int local = position / tileWorld;
-	tiles[i] = all[( (size_t) rank * perRank + local ) * 64 + lane];
-}
-
-
-
-// ---------------------------------------------------------------------------------------
-// Diagnostic kernels (include/pbr_hip_diag.h): one thread per item, for stage-by-stage parity
-// ---------------------------------------------------------------------------------------
-
-__global__ void diagMath( int op, const float* x, const float* y, int n, float* out ) {
-	const int i = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
-
-	if( i >= n ) {
-		return;
-	}
-
-	float s, c;
-
-	switch( op ) {
-		case 0: sincos( x[i], &s, &c ); out[i] = s; break;
-		case 1: sincos( x[i], &s, &c ); out[i] = c; break;
-		case 2: out[i] = tan1( x[i] ); break;
-		case 3: out[i] = acos1( x[i] ); break;
-		case 4: out[i] = atan1( x[i] ); break;
-		case 5: out[i] = pow1( x[i], y[i] ); break;
-		case 6: out[i] = fract( sin1( x[i] ) * 43758.5453123f ); break;
-		default: out[i] = 0.0f; break;
-	}
-}
-
-// rays: n x {origin, dir}; outputs as orc_trace_rays
-template<bool LIGHTS>
-__global__ void diagTrace( const DevParams P, const float* rays, int n, float* outT, int* outFace, float* outNormal, unsigned* outCounts ) {
-	const int i = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
-
-	if( i >= n ) {
-		return;
-	}
-
-	Ray ray;
-	ray.origin = mk3( rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2] );
-	ray.dir = mk3( rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5] );
-	Hit hit;
-	hit.t = inff();
-	hit.face = 0;
-	unsigned nodes = 0, tris = 0;
-	traverse<false, LIGHTS, false>( P, nullptr, ray, hit, nodes, tris );
-
-	f3 normal = mk3( 0.0f, 0.0f, 0.0f );
-
-	if( hit.t != inff() ) {
-		int material;
-		normal = faceNormal( P, hit.face, &material );
-	}
-
-	outT[i] = hit.t;
-	outFace[i] = hit.face;
-	outNormal[i * 3 + 0] = normal.x;
-	outNormal[i * 3 + 1] = normal.y;
-	outNormal[i * 3 + 2] = normal.z;
-	outCounts[i * 2 + 0] = nodes;
-	outCounts[i * 2 + 1] = tris;
-}
-
-// Traversal-only throughput probe: persistent lanes draw ray indices from P.workCounter, walk,
-// store {t, face} — what the walk alone sustains at full occupancy (no shading registers).
-template<bool USE_LDS>
-__global__ __launch_bounds__( PBR_BLOCK, 8 ) void diagTraceStream( const DevParams P, const float4* rays, unsigned n, float2* out ) {
-	const float4* lds = gHotNodes;
-
-	if( USE_LDS ) {
-		stageHotNodes( P, gHotNodes );
-	}
-
-	unsigned nodes = 0, tris = 0;
-	unsigned i = atomicAdd( P.workCounter, 1u );
-
-	while( i < n ) {
-		const float4 a = rays[(size_t) i * 2 + 0];
-		const float4 b = rays[(size_t) i * 2 + 1];
-		Ray ray;
-		ray.origin = mk3( a.x, a.y, a.z );
-		ray.dir = mk3( b.x, b.y, b.z );
-		Hit hit;
-		hit.t = inff();
-		hit.face = 0;
-		traverse<false, false, USE_LDS>( P, lds, ray, hit, nodes, tris );
-		out[i] = make_float2( hit.t, __int_as_float( hit.face ) );
-		i = atomicAdd( P.workCounter, 1u );
-	}
-
-	atomicAdd( &P.counters[0], (unsigned long long) nodes );
-	atomicAdd( &P.counters[1], (unsigned long long) tris );
-}
-
-#if defined( PBR_LAB ) && defined( PT_NODE_PHASE_ASM )
-#include "pt_r04_probe.hpp"   // diagTraceStreamDual (lab)
-#endif
-
-// Counter calibration: read a table of `count` float4 in a KNOWN pattern so that
-// FETCH_SIZE / TCC_EA0_RDREQ_* can be interpreted for this path's access shapes.
-//   MODE 0  coalesced stream: lane l reads element base + l (16 B per lane, 1 KiB per wave)
-//   MODE 1  one random 16-B element per lane and step
-//   MODE 2  one random 32-B record (two adjacent float4, like a BVH node) per lane and step
-template<int MODE>
-__global__ __launch_bounds__( 256 ) void diagCalibrate( const float4* table, unsigned long long count, unsigned steps, float* sink ) {
-	const unsigned long long tid = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
-	const unsigned long long threads = (unsigned long long) gridDim.x * blockDim.x;
-	float acc = 0.0f;
-
-	for( unsigned k = 0; k < steps; k++ ) {
-		const unsigned long long i = (unsigned long long) k * threads + tid;
-
-		if( MODE == 0 ) {
-			const float4 v = table[i % count];
-			acc += v.x + v.w;
-		}
-		else {
-			// splitmix-style hash -> uniformly random element
-			unsigned long long z = ( i + 1 ) * 0x9e3779b97f4a7c15ULL;
-			z = ( z ^ ( z >> 30 ) ) * 0xbf58476d1ce4e5b9ULL;
-			z = ( z ^ ( z >> 27 ) ) * 0x94d049bb133111ebULL;
-			z ^= z >> 31;
-
-			if( MODE == 1 ) {
-				const float4 v = table[z % count];
-				acc += v.x + v.w;
-			}
-			else {
-				const unsigned long long r = ( z % ( count / 2 ) ) * 2;
-				const float4 a = table[r];
-				const float4 b = table[r + 1];
-				acc += a.x + b.w;
-			}
-		}
-	}
-
-	if( acc == 123456.789f ) {
-		sink[0] = acc;   // never true for the zero-filled table; keeps the loads alive
-	}
-}
-
-// in: n x 16 {out_dir, in_dir, normal, pad}; out: n x 4 (as orc_brdf_eval); material 0 of P.mats
-template<int BRDF>
-__global__ void diagBrdf( const DevParams P, const float* in, int n, float* out ) {
-	const int i = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
-
-	if( i >= n ) {
-		return;
-	}
-
-	const float* p = in + (size_t) i * 16;
-	const Material mtl = loadMaterial( P, 0 );
-	const f3 outDir = mk3( p[0], p[1], p[2] );
-	const f3 inDir = mk3( p[3], p[4], p[5] );
-	const f3 normal = mk3( p[6], p[7], p[8] );
-	float* o = out + (size_t) i * 4;
-
-	if( BRDF == 0 ) {
-		float u, pdf;
-		const float b = brdfSchlick( mtl, outDir, inDir, normal, &u, &pdf );
-		o[0] = b; o[1] = u; o[2] = pdf; o[3] = 0.0f;
-	}
-	else {
-		float spec, diff, dotHK1, pdf;
-		brdfSA( mtl, outDir, inDir, normal, &spec, &diff, &dotHK1, &pdf );
-		o[0] = spec; o[1] = diff; o[2] = dotHK1; o[3] = pdf;
-	}
-}
-
-// in: n x 12 {origin, dir, normal, t, seed, pad}; out: n x 8 (as orc_new_ray); material 0
-template<int BRDF>
-__global__ void diagNewRay( const DevParams P, const float* in, int n, float* out ) {
-	const int i = (int) ( blockIdx.x * blockDim.x + threadIdx.x );
-
-	if( i >= n ) {
-		return;
-	}
-
-	const float* p = in + (size_t) i * 12;
-	const Material mtl = loadMaterial( P, 0 );
-	const f3 origin = mk3( p[0], p[1], p[2] );
-	const f3 dir = mk3( p[3], p[4], p[5] );
-	const f3 normal = mk3( p[6], p[7], p[8] );
-	float seed = p[10];
-	bool addDepth = false;
-	const f3 newOrigin = fma3( p[9], dir, origin );
-	const f3 newDir = newRayDir<BRDF>( dir, normal, mtl, seed, addDepth );
-	float* o = out + (size_t) i * 8;
-	o[0] = newOrigin.x; o[1] = newOrigin.y; o[2] = newOrigin.z;
-	o[3] = newDir.x; o[4] = newDir.y; o[5] = newDir.z;
-	o[6] = seed;
-	o[7] = addDepth ? 1.0f : 0.0f;
-}
 
 }  // namespace ptk

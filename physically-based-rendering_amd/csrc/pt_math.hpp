@@ -3,9 +3,19 @@
 // (native_sin/cos/tan/recip/divide/sqrt, fast_normalize, dot, cross, fract, mix, clamp, max,
 // pow, acos, atan).  IEEE binary32 / binary64 operations only, contraction OFF for the whole
 // translation unit (-ffp-contract=off); every fused multiply-add below is explicit.
+//
+// PT_ARITH_NATIVE (pt_flavour.hpp; pbr_config.arith = PBR_ARITH_NATIVE): what the reference literally asks its device
+// for — native_sin / native_cos / native_tan / native_recip / native_divide / native_sqrt / fast_normalize
+// (pt_utils.cl:39-44, pt_brdf.cl:306-321, pt_intersect.cl:104, pt_bvh.cl:83) — as the gfx950 instructions: v_sin_f32 /
+// v_cos_f32 on fract( x / 2 pi ), v_rcp_f32, v_sqrt_f32, v_rsq_f32, and pow through v_log_f32 / v_exp_f32 in binary32;
+// the translation unit is then also compiled with -fno-hip-fp32-correctly-rounded-divide-sqrt, so every `/` of the
+// kernels is a reciprocal-based division.  acos and atan keep their polynomials (the reference calls the full-precision
+// builtins there) over the native division and square root.  Images then agree with the exact mode statistically.
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include "pt_flavour.hpp"
 
 namespace ptm {
 
@@ -24,7 +34,13 @@ PT_DEV f3 yzx( f3 a ) { return mk3( a.y, a.z, a.x ); }
 PT_DEV float fma1( float a, float b, float c ) { return __builtin_fmaf( a, b, c ); }
 PT_DEV float fmin1( float a, float b ) { return __builtin_fminf( a, b ); }
 PT_DEV float fmax1( float a, float b ) { return __builtin_fmaxf( a, b ); }
+#if PT_ARITH_NATIVE
+PT_DEV float sqrt1( float a ) { return __builtin_amdgcn_sqrtf( a ); }
+PT_DEV float rsqrt1( float a ) { return __builtin_amdgcn_rsqf( a ); }
+#else
 PT_DEV float sqrt1( float a ) { return __builtin_sqrtf( a ); }
+PT_DEV float rsqrt1( float a ) { return 1.0f / __builtin_sqrtf( a ); }
+#endif
 PT_DEV float inff() { return __builtin_inff(); }
 
 // dot: z*z' + ( y*y' + x*x' ), two fmas
@@ -41,7 +57,7 @@ PT_DEV f3 cross( f3 a, f3 b ) {
 }
 
 PT_DEV f3 normalize( f3 a ) {
-	const float inv = 1.0f / sqrt1( dot( a, a ) );
+	const float inv = rsqrt1( dot( a, a ) );
 	return a * inv;
 }
 
@@ -66,6 +82,14 @@ PT_DEV float fract( float x ) {
 // ---- sin / cos -------------------------------------------------------------------------
 // k = rint( x * 2/pi ); r = x - k * pi/2 (three-part constant, fma); minimax on [-pi/4, pi/4].
 PT_DEV void sincos( float x, float* sn, float* cs ) {
+#if PT_ARITH_NATIVE
+	// v_sin_f32 / v_cos_f32 take revolutions and are defined on [-256, 256]: reduce with v_fract_f32 first (the RNG's seed
+	// grows by 1 per draw and by the hit distance per bounce, pt_utils.cl:39-44, pathtracing.cl:263)
+	const float turns = __builtin_amdgcn_fractf( x * 0x1.45f306p-3f );
+	*sn = __builtin_amdgcn_sinf( turns );
+	*cs = __builtin_amdgcn_cosf( turns );
+	return;
+#endif
 	if( !( __builtin_fabsf( x ) <= 1.0e8f ) ) {
 		x = x * 0.0f;
 	}
@@ -232,6 +256,10 @@ PT_DEV float pow1( float x, float y ) {
 		return sign;
 	}
 
+#if PT_ARITH_NATIVE
+	// v_log_f32 / v_exp_f32 ( log2( 0 ) = -inf, exp2( -inf ) = 0, log2( inf ) = inf )
+	return sign * __builtin_amdgcn_exp2f( y * __builtin_amdgcn_logf( ax ) );
+#endif
 	double l;
 
 	if( ax == 0.0f ) {

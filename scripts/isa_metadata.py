@@ -20,17 +20,30 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def code_object(lib, workdir):
+def code_objects(lib, workdir):
+    """Every gfx950 code object of the library: since round 5 it is linked from one translation unit per plan and build
+    flavour (build.py), each with its own offload bundle in .hip_fatbin."""
     fat = os.path.join(workdir, "fat.bin")
-    dev = os.path.join(workdir, "dev.co")
     subprocess.check_call([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, lib])
-    # the product is built for gfx950:xnack- since round 4 (build.py, HIP_FLAGS); older and lab libraries for plain gfx950
-    for target in ("hipv4-amdgcn-amd-amdhsa--gfx950:xnack-", "hipv4-amdgcn-amd-amdhsa--gfx950"):
-        done = subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
-                               "--targets=" + target, "--output=" + dev], capture_output=True, text=True)
-        if done.returncode == 0 and os.path.exists(dev) and os.path.getsize(dev) > 0:
-            return dev
-    raise RuntimeError("no gfx950 code object in %s: %s" % (lib, done.stderr))
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    out = []
+    for k, start in enumerate(starts):
+        part = os.path.join(workdir, "bundle%d.bin" % k)
+        with open(part, "wb") as f:
+            f.write(blob[start:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        dev = os.path.join(workdir, "dev%d.co" % k)
+        # the product is built for gfx950:xnack- since round 4 (build.py, HIP_FLAGS); older and lab libraries for plain gfx950
+        for target in ("hipv4-amdgcn-amd-amdhsa--gfx950:xnack-", "hipv4-amdgcn-amd-amdhsa--gfx950"):
+            done = subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part,
+                                   "--targets=" + target, "--output=" + dev], capture_output=True, text=True)
+            if done.returncode == 0 and os.path.exists(dev) and os.path.getsize(dev) > 0:
+                out.append(dev)
+                break
+    if not out:
+        raise RuntimeError("no gfx950 code object in %s" % lib)
+    return out
 
 
 def demangle(names):
@@ -80,13 +93,14 @@ def main():
             args.append(a)
     lib = args[0] if args else os.path.join(ROOT, "physically-based-rendering_amd", "csrc", "libpbrhip.so")
     with tempfile.TemporaryDirectory() as tmp:
-        dev = code_object(lib, tmp)
-        recs = kernels(dev)
+        devs = code_objects(lib, tmp)
+        recs = [r for dev in devs for r in kernels(dev)]
         if "--disasm" in sys.argv:
             out = sys.argv[sys.argv.index("--disasm") + 1]
             os.makedirs(out, exist_ok=True)
             with open(os.path.join(out, "gfx950.s"), "w") as f:
-                subprocess.check_call([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", dev], stdout=f)
+                for dev in devs:
+                    subprocess.check_call([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", dev], stdout=f)
     recs.sort(key=lambda r: r["kernel"])
     print("%-100s %5s %5s %5s %8s %8s %6s %9s %5s" % ("kernel", "VGPR", "AGPR", "SGPR", "LDS(st.)", "scratch", "spills", "code B", "w/SIMD"))
     for r in recs:
