@@ -501,7 +501,8 @@ int applyWalk( pbr_ctx* ctx, DevParams* P, uint32_t* hotAvail ) {
 		}
 	}
 
-	P->nodes = ctx->dNodesWalk + 2;   // behind the 32-byte header
+	P->nodes = ctx->dNodesWalk + 2;   // behind the 32-byte header ...
+	P->walkTable = (const int*) ctx->dNodesWalk;   // ... which the kernels read through a pointer of its own (DevParams)
 	P->firstRef = ctx->walkFirst[0];
 	P->walkScheme = (int) scheme;
 	*hotAvail = ctx->walkHotAvail;
@@ -1807,11 +1808,25 @@ struct DevBuf {
 	hipError_t alloc( size_t bytes ) { return hipMalloc( &p, bytes ? bytes : 4 ); }
 };
 
-DevParams sceneParams( pbr_ctx* ctx ) {
+// The scene for the diagnostic and denoise kernels.  They walk in the configured order (pbr_config.traversal) when its
+// streams can be built, in the reference's otherwise; hotAvail: the ranked prefix of that stream.
+DevParams sceneParams( pbr_ctx* ctx, uint32_t* hotAvail = nullptr ) {
 	DevParams P;
 	std::memset( &P, 0, sizeof( P ) );
+	uint32_t hot = 0;
+
+	if( applyWalk( ctx, &P, &hot ) != PBR_OK ) {
+		P.nodes = ctx->dNodes;
+		P.firstRef = ctx->firstRef;
+		P.walkScheme = 0;
+		hot = ctx->numHotAvail;
+	}
+
+	if( hotAvail != nullptr ) {
+		*hotAvail = hot;
+	}
+
 	P.parkEighths = 4;
-	P.nodes = ctx->dNodes;
 	P.tris = ctx->dTris;
 	P.faceN = ctx->dFaceN;
 	P.mats = ctx->dMats;
@@ -1821,7 +1836,6 @@ DevParams sceneParams( pbr_ctx* ctx ) {
 	P.numLights = (int) ctx->numLights;
 	P.numHot = 0;
 	P.numHotBytes = 0;
-	P.firstRef = ctx->firstRef;
 	return P;
 }
 
@@ -2300,7 +2314,8 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 	HIP_TRY( ctx, dOut.alloc( sizeof( float ) * 2 * (size_t) n ) );
 	HIP_TRY( ctx, hipMemcpy( dRays.p, rays8, sizeof( float ) * 8 * (size_t) n, hipMemcpyHostToDevice ) );
 
-	DevParams P = sceneParams( ctx );
+	uint32_t hotAvail = 0;
+	DevParams P = sceneParams( ctx, &hotAvail );
 	P.workCounter = ctx->dWork;
 	P.counters = ctx->dCounters;
 	ctx->workClean = false;   // this probe uses the queue heads its own way
@@ -2312,7 +2327,7 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 
 		// mode = number of hot nodes to stage in LDS (0 = none); 8 waves / SIMD => 2048 threads per CU
 		const int blocksPerCU = 2048 / PBR_BLOCK;
-		size_t slots = std::min<size_t>( (size_t) mode, ctx->numHotAvail );
+		size_t slots = std::min<size_t>( (size_t) mode, hotAvail );
 		slots = std::min<size_t>( slots, ( 160 * 1024 / (size_t) blocksPerCU - 256 ) / 32 );
 		P.numHot = (int) slots;
 		P.numHotBytes = (int) slots * 32;

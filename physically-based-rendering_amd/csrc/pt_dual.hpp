@@ -188,7 +188,7 @@ PT_DEV void nodePhaseDualPipe(
 		  [leafWordA] "+v"( leafWordA ), [tNearA] "+v"( tNearA ), [leafWordB] "+v"( leafWordB ), [tNearB] "+v"( tNearB )
 		: [oxyA] "v"( oxyA ), [ozzA] "v"( ozzA ), [ixyA] "v"( ixyA ), [izzA] "v"( izzA ), [rayTA] "v"( rayTA ),
 		  [oxyB] "v"( oxyB ), [ozzB] "v"( ozzB ), [ixyB] "v"( ixyB ), [izzB] "v"( izzB ), [rayTB] "v"( rayTB ),
-		  [keep] "s"( keep ), [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( scalarBase( P.nodes ) ), [eps] "s"( eps )
+		  [keep] "s"( keep ), [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps )
 		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
 		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
 		  "s80", "s81", "s82", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "vcc", "scc"

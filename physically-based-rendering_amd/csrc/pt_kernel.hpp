@@ -136,8 +136,10 @@ struct DevParams {
 	int firstRef;           // reference (byte offset) of node 1's record, where every walk starts (walkScheme 0)
 	int walkScheme;         // pbr_config.traversal: 0 the reference's one order; 1 six orders (dominant axis x sign of the ray direction),
 	                        // 2 eight (sign octant): `nodes` then holds one stream of records per order and a walk starts at walkFirst[order]
-	                        // — the eight references sit in the 32 bytes IN FRONT of `nodes` (as kernel arguments they were
-	                        // eight more live registers in every kernel: scalar values the compiler keeps in vector registers)
+	const int* walkTable;   // ... the eight first references (as eight kernel arguments they were eight more live registers in every
+	                        // kernel: scalar values the compiler keeps in vector registers).  They sit in the 32 bytes in front of
+	                        // `nodes`, but the kernels must reach them through a pointer of their own: a vector load based on
+	                        // `nodes` makes hipcc hand the node phases' "s"( P.nodes ) operand a vector register pair
 	int slotBase;           // LDS byte address of the per-lane state behind the staged prefix (= numHotBytes): pathTracingDual's path slots
 	int nFrames, firstCount;
 	int useExplicitWeight;
@@ -815,21 +817,6 @@ PT_DEV NodeLinks decodeNode( const float4 n1 ) {
 	return n;
 }
 
-// The node stream's base as a scalar register pair for the node phases' record loads.  It is a kernel argument and lives
-// in scalar registers already, where v_readfirstlane folds away; but in builds whose walk start reads the table in front
-// of the stream (PT_WALK_MODE 1) hipcc hands the assembly's "s" operand a VECTOR register pair — an invalid instruction —
-// unless the operand is scalar by construction.
-PT_DEV const float4* scalarBase( const float4* p ) {
-#if PT_WALK_MODE == 1
-	const unsigned long long bits = (unsigned long long) (size_t) p;
-	const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane( (int) (unsigned) bits );
-	const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane( (int) (unsigned) ( bits >> 32 ) );
-	return (const float4*) (size_t) ( ( (unsigned long long) hi << 32 ) | lo );
-#else
-	return p;
-#endif
-}
-
 // Which of the successor sets a ray walks (pbr_config.traversal; the statement both ends follow is in pbr_upload's
 // buildWalkStreams and in the oracle's "Ray-ordered walk").  Scheme 1: 2 * dominant axis (x before y before z on ties)
 // + ( dir[axis] < 0 ).  Scheme 2: the sign bits x | y << 1 | z << 2.
@@ -853,15 +840,12 @@ PT_DEV Cursor firstNode( const DevParams& P, const f3 dir ) {
 	(void) dir;
 	c.ref = P.firstRef;
 #elif PT_WALK_MODE == 1
-	// (as an instruction: written in C++ the load takes P.nodes into vector registers, and the hand-scheduled node phases
-	// need it as the scalar base of their record loads — hipcc then hands their "s" operand a vector register pair)
-	const int tableOffset = walkOrderOf( P.walkScheme, dir ) * 4;
-	asm volatile( "global_load_dword %0, %1, %2 offset:-32\n\ts_waitcnt vmcnt(0)" : "=v"( c.ref ) : "v"( tableOffset ), "s"( scalarBase( P.nodes ) ) : "memory" );
+	c.ref = P.walkTable[walkOrderOf( P.walkScheme, dir )];
 #else
 	c.ref = P.firstRef;
 
 	if( P.walkScheme != 0 ) {
-		c.ref = ( (const int*) P.nodes )[walkOrderOf( P.walkScheme, dir ) - 8];
+		c.ref = P.walkTable[walkOrderOf( P.walkScheme, dir )];
 	}
 #endif
 	return c;
@@ -987,7 +971,7 @@ PT_DEV void nodePhaseAsm(
 		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [leafTFar] "=v"( leafTFar ), [parked] "=v"( parked ), \
 		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [count] "=&s"( count ) \
 		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [keep] "s"( keep ), \
-		  [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( scalarBase( P.nodes ) ), [eps] "s"( eps ) \
+		  [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps ) \
 		: "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc"
 
 	if( ANYHIT ) {

@@ -137,6 +137,64 @@ def test_properties_at_full_size(pbr, oracle, device, name):
     assert after["paths"] - before["paths"] == w * h * 2
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_ray_ordered_walk_at_full_size(pbr, oracle, device, name, mode):
+    """pbr_config.traversal = six / eight orders at the configurations' own size (not a reference mode: the reference walks
+    one fixed order, pt_bvh.cl:102,112).  Two claims, whole frame each:
+      (1) HIP(ordered) == oracle(ordered) bit for bit — image, debug image (this walk's own counters), launch counters —
+          in the state machine, in the two-paths-per-lane plan and in whatever the tuner runs, and 8-way tile shards of it
+          re-assemble that frame;
+      (2) oracle(ordered) against oracle(reference order): SURVEY.md section 8(c)'s image tolerance, |d| <= 1e-4 per
+          channel on >= 99.5 % of the pixels and mean |d| <= 1e-5; the share of bit-identical pixels is printed (only
+          equal-distance hits — exact ties, coplanar faces — can differ), with fewer node visits and face tests."""
+    import torch
+    sc, cfg, cam, px, w, h = full_scene(pbr, name)
+    frames, ref_image, ref_debug, ref_counters = oracle_whole_frames(pbr, oracle, name)
+    seeds = pbr.frame_seeds(0, frames)
+    cfg.traversal = mode
+    walk = oracle.Renderer(sc.desc, cfg, threads=os.cpu_count() or 8)
+    image = walk.render(0, seeds, px, cam)
+    counters = walk.counter_dict()
+
+    with np.errstate(invalid="ignore"):
+        d = np.abs(image.astype(np.float64) - ref_image)[..., :3]
+    d[np.isnan(image[..., :3]) & np.isnan(ref_image[..., :3])] = 0.0
+    identical = np.all((image == ref_image) | (np.isnan(image) & np.isnan(ref_image)), axis=2).mean()
+    print("%s traversal %d: %.5f %% of %d pixels bit-identical to the reference order's, max |d| %.3g; node visits %.3fx, face tests %.3fx" % (
+        name, mode, 100 * identical, w * h, d.max(), counters["nodes"] / ref_counters["nodes"], counters["tris"] / ref_counters["tris"]))
+    assert (d.max(axis=2) <= 1e-4).mean() >= 0.995 and d.mean() <= 1e-5
+    assert identical >= 0.999
+    assert counters["paths"] == ref_counters["paths"]
+    assert counters["nodes"] < ref_counters["nodes"] and counters["tris"] < ref_counters["tris"]
+
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    for plan_name in ("phased-mid", "phased-dual", None):
+        device.pin_plan(PLANS.index(plan_name) if plan_name else -1)
+        device.reset_accum()
+        before = device.counters()
+        device.render(0, seeds, px, cam)
+        got, dbg = device.read_output(), device.read_debug()
+        spent = {k: v - before[k] for k, v in device.counters().items()}
+        assert same_values(got, image), "%s: %s" % (plan_name, describe_mismatch(got, image))
+        assert same_values(dbg, walk.debug), "%s debug: %s" % (plan_name, describe_mismatch(dbg, walk.debug))
+        assert spent == counters, (plan_name, spent, counters)
+
+    world, gathered = 8, None
+    for rank in range(world):
+        c = pbr.Config.from_buffer_copy(cfg)
+        c.tile_world, c.tile_rank = world, rank
+        device.configure(c)
+        device.render(0, seeds, px, cam)
+        if gathered is None:
+            gathered = torch.zeros(world * device.tile_bytes() // 4, dtype=torch.float32, device="cuda")
+        device.export_tiles(gathered.data_ptr() + rank * device.tile_bytes())
+    torch.cuda.synchronize()
+    device.import_tiles(gathered.data_ptr())
+    assert same_values(device.read_full(), image)
+
+
 @pytest.mark.parametrize("name", sorted(FULL))
 def test_eight_way_shards_equal_the_unsharded_frame(pbr, device, name):
     import torch

@@ -1,0 +1,193 @@
+"""The ray-ordered walk (pbr_config.traversal; oracle/pt_oracle.c "Ray-ordered walk") — NOT a reference algorithm: the
+reference walks its flat tree in one fixed order (pt_bvh.cl:102,112, accelstructures/BVH.cpp:335-343).  CPU only:
+
+  * the successor tables are the same tree, every order a depth-first sequence over all nodes with every container's
+    children permuted and nothing else;
+  * an ordered walk finds the reference walk's closest hits (same face, same t, bit for bit — only where two faces are hit
+    at the same distance, an exact tie or coplanar faces, may it report the other one) and agrees with a float64 brute
+    force over all triangles;
+  * whole oracle frames in either order agree within SURVEY.md section 8(c)'s tolerance (|d| <= 1e-4 on >= 99.5 % of the
+    pixels, mean |d| <= 1e-5); the share of bit-identical pixels is printed;
+  * an ordered walk visits fewer nodes, the way the review of round 4 measured it would.
+"""
+import numpy as np
+import pytest
+
+from conftest import same_values
+from test_oracle_kernel import brute_force_hits, random_rays
+
+SCHEMES = {1: 6, 2: 8}
+
+
+def scene(pbr, kind, seed, triangles, **keys):
+    pbr.cfg_set(**keys)
+    return pbr.HostScene.generate(kind, seed, triangles)
+
+
+def tree_of(arr):
+    """children[i] (DFS order) of every container of the flat array, from the statement in pt_oracle.c."""
+    bvh = arr["bvh"]
+    n = len(bvh)
+    leaf = bvh[:, 3] >= 0
+    end = np.zeros(n, np.int64)
+    stack = []
+    for i in range(n):
+        while stack and i >= end[stack[-1]]:
+            stack.pop()
+        if leaf[i]:
+            end[i] = i + 1
+        else:
+            link = int(bvh[i, 7])
+            end[i] = link if link > i else (end[stack[-1]] if stack else n)
+            stack.append(i)
+    children = {}
+    for i in range(n):
+        if not leaf[i]:
+            kids, c = [], i + 1
+            while c < end[i]:
+                kids.append(c)
+                c = end[c]
+            children[i] = kids
+    return leaf, children
+
+
+@pytest.mark.parametrize("scheme", sorted(SCHEMES))
+@pytest.mark.parametrize("kind,triangles,skip", [("cornell", 0, True), ("cornell", 0, False), ("sponza", 4000, True), ("hairball", 2500, True), ("dragon", 3000, False)])
+def test_every_order_is_the_same_tree_with_permuted_children(cfg_defaults, oracle, scheme, kind, triangles, skip):
+    sc = scene(cfg_defaults, kind, 3, triangles, **{"bvh.skip_ahead": skip})
+    arr = sc.arrays()
+    bvh = arr["bvh"]
+    n = len(bvh)
+    leaf, children = tree_of(arr)
+    links, first = oracle.walk_orders(sc.desc, scheme)
+    assert links.shape == (SCHEMES[scheme], n, 2)
+    key = bvh[:, 0:3] + bvh[:, 4:7]              # binary32 sums, as the statement has them
+    for k in range(SCHEMES[scheme]):
+        hit, nxt = links[k, :, 0], links[k, :, 1]
+        # leaves continue at next whether hit or not; node 0 (the root) is never visited and has no next
+        assert np.array_equal(hit[leaf], nxt[leaf])
+        assert nxt[0] == -1 and first[k] == hit[0]
+        # following hit (containers) / next (leaves) is a depth-first sequence over every node but the root, once each
+        seq, at = [], int(first[k])
+        while at > 0:
+            seq.append(at)
+            at = int(nxt[at] if leaf[at] else hit[at])
+            assert len(seq) < n
+        assert sorted(seq) == list(range(1, n))
+        # every container: hit = first child, the children chained by next, the last one's next = the container's own
+        for i, kids in children.items():
+            order, c = [], int(hit[i])
+            for _ in kids:
+                order.append(c)
+                c = int(nxt[c])
+            assert sorted(order) == kids, (k, i)
+            assert c == (int(nxt[i]) if i else -1)
+            if scheme == 1:
+                ks = key[order, k // 2]
+                assert np.all(np.diff(ks) <= 0) if k & 1 else np.all(np.diff(ks) >= 0), (k, i, ks)
+            else:
+                spread = key[kids].max(0) - key[kids].min(0)
+                axis = int(np.argmax(spread))    # first of equal maxima: x before y before z
+                ks = key[order, axis]
+                assert np.all(np.diff(ks) <= 0) if (k >> axis) & 1 else np.all(np.diff(ks) >= 0), (k, i, ks)
+    # opposite orders are mirror images where no keys tie (scheme 1: k ^ 1; scheme 2: all three bits flipped)
+    flip = 1 if scheme == 1 else 7
+    for i, kids in children.items():
+        if len(kids) == 2 and scheme == 1 and key[kids[0], 0] != key[kids[1], 0]:
+            assert links[0, i, 0] != links[0 ^ flip, i, 0]
+
+
+@pytest.mark.parametrize("scheme", sorted(SCHEMES))
+@pytest.mark.parametrize("kind,triangles,skip", [("cornell", 0, True), ("sponza", 6000, True), ("hairball", 3000, True), ("dragon", 5000, False)])
+def test_ordered_walk_finds_the_reference_walks_hits(cfg_defaults, oracle, scheme, kind, triangles, skip):
+    sc = scene(cfg_defaults, kind, 2, triangles, **{"bvh.skip_ahead": skip})
+    arr = sc.arrays()
+    lo, hi = arr["vertices"][:, :3].min(0) - 0.2, arr["vertices"][:, :3].max(0) + 0.2
+    rays = random_rays(np.random.default_rng(11), 4000, lo, hi)
+    rays[:6, 3:] = [[1, 0, 0], [0, -1, 0], [0, 0, 1], [-1, 0, 0], [0, 1, 0], [0, 0, -1]]      # 1 / 0 = inf in the slab test; -0 components
+    cfg = sc.config(64, 64)
+    t0, f0, n0, c0 = oracle.trace_rays(sc.desc, cfg, rays)
+    cfg.traversal = scheme
+    t1, f1, n1, c1 = oracle.trace_rays(sc.desc, cfg, rays)
+    hit = np.isfinite(t0)
+    assert hit.sum() > 300 and np.array_equal(hit, np.isfinite(t1))
+    other = hit & (f0 != f1)
+    # Another face only where two faces are hit at the same distance — an exact tie (intersectFace keeps the first of two
+    # equal t, pt_bvh.cl:20), or COPLANAR faces whose t differ in the last place (the Cornell box's blocks stand on its
+    # floor): whichever the walk meets first can cull the other's flat leaf box (ray.t > tNear, pt_bvh.cl:109).  Everywhere
+    # else: the same face at the same t, bit for bit.
+    assert same_values(t0[~other], t1[~other])
+    if other.any():
+        all_t = brute_force_hits(arr, rays[other])
+        i = np.arange(other.sum())
+        assert np.allclose(all_t[i, f1[other]], all_t[i, f0[other]], rtol=1e-6, atol=1e-7)
+        assert np.all(np.abs(t0[other] - t1[other]) <= 1e-6 * np.maximum(1.0, t0[other]))     # SURVEY 8(c)'s traversal tolerance
+    # (random origins INSIDE the Cornell box's blocks look at their coplanar undersides: 0.6 % of these rays; camera paths
+    # never do — the frame test below finds every pixel identical)
+    assert other.sum() <= (0.01 if kind == "cornell" else 0.002) * hit.sum()
+    same = hit & ~other
+    assert same_values(n0[same], n1[same])
+    # against first principles, like the reference-order walk (test_oracle_kernel.py)
+    sub = np.arange(300)
+    bt = brute_force_hits(arr, rays[sub]).min(axis=1)
+    both = np.isfinite(bt) & np.isfinite(t1[sub])
+    assert np.mean(np.isfinite(t1[sub][np.isfinite(bt)])) > 0.995
+    assert np.allclose(t1[sub][both], bt[both], rtol=2e-4, atol=2e-5)
+    assert (c1[:, 0] >= 1).all()
+
+
+@pytest.mark.parametrize("scheme", sorted(SCHEMES))
+@pytest.mark.parametrize("kind,triangles,brdf,lit", [("cornell", 0, 1, True), ("sponza", 9000, 1, False), ("dragon", 9000, 0, False), ("hairball", 7000, 1, False)])
+def test_frames_in_either_order_agree_within_the_stated_tolerance(cfg_defaults, oracle, scheme, kind, triangles, brdf, lit):
+    """|d| <= 1e-4 per channel on >= 99.5 % of the pixels and mean |d| <= 1e-5.  Only exact ties
+    of the closest hit can differ (intersectFace keeps the first of two equal t, pt_bvh.cl:20): expect 100 %."""
+    pbr = cfg_defaults
+    sc = scene(pbr, kind, 5, triangles, **{"render.max_depth": 4, "render.brdf": brdf})
+    w, h, frames = 96, 64, 3
+    desc, keep = sc.desc, None
+    cfg = sc.config(w, h)
+    if lit:
+        lights = np.zeros((2, 12), np.float32)
+        lights[0] = [0.1, 1.6, 0.2, 0, 4.0, 3.5, 3.0, 0, 2, 0.12, 0, 0]
+        lights[1] = [-0.5, 0.4, 0.6, 0, 1, 1, 1, 0, 1, 0, 0, 0]
+        desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
+        desc.lights, desc.num_lights = lights.ctypes.data, 2
+        keep = lights
+        cfg.shadow_rays = 1
+    cam, px, seeds = sc.camera(), pbr.pixel_dimension(w, h), pbr.frame_seeds(0, frames)
+    ref = oracle.Renderer(desc, cfg, threads=8)
+    a = ref.render(0, seeds, px, cam)
+    cfg.traversal = scheme
+    walk = oracle.Renderer(desc, cfg, threads=8)
+    b = walk.render(0, seeds, px, cam)
+    with np.errstate(invalid="ignore"):
+        d = np.abs(a.astype(np.float64) - b)[..., :3]
+    d[np.isnan(a[..., :3]) & np.isnan(b[..., :3])] = 0.0
+    identical = np.all((a == b) | (np.isnan(a) & np.isnan(b)), axis=2).mean()
+    print("%s scheme %d: %.4f %% of the pixels bit-identical, max |d| %.3g" % (kind, scheme, 100 * identical, d.max()))
+    assert (d.max(axis=2) <= 1e-4).mean() >= 0.995 and d.mean() <= 1e-5
+    assert identical >= 0.999
+    assert walk.counter_dict()["paths"] == ref.counter_dict()["paths"] and walk.counter_dict()["hits"] == ref.counter_dict()["hits"]
+    if kind != "cornell":
+        assert walk.counter_dict()["nodes"] < ref.counter_dict()["nodes"]
+        assert walk.counter_dict()["tris"] < ref.counter_dict()["tris"]
+
+
+def test_visit_savings_point_the_way_the_round_4_review_measured(cfg_defaults, oracle):
+    """VERDICT r04 item 1 measured 0.66x node visits / 0.56x face tests for six orders on the 2 M-triangle hairball (this
+    build's oracle: 0.667x / 0.571x, eight orders 0.554x / 0.461x — profiles/r05/experiments/traversal_order.txt).  The
+    saving grows with the depth of the tree; on a 200 k-triangle hairball of the same generator it is 0.87x / 0.83x and
+    0.82x / 0.77x, and eight orders save more than six."""
+    pbr = cfg_defaults
+    sc = scene(pbr, "hairball", 3, 200000, **{"render.max_depth": 3})
+    w, h = 96, 64
+    cam, px, seeds = sc.camera(), pbr.pixel_dimension(w, h), pbr.frame_seeds(0, 1)
+    counts = {}
+    for mode in (0, 1, 2):
+        cfg = sc.config(w, h)
+        cfg.traversal = mode
+        r = oracle.Renderer(sc.desc, cfg, threads=8)
+        r.render(0, seeds, px, cam)
+        counts[mode] = r.counter_dict()
+    assert counts[1]["nodes"] < 0.9 * counts[0]["nodes"] and counts[1]["tris"] < 0.9 * counts[0]["tris"]
+    assert counts[2]["nodes"] < 0.95 * counts[1]["nodes"] and counts[2]["tris"] < 0.95 * counts[1]["tris"]
