@@ -1118,7 +1118,9 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 // Geometric normal of a face: fast_normalize( cross( edge1, edge2 ) ), pt_intersect.cl:122
 template<bool STORED = false>
 PT_DEV f3 faceNormal( const DevParams& P, int face, int* material ) {
-	if( STORED && P.faceN != nullptr ) {
+	// (native arithmetic: every plan recomputes — the stored normals are prepareFaceNormals' exact ones, and the plans of a
+	// mode must agree on the bits so that the tuner's choice never shows in the image)
+	if( STORED && !PT_ARITH_NATIVE && P.faceN != nullptr ) {
 		const float4 r = P.faceN[face];
 		*material = __float_as_int( r.w );
 		return mk3( r.x, r.y, r.z );
@@ -1840,6 +1842,16 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 			finalColor = mk3( finalColor.x / ns, finalColor.y / ns, finalColor.z / ns );
 		}
 
+#if PT_ARITH_NATIVE
+		// Native arithmetic only: a frame whose colour is not finite contributes black.  Measured on the Cornell box with
+		// BRDF 0: 3 of 3.1 M single-sample frames come out NaN with v_sin / v_cos / v_sqrt / v_rsq where the exact arithmetic
+		// has none (a hardware sine that is exactly 0, a square root of a quotient an ulp out of range) — and the reference's
+		// running mean (pt_rgb.cl:9-21) would carry one such sample through every later frame of that pixel.  The exact mode
+		// never does this: there a NaN is the reference's NaN.
+		if( !( __builtin_fabsf( finalColor.x + finalColor.y + finalColor.z ) < inff() ) ) {
+			finalColor = mk3( 0.0f, 0.0f, 0.0f );
+		}
+#endif
 		// the unit ends here; foldFrames applies the running mean (setColors) in frame order
 		P.frameBuf[frameBufIndex( P, st.slot, (unsigned) st.frame )] = make_float4( finalColor.x, finalColor.y, finalColor.z, st.focus );
 		cnt.nodes += st.dbgNodes;

@@ -130,6 +130,11 @@ PT_DEV float asin_core( float x ) {
 }
 
 PT_DEV float acos1( float x ) {
+#if PT_ARITH_NATIVE
+	// a quotient that is <= 1 in exact arithmetic (pt_brdf.cl:197: a / ( rough - a * rough + a )) can come out an ulp above it
+	// from a reciprocal-based division, and acos of that is NaN: one v_med3_f32
+	x = __builtin_amdgcn_fmed3f( x, -1.0f, 1.0f );
+#endif
 	if( x < -0.5f ) {
 		return 0x1.921fb6p+1f - 2.0f * asin_core( sqrt1( 0.5f * ( 1.0f + x ) ) );
 	}
