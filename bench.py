@@ -24,6 +24,12 @@ data path; the timed region ends with one RCCL all-gather of the compact tile bu
 (W*H*16/N bytes per rank) and the scatter into the full frame.  The total work is fixed, so
 this is strong scaling.
 
+Two opt-in modes of round 5 (include/pbr_hip.h, pbr_config): `--traversal six-order | eight-order` walks the same flat BVH
+with every container's children ordered along the ray (same closest hits; fewer visits), `--arith native` computes with
+gfx950's native sin / cos / rcp / sqrt / log / exp (statistical parity).  The default — the reference's one walk order and
+the exact arithmetic, bit-identical to the oracle — is the headline; `config.traversal` / `config.arith` name the mode of a line.
+`--force-dist` runs the collective leg with one rank (a real RCCL communicator and all-gather on one device).
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -89,7 +95,7 @@ def library_stamp():
         return None
 
 
-def recorded_traffic(scene, w, h, depth, brdf):
+def recorded_traffic(scene, w, h, depth, brdf, traversal=0, arith=0):
     """Fabric-side bytes PER SAMPLE from the committed PMC passes (profiles/rNN/pmc_traffic.json: rocprofv3 --pmc in
     separate runs; read = 128 x TCC_EA0_RDREQ_128B + 64 x _64B + 32 x _32B = 2 x FETCH_SIZE[KB] x 1024 on gfx950,
     write = WRITE_SIZE, calibrated with scripts/calibrate.py) of the newest round that profiled exactly this workload;
@@ -102,12 +108,13 @@ def recorded_traffic(scene, w, h, depth, brdf):
         except (OSError, ValueError):
             continue
         for key, rec in records.items():      # keys: the scene, or scene_suffix for another size of it ("hairball_4k")
-            if rec.get("scene", key.split("_")[0]) == scene and (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) == (w, h, depth, brdf):
+            if rec.get("scene", key.split("_")[0]) == scene and (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) == (w, h, depth, brdf) \
+                    and (rec.get("traversal", 0), rec.get("arith", 0)) == (traversal, arith):
                 return dict(rec, source=os.path.relpath(path, ROOT))
     return None
 
 
-def roofline_block(scene, plan, traffic, algo_launch, per_launch_samples, kernel_s, stamp="unchecked"):
+def roofline_block(scene, plan, traffic, algo_launch, per_launch_samples, kernel_s, stamp="unchecked", kernel=None):
     """The roofline of the dominant kernel, physical: `achieved` = bytes the memory system moved behind L2 for one launch
     (fabric reads + writes from the committed PMC passes of this workload — `traffic`, a record of
     profiles/rNN/pmc_traffic.json — Infinity-Cache hits included, scaled to this run's samples) / the launch's duration
@@ -117,7 +124,9 @@ def roofline_block(scene, plan, traffic, algo_launch, per_launch_samples, kernel
     lives in L2 / Infinity Cache."""
     roofline = {
         "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-        "kernel": "ptk::pathTracingPhased" if plan.startswith("phased") else "ptk::pathTracing", "launch_ms": kernel_s * 1e3,
+        # the symbol of the kernel that ran, from the library (pbr_diag_last_kernel) — round 4 derived a name from the plan's
+        # and printed pathTracingPhased for a launch of pathTracingDual (VERDICT r04)
+        "kernel": kernel, "launch_ms": kernel_s * 1e3,
         "algorithmic_bytes_per_launch": algo_launch, "algorithmic_GBs": algo_launch / kernel_s / 1e9,
         "bound_measured": None,      # no counters, no claim
     }
@@ -158,8 +167,15 @@ def roofline_block(scene, plan, traffic, algo_launch, per_launch_samples, kernel
         }
     if traffic.get("l2_requests_per_launch"):
         req = traffic["l2_requests_per_launch"] * scale
-        roofline["l2"] = {"requests_per_s": req / kernel_s, "peak": L2_REQUEST_CEILING, "frac": min(1.0, req / kernel_s / L2_REQUEST_CEILING),
+        l2_frac = req / kernel_s / L2_REQUEST_CEILING
+        roofline["l2"] = {"requests_per_s": req / kernel_s, "peak": L2_REQUEST_CEILING, "frac": l2_frac,
+                          # raw, never clamped: above 1 the measured ceiling, or the scaling of the profiled
+                          # counters, is wrong for this workload, and that must stay visible
+                          "exceeds_measured_ceiling": bool(l2_frac > 1.0),
                           "hit_rate": traffic.get("l2_hit_rate"),
+                          # requests between L1 and L2 priced at a 128-B line each, over the algorithmic bytes:
+                          # how many times the contract's traffic the L1s ask the L2s for (hairball, round 4: 2.2)
+                          "l1_l2_amplification": req * 128.0 / algo_launch,
                           "note": "TCC_REQ per second against the request rate of dependent random 32-B gathers from an L2-resident table (scripts/micro/gather_rate.hip under rocprofv3 --pmc TCC_REQ_sum)"}
     verdict = measured_bound(roofline["frac"], roofline.get("l2", {}).get("frac"), roofline.get("issue", {}).get("valu_busy"))
     roofline["bound_measured"] = {
@@ -239,23 +255,54 @@ def launch_ranks(n, argv, popen=subprocess.Popen, environ=None):
         # hipIpcGetMemHandle: invalid argument"; the variable is exported on the pool's boxes already).  This build has
         # never had two devices to exercise it on: it is passed on, not verified.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # every rank in its own session: the parent can end a rank AND whatever it started (start_new_session)
+        # every rank in its own session = its own process group: end_ranks signals the GROUP (os.killpg), so the parent ends
+        # a rank AND whatever it started; and a rank asks the kernel for SIGTERM when this parent dies (BENCH_PARENT_PID ->
+        # die_with_parent: prctl PR_SET_PDEATHSIG), so that a parent killed outright (SIGKILL, OOM) leaves no orphans holding
+        # the GPUs in a half-finished all-gather
+        env["BENCH_PARENT_PID"] = str(os.getpid())
         procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                            stdout=None if rank == 0 else sys.stderr, start_new_session=True))
     return procs
 
 
+def die_with_parent():
+    """A self-launched rank: SIGTERM from the kernel when the launching parent dies, however it dies."""
+    parent = os.environ.get("BENCH_PARENT_PID")
+    if not parent:
+        return
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG
+    except (OSError, AttributeError):
+        pass
+    if os.getppid() != int(parent):     # it died between our start and the prctl
+        sys.exit(143)
+
+
+def signal_rank(p, sig):
+    """Signal a rank's whole process group (it leads its own session); the bare PID where there is no group to address."""
+    try:
+        os.killpg(p.pid, sig)
+    except (ProcessLookupError, PermissionError, OSError, AttributeError):
+        try:
+            p.send_signal(sig)
+        except (ProcessLookupError, OSError):
+            pass
+
+
 def end_ranks(procs, grace_s=10.0):
-    """Terminate the ranks that still run (their exact PIDs), wait, then kill what is left."""
+    """Terminate the ranks that still run — each rank's own process group, by its exact id — wait, then kill what is left."""
+    import signal
     for p in procs:
         if p.poll() is None:
-            p.terminate()
+            signal_rank(p, signal.SIGTERM)
     deadline = time.monotonic() + grace_s
     for p in procs:
         try:
             p.wait(timeout=max(0.0, deadline - time.monotonic()))
         except subprocess.TimeoutExpired:
-            p.kill()
+            signal_rank(p, signal.SIGKILL)
     for p in procs:
         if p.poll() is None:
             try:
@@ -264,16 +311,16 @@ def end_ranks(procs, grace_s=10.0):
                 pass
 
 
-def wait_ranks(procs, poll_s=0.05, limit_s=None):
-    """Wait for every rank; the first one that fails ends the others (their exact PIDs), and its code is the run's.
-    SIGTERM / SIGINT to this parent (a `timeout` around `python bench.py --gpus 8` signals only the parent) end the ranks
-    before the parent exits — no orphans holding the GPUs in a half-finished all-gather —, and so does the wall-clock
-    limit `limit_s`, after which the run fails with code 124 (ADVICE r03)."""
+_STOP = {"signal": None}
+
+
+def arm_signals():
+    """SIGTERM / SIGINT handlers of the parent, installed BEFORE the ranks are started (a signal that arrives while they
+    start is then seen by wait_ranks' first poll, not lost).  Returns the previous handlers."""
     import signal
-    stop = {"signal": None}
 
     def on_signal(signum, _frame):
-        stop["signal"] = signum
+        _STOP["signal"] = signum
 
     previous = {}
     for sig in (signal.SIGTERM, signal.SIGINT):
@@ -281,6 +328,18 @@ def wait_ranks(procs, poll_s=0.05, limit_s=None):
             previous[sig] = signal.signal(sig, on_signal)
         except ValueError:          # not the main thread (tests): no handlers, the rest works as before
             pass
+    return previous
+
+
+def wait_ranks(procs, poll_s=0.05, limit_s=None, previous=None):
+    """Wait for every rank; the first one that fails ends the others (their exact PIDs), and its code is the run's.
+    SIGTERM / SIGINT to this parent (a `timeout` around `python bench.py --gpus 8` signals only the parent) end the ranks
+    before the parent exits — no orphans holding the GPUs in a half-finished all-gather —, and so does the wall-clock
+    limit `limit_s`, after which the run fails with code 124 (ADVICE r03)."""
+    import signal
+    stop = _STOP
+    if previous is None:
+        previous = arm_signals()
     code, started = 0, time.monotonic()
     try:
         while any(p.poll() is None for p in procs):
@@ -327,6 +386,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="repetitions of the K-step render (0 = until 250 ms have been timed, at most 15); the median is reported")
     ap.add_argument("--plan", type=int, default=-1,
                     help="pin schedule 0..6 (refill-lean, refill-wide, phased-lean, phased-wide, phased-mid, refill-mid, phased-dual) instead of tuning; profiling runs")
+    ap.add_argument("--traversal", default="reference", choices=["reference", "six-order", "eight-order"],
+                    help="pbr_config.traversal: the reference's one walk order (default, the headline), or the opt-in ray-ordered walk over the same flat BVH")
+    ap.add_argument("--arith", default="exact", choices=["exact", "native"],
+                    help="pbr_config.arith: every builtin one exact definition (default, the headline), or gfx950's native sin / cos / rcp / sqrt / log / exp")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: run the multi-GPU leg all the same — init_process_group(backend, world_size=1), the all-gather on pbr_export_tiles / pbr_import_tiles device pointers — and check the gathered frame")
     ap.add_argument("--dump", default="", help="rank 0 writes the gathered / rendered frame to this .npy")
     ap.add_argument("--rank-limit", type=float, default=1500.0, help="self-launched ranks (--gpus N without a launcher): wall-clock seconds after which the parent ends them and fails")
     ap.add_argument("--hold-seconds", type=float, default=3.0, help="N = 1: keep the GPU rendering (untimed) this long after the timed region, so that an outside utilisation sampler sees the GPU leg at all")
@@ -337,7 +402,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes the parent of N ranks.  Nothing GPU-related has been imported yet.
-        sys.exit(wait_ranks(launch_ranks(args.gpus, sys.argv[1:]), limit_s=args.rank_limit))
+        previous = arm_signals()
+        sys.exit(wait_ranks(launch_ranks(args.gpus, sys.argv[1:]), limit_s=args.rank_limit, previous=previous))
+    die_with_parent()
     if world != args.gpus:
         args.gpus = world
 
@@ -345,12 +412,21 @@ def main():
     pbr = pbr_loader.load()
 
     dist = torch = None
-    if world > 1:
+    multi = world > 1 or args.force_dist          # the collective leg runs (N = 1 with --force-dist: a one-rank RCCL communicator)
+    if multi:
         import torch
         import torch.distributed as dist
         if args.one_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
+        if "MASTER_ADDR" not in os.environ:      # --force-dist without a launcher: a rendezvous of one
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            holder = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            holder.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            holder.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(holder.getsockname()[1])
+            _PORT_HOLDERS.append(holder)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     kind, seed, triangles, depth, label = WORKLOADS[args.scene]
@@ -365,6 +441,8 @@ def main():
     w, h = args.width, args.height
     cfg, cam, px = scene.config(w, h), scene.camera(), pbr.pixel_dimension(w, h)
     cfg.tile_world, cfg.tile_rank = world, rank
+    cfg.traversal = {"reference": 0, "six-order": 1, "eight-order": 2}[args.traversal]
+    cfg.arith = {"exact": 0, "native": 1}[args.arith]
 
     dev = pbr.Device(local_rank)
     dev.upload_scene(scene.desc)
@@ -378,20 +456,20 @@ def main():
         baseline = cpu_baseline(pbr, scene, scene.config(w, h), cam, px, args.cpu_seconds)
 
     gather_out = gather_in = None
-    if world > 1:
+    if multi:
         n_floats = dev.tile_bytes() // 4
         gather_in = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
         gather_out = torch.zeros(n_floats * world, dtype=torch.float32, device="cuda")
 
     def sync():
-        if world > 1:
+        if multi:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
     def gather():
         # every rank's accumulated tiles -> the full frame on every rank: the one collective of the path (RCCL all-gather)
-        if world == 1:
+        if not multi:
             return
         dev.export_tiles(gather_in.data_ptr())
         if args.backend == "nccl":
@@ -422,7 +500,7 @@ def main():
             if setup_frames >= 4 * budget:
                 break
     plan_votes = None
-    if world > 1 and not forced:
+    if multi and not forced:
         where = "cuda" if args.backend == "nccl" else "cpu"
         mine = torch.tensor([dev.last_plan()[1]], dtype=torch.int32, device=where)
         votes = torch.zeros(world, dtype=torch.int32, device=where)
@@ -454,18 +532,26 @@ def main():
         runs.append({"elapsed": elapsed, "render": t_render, "kernel_ms": kernel_ms, "trace_ms": trace_ms, "launches": trace_launches})
         first += args.steps
         more = (len(runs) < args.repeats) if args.repeats > 0 else (sum(r["elapsed"] for r in runs) < 0.25 and len(runs) < 15)
-        if world > 1:                                  # every rank must take the same decision
+        if multi:                                      # every rank must take the same decision
             flag = torch.tensor([1 if more else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
             dist.broadcast(flag, src=0)
             more = bool(int(flag[0]))
         if not more:
             break
     plan, tuned = dev.last_plan()
+    kernel_name = dev.last_kernel()
+    fit = dev.launch_fit()
     repeats = len(runs)
+    gathered_ok = None
+    if args.force_dist and world == 1:
+        # the gathered frame (all-gather of one rank's tiles, scattered by pbr_import_tiles) must be the rendered frame
+        gathered_ok = bool(np.array_equal(dev.read_full(), dev.read_output(), equal_nan=True))
+        if not gathered_ok:
+            raise SystemExit("bench.py --force-dist: the frame behind the %s all-gather differs from the rendered one" % args.backend)
 
     counters = diff(dev.counters(), before)
     if rank == 0 and args.dump:
-        np.save(args.dump, dev.read_full() if world > 1 else dev.read_output())
+        np.save(args.dump, dev.read_full() if multi else dev.read_output())
     # untimed: keep rendering for --hold-seconds, so that a sampler with a period of a second or two sees the GPU leg at all
     # (the timed region of the driver's command is 0.3 s)
     held_frames = 0
@@ -478,7 +564,7 @@ def main():
     per_run = [[r["elapsed"], r["trace_ms"] / r["launches"] / 1e3, r["render"], r["elapsed"] - r["render"]] for r in runs]
     totals = [float(counters["nodes"]), float(counters["tris"]), float(counters["hits"]), float(counters["paths"])]
     rank_ms = None
-    if world > 1:
+    if multi:
         where = "cuda" if args.backend == "nccl" else "cpu"
         t = torch.tensor(per_run, dtype=torch.float64, device=where)
         tmax = t.clone()
@@ -505,8 +591,8 @@ def main():
         # per launch of the dominant kernel (the path-tracing kernel the auto-tuner settled on): each rank runs
         # trace_launches of them per render; the slowest rank's average launch duration
         algo_launch = algo / world / trace_launches          # SURVEY 8(d)'s per-sample figure x the samples one launch processes
-        traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf))
-        roofline = roofline_block(args.scene, plan, traffic, algo_launch, samples / world / trace_launches, kernel_s, stamp=library_stamp())
+        traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), int(cfg.traversal), int(cfg.arith))
+        roofline = roofline_block(args.scene, plan, traffic, algo_launch, samples / world / trace_launches, kernel_s, stamp=library_stamp(), kernel=kernel_name)
         out = {
             "metric": "Msamples/s (paths/s) @1080p fixed seed; 1/2/4/8 MI355X scaling",
             "value": samples / elapsed / 1e6,
@@ -527,6 +613,8 @@ def main():
                 "max_added_depth": int(cfg.max_added_depth), "brdf": int(cfg.brdf),
                 "seeds": "seed_k = 0.0333 * (k + 1)", "tiles": "8x8 px, dealt round-robin to %d rank(s) along rows rotated by 5 * row columns" % world,
                 "host_bvh_build_s": round(t_build, 3),
+                # the two opt-in modes of round 5 (include/pbr_hip.h); "reference" / "exact" is the reference's behaviour and the headline
+                "traversal": args.traversal, "arith": args.arith,
             },
             "repeats": repeats, "ms_per_step_all": [round(r[0] * 1e3 / args.steps, 5) for r in per_run],
             "setup_frames": setup_frames, "setup_s": round(t_setup, 3),
@@ -537,8 +625,22 @@ def main():
             },
             "roofline": roofline,
         }
+        if fit is not None:
+            # what the schedule tuner measured on rank 0: a launch of n frames costs fixed + n x per_frame
+            out["launch_fit_ms"] = {"fixed": round(fit[0], 4), "per_frame": round(fit[1], 5)}
         if rank_ms is not None:
             out["per_rank_ms"] = rank_ms
+            # How far from linear a split of this render CAN be: every rank's launch carries the same fixed cost D (ramp-up
+            # + the drain of its longest paths, independent of N) next to 1 / N of the work W, so N ranks reach
+            # ( W + D ) / ( W + N D ) of N x one GPU.  W from the slowest rank's measured render R: W = N ( R - D ).
+            if fit is not None and world > 1:
+                R, D = max(rank_ms["render"]), fit[0]
+                W = world * max(R - D, 0.0)
+                out["expected_linear_frac"] = round((W + D) / (W + world * D), 4) if W + world * D > 0 else None
+                out["expected_linear_frac_note"] = "( W + D ) / ( W + N D ): D = rank 0's fitted fixed cost per launch, W = N ( slowest rank's render - D ); the all-gather is not in it"
+        if gathered_ok is not None:
+            out["force_dist"] = {"backend": args.backend, "world_size": world, "gathered_frame_equals_rendered": gathered_ok,
+                                 "gather_ms": round(per_run[median][3] * 1e3, 3)}
         if plan_votes is not None:
             out["plan_votes"] = plan_votes
         if baseline is not None:
@@ -546,7 +648,7 @@ def main():
         out["held_frames_untimed"] = held_frames
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     dev.close()
 

@@ -46,6 +46,16 @@ int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t r
  * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
 int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
 
+/* The kernel behind pbr_diag_last_plan's schedule, as a profiler prints its symbol (without "void " and the argument
+ * list): "ptk_f0::pathTracingDual<1, false, false>" — namespace ptk_f<flavour> (bit 0: ray-ordered walk, bit 1: native
+ * arithmetic; csrc/pt_flavour.hpp), template arguments BRDF, SHADOW_RAYS, LIGHTS[, waves per SIMD[, PHONGTESS]]. */
+int pbr_diag_last_kernel( pbr_ctx* ctx, char* name, size_t capacity );
+
+/* What the schedule tuner measured for the plan in use: a launch of n frames costs fixed_ms + n * per_frame_ms (least
+ * squares over its refinement launches of two lengths; fixed_ms = the ramp-up of a launch and the drain of its longest
+ * paths).  PBR_ESTATE when there is no such fit (plan pinned before the tuner ran, single-length launches only). */
+int pbr_diag_launch_fit( pbr_ctx* ctx, double* fixed_ms, double* per_frame_ms );
+
 /* Experiment and test knobs, per context; value -1 = the built-in default.  The library reads NO environment variable:
  * lab scripts and tests that need a knob set it here (the Python harness maps PBR_* variables onto this call).
  *   "lds_slots"     cap of the node records a block stages in LDS (0 = none)

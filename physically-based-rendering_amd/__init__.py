@@ -134,6 +134,8 @@ hip.pbr_diag_guard_trips.argtypes = [_vp, _up]
 hip.pbr_diag_last_trace.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
 hip.pbr_diag_last_plan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
 hip.pbr_diag_pin_plan.argtypes = [_vp, ctypes.c_int]
+hip.pbr_diag_last_kernel.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
+hip.pbr_diag_launch_fit.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
 if hasattr(hip, "pbr_diag_set_knob"):       # absent from round 2's library (A/B runs against it: PBR_HIP_LIB)
     hip.pbr_diag_set_knob.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int]
 hip.pbr_diag_tune_budget.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint32)]
@@ -301,7 +303,6 @@ class HostScene:
 # the process is a lab run (round 4: a stray PBR_* variable in a user's environment must not change the schedule of a
 # product render; scripts/*.py and scripts/*.sh set PBR_LAB_ENV themselves).
 _ENV_KNOBS = {
-    "PBR_ASYNC_EIGHTHS": "async_eighths",
     "PBR_LDS_SLOTS": "lds_slots", "PBR_BLOCKS_PER_CU": "blocks_per_cu", "PBR_PH_PARK": "ph_park", "PBR_PH_SHADE": "ph_shade",
     "PBR_PARK_EIGHTHS": "park_eighths", "PBR_DRAIN_MODE": "drain_mode", "PBR_REFILL_BATCH": "refill_batch",
     "PBR_CHUNK_FRAMES": "chunk_frames", "PBR_FACE_NORMALS": "face_normals", "PBR_PLOC_RADIUS": "ploc_radius", "PBR_TUNE_LOG": "tune_log",
@@ -493,6 +494,19 @@ class Device:
         name, tuned = ctypes.create_string_buffer(48), ctypes.c_int(-1)
         self._check(hip.pbr_diag_last_plan(self._ctx, name, 48, ctypes.byref(tuned)))
         return name.value.decode(), int(tuned.value)
+
+    def last_kernel(self):
+        """The symbol of the kernel behind last_plan()[0], as a profiler prints it: "ptk_f0::pathTracingDual<1, false, false>"."""
+        name = ctypes.create_string_buffer(96)
+        self._check(hip.pbr_diag_last_kernel(self._ctx, name, 96))
+        return name.value.decode()
+
+    def launch_fit(self):
+        """(fixed ms, ms per frame) of a launch of the plan in use, as the schedule tuner fitted them; None without a fit."""
+        a, b = ctypes.c_double(), ctypes.c_double()
+        if hip.pbr_diag_launch_fit(self._ctx, ctypes.byref(a), ctypes.byref(b)) != PBR_OK:
+            return None
+        return float(a.value), float(b.value)
 
     PLAN_NAMES = ("refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid", "phased-dual")
 

@@ -33,6 +33,7 @@ struct Plan {
 	int blocks = 0, blockThreads = 0, numHot = 0, park = 0, shade = 0, parkEighths = 4;
 	size_t ldsBytes = 0;
 	const char* name = "";
+	char kernelName[96] = "";   // the kernel's symbol as a profiler prints it (without "void " and the argument list)
 };
 
 // Experiment and test knobs (pbr_diag_set_knob, include/pbr_hip_diag.h): per context, -1 = the built-in value.  This
@@ -117,6 +118,7 @@ struct pbr_ctx {
 	uint32_t refineRounds = 1;                      // 1; 2 once a close call (best two within 5 %) has been given a second palindrome
 	double refineFit[7][5] = {};                    // per finalist, over its refinement launches: sums of 1, n, n^2, ms, n * ms (n = frames of the launch)
 	char lastPlan[48] = "";        // name of the plan that rendered the largest chunk of the last render
+	char lastKernel[96] = "";      // ... and its kernel
 	double lastTraceMs = 0.0;      // of the last render: time inside the path-tracing launches only ...
 	uint32_t lastTraceLaunches = 0; // ... and how many there were (frame-parallel renders are chunked)
 	float* dSeeds = nullptr;
@@ -672,7 +674,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	// split between the blocks the register budget admits.  The experiment knobs (PBR_BLOCKS_PER_CU, PBR_LDS_SLOTS,
 	// PBR_PH_PARK, PBR_PH_SHADE, PBR_PARK_EIGHTHS, PBR_DRAIN_MODE) are read when the plans are built — once per
 	// scene + configuration — not per launch.
-	auto makePlan = [&]( KernelFn kernel, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK, size_t pathSlotBytes = 0 ) -> int {
+	auto makePlan = [&]( int group, const char* name, int park, int shade, Plan* plan, int blockThreads = PBR_BLOCK, size_t pathSlotBytes = 0 ) -> int {
+		const KernelFn kernel = pickKernel( flavour, group, ctx->cfg.brdf, shadow, lights );
+
 		if( kernel == nullptr ) {
 			return fail( ctx, PBR_ESTATE, "plan %s: this library was built without that kernel (flavour %d)", name, flavour );
 		}
@@ -727,6 +731,20 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		}
 
 		plan->name = name;
+		// the symbol as rocprofv3 prints it (pt_instance.hip instantiates exactly these; namespaces: pt_flavour.hpp)
+		const char* const tf[2] = { "false", "true" };
+		const int minw[PTI_GROUPS] = { 4, 6, 8, 4, 4, 6, 8, 0 };
+
+		if( group == PTI_DUAL ) {
+			std::snprintf( plan->kernelName, sizeof( plan->kernelName ), "ptk_f%d::pathTracingDual<%u, %s, %s>", flavour, ctx->cfg.brdf, tf[shadow], tf[lights] );
+		}
+		else if( group >= PTI_PHASED_LEAN ) {
+			std::snprintf( plan->kernelName, sizeof( plan->kernelName ), "ptk_f%d::pathTracingPhased<%u, %s, %s, %d>", flavour, ctx->cfg.brdf, tf[shadow], tf[lights], minw[group] );
+		}
+		else {
+			std::snprintf( plan->kernelName, sizeof( plan->kernelName ), "ptk_f%d::pathTracing<%u, %s, %s, %d, %s>", flavour, ctx->cfg.brdf, tf[shadow], tf[lights], minw[group], tf[group == PTI_REFILL_PHONG] );
+		}
+
 		return PBR_OK;
 	};
 
@@ -779,20 +797,18 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	const uint32_t kRefineShort = 4 * tuneScale, kRefineLong = 12 * tuneScale;     // refinement: two chunks of each length per plan
 	const uint32_t kRefinePasses = 4;
 	if( !ctx->plansBuilt ) {
-		const uint32_t brdf = ctx->cfg.brdf;
 		Plan* plans = ctx->plans;
-		auto kernelOf = [&]( int group ) { return pickKernel( flavour, group, brdf, shadow, lights ); };
-		int status = makePlan( kernelOf( PTI_REFILL_LEAN ), "refill-lean", 0, 0, &plans[0] );
-		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_REFILL_WIDE ), "refill-wide", 0, 0, &plans[1] );
-		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_PHASED_LEAN ), "phased-lean", 16, 32, &plans[2] );
-		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_PHASED_WIDE ), "phased-wide", 16, 48, &plans[3] );
-		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_PHASED_MID ), "phased-mid", 16, 40, &plans[4], kMidBlockThreads );
-		status = ( status != PBR_OK ) ? status : makePlan( kernelOf( PTI_REFILL_MID ), "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
+		int status = makePlan( PTI_REFILL_LEAN, "refill-lean", 0, 0, &plans[0] );
+		status = ( status != PBR_OK ) ? status : makePlan( PTI_REFILL_WIDE, "refill-wide", 0, 0, &plans[1] );
+		status = ( status != PBR_OK ) ? status : makePlan( PTI_PHASED_LEAN, "phased-lean", 16, 32, &plans[2] );
+		status = ( status != PBR_OK ) ? status : makePlan( PTI_PHASED_WIDE, "phased-wide", 16, 48, &plans[3] );
+		status = ( status != PBR_OK ) ? status : makePlan( PTI_PHASED_MID, "phased-mid", 16, 40, &plans[4], kMidBlockThreads );
+		status = ( status != PBR_OK ) ? status : makePlan( PTI_REFILL_MID, "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
 		// 28 of a wave's up to 128 walks leave a node phase before it ends; a shade phase waits for 48 lanes (measured:
 		// profiles/r04/experiments/two_paths_per_lane.txt).  Without the hand-scheduled node phase: phased-mid's kernel and thresholds.
 		status = ( status != PBR_OK ) ? status : ( kDualIsDual
-			? makePlan( kernelOf( PTI_DUAL ), "phased-dual", 28, 48, &plans[6], PBR_BLOCK, (size_t) 2 * 4 * 16 * PBR_BLOCK )
-			: makePlan( kernelOf( PTI_PHASED_MID ), "phased-dual", 16, 40, &plans[6], kMidBlockThreads ) );
+			? makePlan( PTI_DUAL, "phased-dual", 28, 48, &plans[6], PBR_BLOCK, (size_t) 2 * 4 * 16 * PBR_BLOCK )
+			: makePlan( PTI_PHASED_MID, "phased-dual", 16, 40, &plans[6], kMidBlockThreads ) );
 
 		if( status != PBR_OK ) {
 			return status;
@@ -826,7 +842,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	if( phong ) {
 		// one plan: the Phong-tessellation build of the lock-step kernel (lean budget), in the slot of plan 1
 		if( !ctx->phongPlanBuilt ) {
-			const int made = makePlan( pickKernel( flavour, PTI_REFILL_PHONG, ctx->cfg.brdf, shadow, lights ), "refill-lean-phong", 0, 0, &ctx->phongPlan );
+			const int made = makePlan( PTI_REFILL_PHONG, "refill-lean-phong", 0, 0, &ctx->phongPlan );
 
 			if( made != PBR_OK ) {
 				return made;
@@ -1008,6 +1024,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		if( n > largest ) {
 			largest = n;
 			std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "%s", plan.name );
+			std::snprintf( ctx->lastKernel, sizeof( ctx->lastKernel ), "%s", plan.kernelName );
 		}
 
 		if( ( tuning || refining >= 0 ) && knobs.tuneLog > 0 ) {
@@ -2422,6 +2439,43 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned ) 
 	}
 
 	return PBR_OK;
+}
+
+int pbr_diag_last_kernel( pbr_ctx* ctx, char* name, size_t capacity ) {
+	if( ctx == nullptr || name == nullptr || capacity == 0 ) {
+		return fail( ctx, PBR_EINVAL, "diag_last_kernel: null argument" );
+	}
+
+	std::snprintf( name, capacity, "%s", ctx->lastKernel );
+	return PBR_OK;
+}
+
+int pbr_diag_launch_fit( pbr_ctx* ctx, double* fixed_ms, double* per_frame_ms ) {
+	if( ctx == nullptr || fixed_ms == nullptr || per_frame_ms == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "diag_launch_fit: null argument" );
+	}
+
+	const int plan = ( ctx->pinnedPlan >= 0 ) ? ctx->pinnedPlan : ctx->tunedPlan;
+
+	for( int k = 0; k < ctx->refineCount; k++ ) {
+		const double* f = ctx->refineFit[k];
+		const double det = f[0] * f[2] - f[1] * f[1];
+
+		if( ctx->refinePlan[k] != plan || !( det > 1e-9 * f[2] * f[0] ) ) {
+			continue;
+		}
+
+		const double b = ( f[0] * f[4] - f[1] * f[3] ) / det;
+		const double a = ( f[3] - b * f[1] ) / f[0];
+
+		if( a >= 0.0 && b >= 0.0 ) {
+			*fixed_ms = a;
+			*per_frame_ms = b;
+			return PBR_OK;
+		}
+	}
+
+	return fail( ctx, PBR_ESTATE, "diag_launch_fit: the tuner holds no two-length fit for the plan in use (pinned before it tuned, or launches of one length only)" );
 }
 
 int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value ) {

@@ -984,6 +984,42 @@ def test_bench_full_scale_shape_rehearsed_on_one_device(tmp_path):
     assert same_values(np.load(tmp_path / "one.npy"), np.load(tmp_path / "eight.npy"))
 
 
+def test_bench_runs_the_rccl_leg_with_one_rank(tmp_path):
+    """the `nccl` leg had never executed on an MI355X in any form (bench.py skipped torch.distributed
+    when world == 1, every rehearsal went through gloo and host memory).  `--force-dist`: init_process_group("nccl",
+    world_size=1) — a real RCCL communicator —, all_gather_into_tensor on the device buffers of pbr_export_tiles /
+    pbr_import_tiles, scatterGathered, the plan vote and the control reductions through RCCL; the gathered frame must be
+    the rendered frame at 1920 x 1080 (bench.py asserts it and says so in the line) and the run's frame the plain run's."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--steps", "8", "--warmup", "4", "--cpu-seconds", "0", "--repeats", "2", "--hold-seconds", "0"]
+    forced = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl",
+                             "--dump", str(tmp_path / "dist.npy")] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    line = json.loads([ln for ln in forced.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and (line["config"]["width"], line["config"]["height"]) == (1920, 1080)
+    assert line["force_dist"] == {"backend": "nccl", "world_size": 1, "gathered_frame_equals_rendered": True, "gather_ms": line["force_dist"]["gather_ms"]}
+    assert line["force_dist"]["gather_ms"] > 0 and len(line["per_rank_ms"]["render"]) == 1 and len(line["plan_votes"]) == 1
+    assert line["roofline"]["kernel"].startswith("ptk_f0::pathTracing")
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dump", str(tmp_path / "plain.npy")] + common,
+                           capture_output=True, text=True, timeout=900, env=env)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    assert same_values(np.load(tmp_path / "dist.npy"), np.load(tmp_path / "plain.npy"))
+
+
+def test_configs_0_as_baseline_json_writes_it(pbr, oracle, device):
+    """BASELINE.json configs[0]: "Cornell box 256 x 256, 4 spp, depth 4" — the reference's own CPU-runnable case, at its own
+    size (it had only been run at 64 x 48 and 64 x 64): the whole frame, the debug image and the counters."""
+    sc = make_scene(pbr, **{"render.max_depth": 4})
+    got, want, ref = both_render(pbr, oracle, device, sc, 256, 256, 4)
+    assert same_values(got, want), describe_mismatch(got, want)
+    assert same_values(device.read_debug(), ref.debug)
+    assert device.counters() == ref.counter_dict() and device.counters()["paths"] == 256 * 256 * 4
+    assert np.isfinite(want[..., 3]).mean() > 0.5
+
+
 # ----------------------------------------------------------------------------------------------
 # the reference's own scenes (resources/models/testing/*.obj|.mtl|.lights) as committed fixtures
 # ----------------------------------------------------------------------------------------------

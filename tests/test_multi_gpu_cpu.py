@@ -212,6 +212,77 @@ def test_bench_parent_ends_its_ranks_on_sigterm_and_on_the_deadline():
     assert not any(alive(p) for p in pids)
 
 
+def test_bench_ranks_are_ended_as_process_groups_and_die_with_their_parent():
+    """every rank leads its own session, so (1) ending a rank means signalling its process GROUP — a helper
+    the rank started must go with it; (2) a parent that is killed outright (SIGKILL: no handler runs) must not leave its
+    ranks behind: each rank asked the kernel for SIGTERM on its parent's death (bench.die_with_parent)."""
+    import signal
+    import subprocess
+    import textwrap
+    import time
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+            with open("/proc/%d/stat" % pid) as f:
+                return f.read().split(")")[-1].split()[0] != "Z"
+        except (OSError, IndexError):
+            return False
+
+    bench = _bench_module()
+    # (1) a "rank" that starts a helper in its own group; end_ranks takes both
+    rank = subprocess.Popen([sys.executable, "-c", textwrap.dedent("""
+        import subprocess, sys, time
+        child = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"])
+        print(child.pid, flush=True)
+        time.sleep(120)
+    """)], stdout=subprocess.PIPE, text=True, start_new_session=True)
+    helper = int(rank.stdout.readline())
+    assert alive(rank.pid) and alive(helper)
+    bench.end_ranks([rank], grace_s=5.0)
+    deadline = time.time() + 10
+    while alive(helper) and time.time() < deadline:
+        time.sleep(0.05)
+    assert rank.poll() is not None and not alive(helper)
+
+    # (2) the parent launches ranks through launch_ranks (which hands them BENCH_PARENT_PID) and is then SIGKILLed
+    code = textwrap.dedent("""
+        import importlib.util, os, subprocess, sys, time
+        spec = importlib.util.spec_from_file_location("bench_under_test", %r)
+        bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+        if os.environ.get("BENCH_PARENT_PID"):          # a rank: what bench.main does first
+            bench.die_with_parent()
+            print(os.getpid(), flush=True)
+            time.sleep(120)
+            sys.exit(0)
+        def popen(cmd, env, stdout, start_new_session):
+            return subprocess.Popen([sys.executable, "-c", open(sys.argv[1]).read(), sys.argv[1]], env=env, stdout=sys.stdout, start_new_session=start_new_session)
+        procs = bench.launch_ranks(2, [], popen=popen)
+        time.sleep(120)
+    """ % os.path.join(ROOT, "bench.py"))
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+        path = f.name
+    try:
+        parent = subprocess.Popen([sys.executable, path, path], stdout=subprocess.PIPE, text=True)
+        pids = [int(parent.stdout.readline()) for _ in range(2)]
+        assert all(alive(p) for p in pids)
+        parent.kill()                                   # SIGKILL: no handler, no cleanup
+        parent.wait(timeout=30)
+        deadline = time.time() + 15
+        while any(alive(p) for p in pids) and time.time() < deadline:
+            time.sleep(0.05)
+        assert not any(alive(p) for p in pids)
+    finally:
+        os.unlink(path)
+        for p in pids if "pids" in dir() else []:
+            try:
+                os.kill(p, signal.SIGKILL)
+            except OSError:
+                pass
+
+
 def test_bench_gpus_8_without_a_launcher_spawns_instead_of_refusing():
     """`python bench.py --gpus 8` with no WORLD_SIZE must not stop at argument parsing (round 2 did: "needs a
     torch.distributed.run launch").  Here there is no GPU, so the eight ranks it starts fail loudly at their first device call —
