@@ -1442,6 +1442,9 @@ static void traverseOrdered( ctx_t* c, ray4* ray ) {
 		if( g_node_hist ) {
 			__atomic_fetch_add( &g_node_hist[(size_t) k * N + (size_t) index], 1u, __ATOMIC_RELAXED );
 		}
+		if( g_visit_log && *g_visit_count < g_visit_cap ) {
+			g_visit_log[( *g_visit_count )++] = index;
+		}
 		const orc_bvh_node node = c->scene->bvh[index];
 		const int currentIndex = index;
 
