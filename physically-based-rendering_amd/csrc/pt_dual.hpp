@@ -244,7 +244,7 @@ PT_DEV void storeCold( const DevParams& P, int slot, const PixelState& st ) {
 
 template<bool LIGHTS>
 PT_DEV void startWalkDual( const DevParams& P, DualSlot& s ) {
-	s.invDir = mk3( 1.0f / s.ray.dir.x, 1.0f / s.ray.dir.y, 1.0f / s.ray.dir.z );
+	s.invDir = mk3( div1( 1.0f, s.ray.dir.x ), div1( 1.0f, s.ray.dir.y ), div1( 1.0f, s.ray.dir.z ) );
 	s.cur = firstNode( P, s.ray.dir ).ref;
 	Hit h;
 	h.t = inff();

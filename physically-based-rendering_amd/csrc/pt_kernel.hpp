@@ -821,14 +821,13 @@ PT_DEV NodeLinks decodeNode( const float4 n1 ) {
 // buildWalkStreams and in the oracle's "Ray-ordered walk").  Scheme 1: 2 * dominant axis (x before y before z on ties)
 // + ( dir[axis] < 0 ).  Scheme 2: the sign bits x | y << 1 | z << 2.
 PT_DEV int walkOrderOf( int scheme, const f3 d ) {
-	if( scheme == 2 ) {
-		return ( ( d.x < 0.0f ) ? 1 : 0 ) | ( ( d.y < 0.0f ) ? 2 : 0 ) | ( ( d.z < 0.0f ) ? 4 : 0 );
-	}
-
+	// both formulas, then a select on the (wave-uniform) scheme: as a branch around one of them this cost the 80-register
+	// state machine 16 B of scratch
+	const int eight = ( ( d.x < 0.0f ) ? 1 : 0 ) | ( ( d.y < 0.0f ) ? 2 : 0 ) | ( ( d.z < 0.0f ) ? 4 : 0 );
 	const float ax = __builtin_fabsf( d.x ), ay = __builtin_fabsf( d.y ), az = __builtin_fabsf( d.z );
-	const int axis = ( ax >= ay && ax >= az ) ? 0 : ( ( ay >= az ) ? 1 : 2 );
-	const float along = ( axis == 0 ) ? d.x : ( ( axis == 1 ) ? d.y : d.z );
-	return 2 * axis + ( ( along < 0.0f ) ? 1 : 0 );
+	const bool xDominates = ( ax >= ay && ax >= az ), yDominates = ( ay >= az );
+	const int six = xDominates ? ( ( d.x < 0.0f ) ? 1 : 0 ) : ( yDominates ? ( ( d.y < 0.0f ) ? 3 : 2 ) : ( ( d.z < 0.0f ) ? 5 : 4 ) );
+	return ( scheme == 2 ) ? eight : six;
 }
 
 PT_DEV Cursor firstNode( const DevParams& P, const f3 dir ) {
@@ -1016,7 +1015,7 @@ PT_DEV void nodePhaseAsm(
 // of a node before the slab test (a loss once registers are tight).
 template<bool ANYHIT, bool LIGHTS, bool USE_LDS, bool PHONG = false, bool EAGER = false>
 PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit& hit, unsigned& nodeVisits, unsigned& faceTests ) {
-	const f3 invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
+	const f3 invDir = mk3( div1( 1.0f, ray.dir.x ), div1( 1.0f, ray.dir.y ), div1( 1.0f, ray.dir.z ) );
 	const float tLight = hit.t;
 	Cursor cur = firstNode( P, ray.dir );
 #ifdef PBR_GUARD_TRAV
@@ -1199,19 +1198,19 @@ PT_DEV Ray initRay( const DevParams& P, int px, int py, float& seed, float tFocu
 
 PT_DEV float schZ( float t, float r ) {
 	const float x = 1.0f + r * t * t - t * t;
-	return ( x == 0.0f ) ? 0.0f : r / ( x * x );
+	return ( x == 0.0f ) ? 0.0f : div1( r, x * x );
 }
 
 PT_DEV float schA( float w, float p ) {
 	const float p2 = p * p;
 	const float w2 = w * w;
 	const float x = p2 - p2 * w2 + w2;
-	return ( x == 0.0f ) ? 0.0f : sqrt1( p / x );
+	return ( x == 0.0f ) ? 0.0f : sqrt1( div1( p, x ) );
 }
 
 PT_DEV float schG( float v, float r ) {
 	const float x = r - r * v + v;
-	return ( x == 0.0f ) ? 0.0f : v / x;
+	return ( x == 0.0f ) ? 0.0f : div1( v, x );
 }
 
 // brdfSchlick, pt_brdf.cl:125-150 with D / B2 (:71-112) inlined
@@ -1234,7 +1233,7 @@ PT_DEV float brdfSchlick( const Material& mtl, f3 outDir, f3 inDir, f3 normal, f
 	const float w = dot( un, hp );
 
 	*u = dot( h, vOutV );
-	*pdf = t / (float) ( (double) 4.0f * M_PI_D * (double) dot( vOutV, h ) );
+	*pdf = div1( t, (float) ( (double) 4.0f * M_PI_D * (double) dot( vOutV, h ) ) );
 
 	const float r = mtl.p3;  // rough
 	const float p = mtl.p2;  // isotropy
@@ -1249,10 +1248,10 @@ PT_DEV float brdfSchlick( const Material& mtl, f3 outDir, f3 inDir, f3 normal, f
 		const float gp = schG( vOut, r ) * schG( vIn, r );
 		const float obstructed = gp * schZ( t, r ) * schA( w, p );
 		const float reemission = 1.0f - gp;
-		ani = ( b / d ) * ( obstructed + reemission );
+		ani = div1( b, d ) * ( obstructed + reemission );
 	}
 
-	const float fres = ( vIn == 0.0f ) ? 0.0f : c / vIn;
+	const float fres = ( vIn == 0.0f ) ? 0.0f : div1( c, vIn );
 
 	return lam + ani + fres;
 }
@@ -1269,7 +1268,7 @@ PT_DEV f3 newRaySchlick( f3 dir, f3 normal, const Material& mtl, float& seed, Ta
 	const float a = rnd( seed );
 	float b = rnd( seed );
 	const float iso2 = iso * iso;
-	const float alpha = acos1( sqrt1( a / ( rough - a * rough + a ) ) );
+	const float alpha = acos1( sqrt1( div1( a, rough - a * rough + a ) ) );
 	float edge, base;
 	int mode;
 
@@ -1280,7 +1279,7 @@ PT_DEV f3 newRaySchlick( f3 dir, f3 normal, const Material& mtl, float& seed, Ta
 
 	b = 1.0f - 4.0f * ( edge - b );
 	const float b2 = b * b;
-	base = (float) ( M_PI_2_D * (double) sqrt1( ( iso2 * b2 ) / ( 1.0f - b2 + b2 * iso2 ) ) );
+	base = (float) ( M_PI_2_D * (double) sqrt1( div1( iso2 * b2, 1.0f - b2 + b2 * iso2 ) ) );
 
 	float phi = base;
 
@@ -1349,10 +1348,10 @@ PT_DEV void brdfSA(
 	*dotHK1 = hk1;
 
 	float ps_e = nu * dotHU * dotHU + nv * dotHV * dotHV;
-	ps_e = ( dotHN == 1.0f ) ? 0.0f : ps_e / ( 1.0f - dotHN * dotHN );
+	ps_e = ( dotHN == 1.0f ) ? 0.0f : div1( ps_e, 1.0f - dotHN * dotHN );
 	const float ps0 = (float) ( (double) ( sqrt1( ( nu + 1.0f ) * ( nv + 1.0f ) ) * 0.125f ) * M_1_PI_D );
 	const float ps1_num = powSelect<CALLS>( dotHN, ps_e );
-	const float ps1 = ps1_num / ( hk1 * fmax1( dotNK1, dotNK2 ) );
+	const float ps1 = div1( ps1_num, hk1 * fmax1( dotNK1, dotNK2 ) );
 
 	float pd = mtl.Rd * 0.38750768752f;
 	const float a = 1.0f - dotNK1 * 0.5f;
@@ -1362,7 +1361,7 @@ PT_DEV void brdfSA(
 
 	*brdfSpec = ps0 * ps1;
 	*brdfDiff = pd;
-	*pdf = ( ps0 * ps1_num ) / hk1;
+	*pdf = div1( ps0 * ps1_num, hk1 );
 }
 
 // newRayShirleyAshikhmin, pt_brdf.cl:278-330
@@ -1393,12 +1392,12 @@ PT_DEV f3 newRaySA( f3 dir, f3 rayNormal, const Material& mtl, float& seed, Tang
 
 	a = 1.0f - 4.0f * ( aMax - a );
 
-	const float phi = atan1( sqrt1( ( nu + 1.0f ) / ( nv + 1.0f ) ) * tan1( (float) ( M_PI_2_D * (double) a ) ) );
+	const float phi = atan1( sqrt1( div1( nu + 1.0f, nv + 1.0f ) ) * tan1( (float) ( M_PI_2_D * (double) a ) ) );
 	const float phi_full = phi_flip + phi_flipf * phi;
 
 	float sinphi, cosphi;
 	sincos( phi, &sinphi, &cosphi );
-	const float theta_e = 1.0f / ( nu * cosphi * cosphi + nv * sinphi * sinphi + 1.0f );
+	const float theta_e = div1( 1.0f, nu * cosphi * cosphi + nv * sinphi * sinphi + 1.0f );
 	const float theta = acos1( powSelect<CALLS>( 1.0f - b, theta_e ) );
 
 	const f3 normal = ( mtl.d < 1.0f || dot( rayNormal, -dir ) >= 0.0f ) ? rayNormal : -rayNormal;
@@ -1428,7 +1427,7 @@ PT_DEV f3 refract( f3 dir, f3 normal, const Material& mtl, float& seed ) {
 	const f3 nl = into ? normal : -normal;
 	const float m1 = into ? NI_AIR : mtl.Ni;
 	const float m2 = into ? mtl.Ni : NI_AIR;
-	const float m = m1 / m2;
+	const float m = div1( m1, m2 );
 	const float cosI = -dot( nl, dir );
 	const float sinT2 = m * m * ( 1.0f - cosI * cosI );
 
@@ -1437,7 +1436,7 @@ PT_DEV f3 refract( f3 dir, f3 normal, const Material& mtl, float& seed ) {
 	}
 
 	const float sqrtCosT = sqrt1( 1.0f - sinT2 );
-	const float r0 = ( m1 - m2 ) / ( m1 + m2 );
+	const float r0 = div1( m1 - m2, m1 + m2 );
 	const float c = ( m1 > m2 ) ? sqrtCosT : cosI;
 	const float reflectance = fresnel( c, r0 * r0 );
 
@@ -1477,7 +1476,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const
 		float u, pdf;
 		float brdf = brdfSchlick( mtl, outDir, inDir, normal, &u, &pdf, frame );
 		brdf *= fmax1( dot( normal, inDir ), 0.0f );
-		brdf = brdf / pdf;
+		brdf = div1( brdf, pdf );
 
 		const MaterialColours mc = materialColours<LATE>( mtl );
 		const f3 f4 = mk3( fresnel( u, mc.Ks.x ), fresnel( u, mc.Ks.y ), fresnel( u, mc.Ks.z ) );
@@ -1487,8 +1486,8 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const
 
 	float spec, diff, dotHK1, pdf;
 	brdfSA<CALLS>( mtl, outDir, inDir, normal, &spec, &diff, &dotHK1, &pdf, frame );
-	spec = spec / pdf;
-	diff = diff / pdf;
+	spec = div1( spec, pdf );
+	diff = div1( diff, pdf );
 
 	const float fr = fresnel( dotHK1, mtl.Rs );
 	const MaterialColours mc = materialColours<LATE>( mtl );
@@ -1497,7 +1496,7 @@ PT_DEV f3 throughput( const Material& mtl, f3 outDir, f3 inDir, f3 normal, const
 	f3 bc = brdf_s + brdf_d;
 	bc = mk3( bc.x * d + ( 1.0f - d ), bc.y * d + ( 1.0f - d ), bc.z * d + ( 1.0f - d ) );
 	const float maxRGB = max_cl( 1.0f, max_cl( bc.x, max_cl( bc.y, bc.z ) ) );
-	bc = mk3( bc.x / maxRGB, bc.y / maxRGB, bc.z / maxRGB );
+	bc = mk3( div1( bc.x, maxRGB ), div1( bc.y, maxRGB ), div1( bc.z, maxRGB ) );
 
 	return mk3( clamp01( bc.x ), clamp01( bc.y ), clamp01( bc.z ) );
 }
@@ -1519,7 +1518,7 @@ PT_DEV bool shadowContribution(
 		}
 
 		brdf *= fmax1( dot( normal, lightDir ), 0.0f );
-		brdf = brdf / pdf;
+		brdf = div1( brdf, pdf );
 
 		const MaterialColours mc = materialColours<LATE>( mtl );
 		const f3 f4 = mk3( fresnel( u, mc.Ks.x ), fresnel( u, mc.Ks.y ), fresnel( u, mc.Ks.z ) );
@@ -1535,8 +1534,8 @@ PT_DEV bool shadowContribution(
 		return false;
 	}
 
-	spec = spec / pdf;
-	diff = diff / pdf;
+	spec = div1( spec, pdf );
+	diff = div1( diff, pdf );
 
 	const float fr = fresnel( dotHK1, mtl.Rs );
 	const MaterialColours mc = materialColours<LATE>( mtl );
@@ -1545,7 +1544,7 @@ PT_DEV bool shadowContribution(
 	f3 bc = brdf_s + brdf_d;
 	bc = mk3( bc.x * d + ( 1.0f - d ), bc.y * d + ( 1.0f - d ), bc.z * d + ( 1.0f - d ) );
 	const float maxRGB = max_cl( 1.0f, max_cl( bc.x, max_cl( bc.y, bc.z ) ) );
-	bc = mk3( bc.x / maxRGB, bc.y / maxRGB, bc.z / maxRGB );
+	bc = mk3( div1( bc.x, maxRGB ), div1( bc.y, maxRGB ), div1( bc.z, maxRGB ) );
 
 	const f3 cl = mk3( clamp01( bc.x ), clamp01( bc.y ), clamp01( bc.z ) );
 	*add = mk3(
@@ -1835,11 +1834,11 @@ PT_DEV bool shadeStep( const DevParams& P, const float4* lds, PixelState& st, La
 	if( st.sample == P.samples ) {
 		// pathtracing.cl:326-333 + setColors, pt_rgb.cl:9-21
 		const float sp = (float) secondaryPaths;
-		finalColor = mk3( finalColor.x / sp, finalColor.y / sp, finalColor.z / sp );
+		finalColor = mk3( div1( finalColor.x, sp ), div1( finalColor.y, sp ), div1( finalColor.z, sp ) );
 
 		if( P.samples > 1 ) {
 			const float ns = P.samplesF;
-			finalColor = mk3( finalColor.x / ns, finalColor.y / ns, finalColor.z / ns );
+			finalColor = mk3( div1( finalColor.x, ns ), div1( finalColor.y, ns ), div1( finalColor.z, ns ) );
 		}
 
 #if PT_ARITH_NATIVE
@@ -2117,7 +2116,7 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracing( const DevParam
 // interleaving across lanes changes.
 template<bool LIGHTS>
 PT_DEV int startWalk( const DevParams& P, const Ray& ray, WalkState& w ) {
-	w.invDir = mk3( 1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z );
+	w.invDir = mk3( div1( 1.0f, ray.dir.x ), div1( 1.0f, ray.dir.y ), div1( 1.0f, ray.dir.z ) );
 	w.cur = firstNode( P, ray.dir );
 	w.hit.t = inff();
 	w.hit.face = 0;

@@ -34,6 +34,13 @@ PT_DEV f3 yzx( f3 a ) { return mk3( a.y, a.z, a.x ); }
 PT_DEV float fma1( float a, float b, float c ) { return __builtin_fmaf( a, b, c ); }
 PT_DEV float fmin1( float a, float b ) { return __builtin_fminf( a, b ); }
 PT_DEV float fmax1( float a, float b ) { return __builtin_fmaxf( a, b ); }
+// a / b where the reference writes native_divide / native_recip or a plain `/` in shading code: the IEEE quotient, or
+// (native) a * v_rcp_f32( b ) — two instructions where the compiler's 2.5-ulp division with denormal support takes eight
+#if PT_ARITH_NATIVE
+PT_DEV float div1( float a, float b ) { return a * __builtin_amdgcn_rcpf( b ); }
+#else
+PT_DEV float div1( float a, float b ) { return a / b; }
+#endif
 #if PT_ARITH_NATIVE
 PT_DEV float sqrt1( float a ) { return __builtin_amdgcn_sqrtf( a ); }
 PT_DEV float rsqrt1( float a ) { return __builtin_amdgcn_rsqf( a ); }
@@ -117,7 +124,7 @@ PT_DEV void sincos( float x, float* sn, float* cs ) {
 }
 
 PT_DEV float sin1( float x ) { float s, c; sincos( x, &s, &c ); return s; }
-PT_DEV float tan1( float x ) { float s, c; sincos( x, &s, &c ); return s / c; }
+PT_DEV float tan1( float x ) { float s, c; sincos( x, &s, &c ); return div1( s, c ); }
 
 // ---- acos / atan -----------------------------------------------------------------------
 PT_DEV float asin_core( float x ) {
