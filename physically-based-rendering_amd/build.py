@@ -190,6 +190,32 @@ def _build_hip_locked(target, sources, guard):
     return target
 
 
+def build_lab(name, extra_flags=(), flavours=None):
+    """A measurement build of the same sources: lab/libpbrhip_<name>.so with -DPBR_LAB_HOOKS -I lab/src (the hooks of
+    csrc/pt_kernel.hpp then come from lab/src/pt_lab_hooks.hpp) and the experiment's own -D flags; loaded by the Python
+    harness with PBR_LAB_ENV=1 PBR_HIP_LIB=lab/libpbrhip_<name>.so.  Never the product: no digest, not in hip_sources()."""
+    from concurrent.futures import ThreadPoolExecutor
+    lab = os.path.join(ROOT, "lab")
+    target = os.path.join(lab, "libpbrhip_%s.so" % name)
+    compiles, link, objdir = hip_commands(target, False, objdir="%s.obj.%d" % (target, os.getpid()))
+    extra = ["-DPBR_LAB_HOOKS=1", "-I", os.path.join(lab, "src"), *extra_flags]
+    keep = []
+    for cmd in compiles:
+        flav = [c for c in cmd if c.startswith("-DPT_FLAVOUR=")]
+        if flavours is not None and flav and int(flav[0].split("=")[1]) not in flavours:
+            continue
+        keep.append(cmd[:1] + extra + cmd[1:])
+    objects = [cmd[cmd.index("-o") + 1] for cmd in keep]
+    os.makedirs(objdir, exist_ok=True)
+    try:
+        with ThreadPoolExecutor(max_workers=max(1, min(len(keep), os.cpu_count() or 4))) as pool:
+            list(pool.map(_run, keep))
+        _run([_hipcc(), "--offload-arch=gfx950:xnack-", "-shared", "-fPIC", *objects, "-o", target])
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
+    return target
+
+
 def build_host(force=False):
     sources = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".cpp", ".h"))] + [os.path.join(INCLUDE, "pbr_hip.h")]
     build_hip()
@@ -224,5 +250,8 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    for lib in build_all(force="--force" in sys.argv):
-        print(lib)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--lab":       # python build.py --lab <name> [flags ...]
+        print(build_lab(sys.argv[2], [f for arg in sys.argv[3:] for f in arg.split()]))
+    else:
+        for lib in build_all(force="--force" in sys.argv):
+            print(lib)

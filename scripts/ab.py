@@ -10,7 +10,7 @@ pbr = pbr_loader.load()
 
 SCENES = {"cornell": ("cornell", 1, 0, 8), "sponza": ("sponza", 2, 260000, 3), "dragon": ("dragon", 1, 870000, 3), "hairball": ("hairball", 3, 2000000, 3)}
 jobs = sys.argv[1:] or ["cornell:64", "sponza:32", "dragon:32", "hairball:16"]
-tag = os.path.basename(os.environ.get("PBR_HIP_LIB", "default")) + "/" + ("plan " + os.environ["PBR_PLAN"] if os.environ.get("PBR_PLAN") else "auto")
+tag = os.path.basename(os.environ.get("PBR_HIP_LIB", "default")) + "/t%s a%s/" % (os.environ.get("AB_TRAVERSAL", "0"), os.environ.get("AB_ARITH", "0")) + ("plan " + os.environ["PBR_PLAN"] if os.environ.get("PBR_PLAN") else "auto")
 W, H = (int(v) for v in os.environ.get("AB_SIZE", "1920x1080").split("x"))
 for job in jobs:
     name, frames = job.split(":"); frames = int(frames)
@@ -18,6 +18,7 @@ for job in jobs:
     pbr.cfg_reset(); pbr.cfg_set(**{"render.max_depth": depth})
     sc = pbr.HostScene.generate(kind, seed, tris)
     cfg, cam, px = sc.config(W, H), sc.camera(), pbr.pixel_dimension(W, H)
+    cfg.traversal, cfg.arith = int(os.environ.get("AB_TRAVERSAL", "0")), int(os.environ.get("AB_ARITH", "0"))     # pbr_config's opt-in modes
     dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(cfg)
     dev.render(0, pbr.frame_seeds(0, 112), px, cam)                     # warm-up (and schedule auto-tuning: 6 x 2 + up to 3 x 32 frames)
     times = []

@@ -50,7 +50,7 @@ def collect(out, loads):
         try:
             rec["bench_under_rocprof"] = last_line_json("%s/stats_%s.json" % (out, key))
             rows = list(csv.DictReader(open(newest("%s/stats_%s/*/*_kernel_stats.csv" % (out, key))[0])))
-            rec["kernel_stats"] = [r for r in rows if "ptk::" in r["Name"]]
+            rec["kernel_stats"] = [r for r in rows if "ptk" in r["Name"]]
         except Exception as e:
             rec["stats_error"] = str(e)
         pmc = collections.OrderedDict()
@@ -103,6 +103,7 @@ def assemble(src, round_name):
         rd = r.get("fabric_read_bytes_per_launch", 0.0); wr = r.get("write_size_bytes", 0.0)
         sq_keys = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS")
         traffic[key] = {"scene": cfg["scene"], "width": cfg["width"], "height": cfg["height"], "max_depth": cfg["max_depth"], "brdf": cfg["brdf"], "steps": b["steps"],
+                        "traversal": {"reference": 0, "six-order": 1, "eight-order": 2}[cfg.get("traversal", "reference")], "arith": {"exact": 0, "native": 1}[cfg.get("arith", "exact")],
                         "schedule": b.get("schedule"), "plan": PLAN_NAMES.index(b["schedule"]) if b.get("schedule") in PLAN_NAMES else None,
                         "srchash": r.get("library_srchash"),
                         "fabric_read_bytes_per_launch": rd, "fabric_write_bytes_per_launch": wr,
@@ -123,7 +124,7 @@ def assemble(src, round_name):
         r["issue"] = {"valu_busy": busy, "salu_busy": p["SQ_INSTS_SALU"] * 2.0 / (1024 * 1e9 * ns * 1e-9), "lane_utilisation": r["valu_lane_utilisation"],
                       "useful_lane_throughput_frac": busy * r["valu_lane_utilisation"]}
         rdns = [v for k, v in p.items() if k.startswith("duration_ns(TCC_EA0_RDREQ")][0]
-        print("%-11s %7.1f Msamples/s %-12s launch %.3f ms | fabric %4.0f + %3.0f B/sample = %.2f TB/s read (%.0f %% of 8) | L2 hit %.3f, %.1f G requests/s | VALU busy %.0f %% x lanes %.0f %% = %.0f %% | waiting %.0f %% | cpu %.2f (%.0fx) | rocprof stats %d calls avg %.3f ms, timed %.3f vs events %.3f" % (
+        print("%-26s %7.1f Msamples/s %-12s launch %.3f ms | fabric %4.0f + %3.0f B/sample = %.2f TB/s read (%.0f %% of 8) | L2 hit %.3f, %.1f G requests/s | VALU busy %.0f %% x lanes %.0f %% = %.0f %% | waiting %.0f %% | cpu %.2f (%.0fx) | rocprof stats %d calls avg %.3f ms, timed %.3f vs events %.3f" % (
             key, b["value"], b["schedule"], b["roofline"]["launch_ms"], rd / samples, wr / samples, rd / rdns / 1e3, 100 * rd / rdns / 1e3 / 8.0,
             r["l2_hit_rate"], p.get("TCC_REQ_sum", 0) / rdns, 100 * busy, 100 * r["valu_lane_utilisation"], 100 * busy * r["valu_lane_utilisation"],
             100 * r["wave_wait_fraction"], b["cpu_baseline"]["value"], b["value"] / b["cpu_baseline"]["value"], calls, avg, dur, u["roofline"]["launch_ms"]))
@@ -135,4 +136,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "--collect":
         collect(sys.argv[2], sys.argv[3:])
     else:
-        assemble(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r04")
+        assemble(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r05")

@@ -13,7 +13,9 @@ for job in (sys.argv[1:] or ["sponza:32", "dragon:32", "hairball:16", "cornell:6
     kind, seed, tris, depth = SCENES[name]
     pbr.cfg_reset(); pbr.cfg_set(**{"render.max_depth": depth})
     sc = pbr.HostScene.generate(kind, seed, tris)
-    dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(sc.config(W, H))
+    cfg = sc.config(W, H)
+    cfg.traversal, cfg.arith = int(os.environ.get("AB_TRAVERSAL", "0")), int(os.environ.get("AB_ARITH", "0"))     # pbr_config's opt-in modes
+    dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(cfg)
     cam, px = sc.camera(), pbr.pixel_dimension(W, H)
     dev.render(0, pbr.frame_seeds(0, 16), px, cam)
     dev.reset_accum()
@@ -22,6 +24,6 @@ for job in (sys.argv[1:] or ["sponza:32", "dragon:32", "hairball:16", "cornell:6
     pbr.hip.pbr_diag_raw_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     pbr.hip.pbr_diag_raw_counters(dev._ctx, raw)
     node, leaf, shade, life = raw[4], raw[5], raw[6], raw[7]
-    print("%-8s %3d frames %s %.2f ms: of a wave's life %.1f %% node phases, %.1f %% leaf phases, %.1f %% shade phases, %.1f %% the rest" % (
-        name, frames, dev.last_plan()[0], dev.last_trace()[0], 100.0 * node / life, 100.0 * leaf / life, 100.0 * shade / life, 100.0 * (life - node - leaf - shade) / life), flush=True)
+    print("%-8s traversal %d arith %d %3d frames %s %.2f ms: of a wave's life %.1f %% node phases, %.1f %% leaf phases, %.1f %% shade phases, %.1f %% the rest" % (
+        name, cfg.traversal, cfg.arith, frames, dev.last_plan()[0], dev.last_trace()[0], 100.0 * node / life, 100.0 * leaf / life, 100.0 * shade / life, 100.0 * (life - node - leaf - shade) / life), flush=True)
     dev.close()

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collects the round's measurements on the GPU box: bench lines, rocprofv3 kernel stats and the PMC passes (each in its
 # own run, each under a timeout; --pmc never together with a trace domain other than --kernel-trace).
-# usage: scripts/profile_round.sh <outdir> [workload ...]     workloads: cornell sponza dragon hairball hairball_4k
+# usage: scripts/profile_round.sh <outdir> [workload ...]     workloads: <scene>[_4k][_walk6|_walk8][_native], scene = cornell sponza dragon hairball
+#        (_4k: 3840x2160; _walk6 / _walk8: pbr_config.traversal six / eight orders; _native: pbr_config.arith native)
 out=${1:-gpurun_out/round}; shift
 loads=${@:-cornell sponza dragon hairball hairball_4k}
 R=$PWD
@@ -10,7 +11,11 @@ export TMPDIR=/tmp
 for key in $loads; do
   s=${key%%_*}; size=""; steps=64
   [ $s = cornell ] && steps=256
-  [ $key = hairball_4k ] && { size="--width 3840 --height 2160"; steps=16; }
+  mode=""
+  case $key in *_4k*) size="--width 3840 --height 2160"; steps=16;; esac
+  case $key in *_walk6*) mode="$mode --traversal six-order";; *_walk8*) mode="$mode --traversal eight-order";; esac
+  case $key in *_native*) mode="$mode --arith native";; esac
+  size="$size $mode"
   timeout 600 python3 bench.py --scene $s $size --steps $steps > $out/bench_$key.json 2> $out/bench_$key.err
   # the profiled runs pin the schedule the tuner settled on in the plain run (--plan: no tuning launches under the profiler)
   plan=$(python3 -c "import json,sys; n=json.loads(open('$out/bench_$key.json').read().strip().splitlines()[-1]).get('schedule','refill-lean'); print(['refill-lean','refill-wide','phased-lean','phased-wide','phased-mid','refill-mid','phased-dual'].index(n))")

@@ -17,13 +17,14 @@ cam, px = sc.camera(), pbr.pixel_dimension(W, H)
 base = None
 for world in (1, 2, 4, 8):
     cfg = sc.config(W, H); cfg.tile_world, cfg.tile_rank = world, 0
+    cfg.traversal, cfg.arith = int(os.environ.get("AB_TRAVERSAL", "0")), int(os.environ.get("AB_ARITH", "0"))     # pbr_config's opt-in modes
     dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(cfg)
     warm = dev.tune_budget()
     dev.render(0, pbr.frame_seeds(0, warm), px, cam)
     best = 1e9
-    for rep in range(2):
+    for rep in range(4):
         dev.render(warm, pbr.frame_seeds(warm, frames), px, cam)
         best = min(best, dev.last_kernel_ms())
     base = base or best
-    print("%-8s N=%d  %-12s %8.3f ms for %d frames of 1/%d of the tiles   efficiency %.3f" % (name, world, dev.last_plan()[0], best, frames, world, base / (world * best)), flush=True)
+    print("%-8s traversal %d arith %d N=%d  %-12s %8.3f ms for %d frames of 1/%d of the tiles   efficiency %.3f" % (name, cfg.traversal, cfg.arith, world, dev.last_plan()[0], best, frames, world, base / (world * best)), flush=True)
     dev.close()
