@@ -166,6 +166,8 @@ host.pbrh_pt_generate_image.argtypes = [_vp, _fp, _fp]
 host.pbrh_pt_generate_images.argtypes = [_vp, ctypes.c_uint32, _fp]
 host.pbrh_write_ppm.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
 host.pbrh_write_pfm.argtypes = [ctypes.c_char_p, _fp, ctypes.c_uint32, ctypes.c_uint32]
+host.pbrh_write_png.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+host.pbrh_write_exr.argtypes = [ctypes.c_char_p, _fp, ctypes.c_uint32, ctypes.c_uint32]
 host.pbrh_cl_adaptor_render.argtypes = [_vp, ctypes.c_uint32, ctypes.c_float, _fp, _fp]
 host.pbrh_cl_adaptor_render_ex.argtypes = [_vp, ctypes.c_uint32, ctypes.c_float, _fp, _fp, ctypes.c_uint32]
 host.pbrh_pt_set_focus.argtypes = [_vp, ctypes.c_int, ctypes.c_int]
@@ -538,6 +540,20 @@ def write_pfm(path, rgba):
     """(H, W, 4) float32, row 0 = bottom (Device.read_output()) -> PFM, the linear image."""
     rgba = np.ascontiguousarray(rgba, np.float32)
     if host.pbrh_write_pfm(str(path).encode(), _as_fp(rgba), rgba.shape[1], rgba.shape[0]) != 0:
+        raise PbrError(host.pbrh_last_error().decode())
+
+
+def write_png(path, rgba8):
+    """(H, W, 4) uint8, top row first (Device.read_display(top_row_first=True)) -> PNG (8-bit RGBA)."""
+    rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+    if host.pbrh_write_png(str(path).encode(), rgba8.ctypes.data, rgba8.shape[1], rgba8.shape[0]) != 0:
+        raise PbrError(host.pbrh_last_error().decode())
+
+
+def write_exr(path, rgba):
+    """(H, W, 4) float32, row 0 = bottom (Device.read_output()) -> OpenEXR: binary32 R, G, B and A = the first-hit distance."""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    if host.pbrh_write_exr(str(path).encode(), _as_fp(rgba), rgba.shape[1], rgba.shape[0]) != 0:
         raise PbrError(host.pbrh_last_error().decode())
 
 

@@ -518,6 +518,11 @@ PT_DEV f3 getPhongTessNormal( f3 an, f3 bn, f3 cn, f3 rayDir, float u, float v, 
 	return ( dot( ns, r ) < 0.0f ) ? ns : np;
 }
 
+// A conic uu u^2 + vv v^2 + k + 2 ( uv u v + u1 u + v1 v ) = 0 in the barycentric ( u, v ) plane of a Phong-tessellated patch
+struct Conic {
+	float uu, vv, k, uv, u1, v1;
+};
+
 // phongTessTriAndRayIntersect, pt_phongtess.cl:56-212 (after Ogaki & Tokuyoshi, "Direct Ray Tracing of Phong
 // Tessellation"); getPlanesFromRay (pt_utils.cl:208-218) and getBestRayDomain (pt_phongtess.cl:35-44) inlined.
 // Returns t (INF: no hit) and the normal at the hit.
@@ -541,46 +546,50 @@ PT_DEV float phongTessTriAndRayIntersect(
 	const float o2 = dot( n2, ray.origin );
 	const f3 C123 = ( C1 - C2 ) - C3;
 
-	const float a = dot( -n1, C3 );
-	const float b = dot( -n1, C2 );
-	const float c = dot( n1, P3 ) - o1;
-	const float d = dot( n1, C123 ) * 0.5f;
-	const float e = dot( n1, C3 + E20 ) * 0.5f;
-	const float f = dot( n1, C2 - E12 ) * 0.5f;
-	const float l = dot( -n2, C3 );
-	const float m = dot( -n2, C2 );
-	const float n = dot( n2, P3 ) - o2;
-	const float o = dot( n2, C123 ) * 0.5f;
-	const float p = dot( n2, C3 + E20 ) * 0.5f;
-	const float q = dot( n2, C2 - E12 ) * 0.5f;
+	// the conics the ray's two planes cut out of the patch, in the barycentric ( u, v ) plane (Conic above)
+	Conic ca, cb;
+	ca.uu = dot( -n1, C3 );
+	ca.vv = dot( -n1, C2 );
+	ca.k = dot( n1, P3 ) - o1;
+	ca.uv = dot( n1, C123 ) * 0.5f;
+	ca.u1 = dot( n1, C3 + E20 ) * 0.5f;
+	ca.v1 = dot( n1, C2 - E12 ) * 0.5f;
+	cb.uu = dot( -n2, C3 );
+	cb.vv = dot( -n2, C2 );
+	cb.k = dot( n2, P3 ) - o2;
+	cb.uv = dot( n2, C123 ) * 0.5f;
+	cb.u1 = dot( n2, C3 + E20 ) * 0.5f;
+	cb.v1 = dot( n2, C2 - E12 ) * 0.5f;
 
-	float xs[3] = { -1.0f, -1.0f, -1.0f };
-	const float a3 = ( l*m*n + 2.0f*o*p*q ) - ( l*q*q + m*p*p + n*o*o );
-	const float a2 = ( a*m*n + l*b*n + l*m*c + 2.0f*( d*p*q + o*e*q + o*p*f ) ) -
-	                 ( a*q*q + b*p*p + c*o*o + 2.0f*( l*f*q + m*e*p + n*d*o ) );
-	const float a1 = ( a*b*n + a*m*c + l*b*c + 2.0f*( o*e*f + d*e*q + d*p*f ) ) -
-	                 ( l*f*f + m*e*e + n*d*d + 2.0f*( a*f*q + b*e*p + c*d*o ) );
-	const float a0 = ( a*b*c + 2.0f*d*e*f ) - ( a*f*f + b*e*e + c*d*d );
-	const int numCubicRoots = solveCubic( a0, a1, a2, a3, xs );
+	// det( lambda ca + cb ) = 0: the members of the pencil of the two conics that are degenerate (a pair of lines)
+	float roots[3] = { -1.0f, -1.0f, -1.0f };
+	const float a3 = ( cb.uu*cb.vv*cb.k + 2.0f*cb.uv*cb.u1*cb.v1 ) - ( cb.uu*cb.v1*cb.v1 + cb.vv*cb.u1*cb.u1 + cb.k*cb.uv*cb.uv );
+	const float a2 = ( ca.uu*cb.vv*cb.k + cb.uu*ca.vv*cb.k + cb.uu*cb.vv*ca.k + 2.0f*( ca.uv*cb.u1*cb.v1 + cb.uv*ca.u1*cb.v1 + cb.uv*cb.u1*ca.v1 ) ) -
+	                 ( ca.uu*cb.v1*cb.v1 + ca.vv*cb.u1*cb.u1 + ca.k*cb.uv*cb.uv + 2.0f*( cb.uu*ca.v1*cb.v1 + cb.vv*ca.u1*cb.u1 + cb.k*ca.uv*cb.uv ) );
+	const float a1 = ( ca.uu*ca.vv*cb.k + ca.uu*cb.vv*ca.k + cb.uu*ca.vv*ca.k + 2.0f*( cb.uv*ca.u1*ca.v1 + ca.uv*ca.u1*cb.v1 + ca.uv*cb.u1*ca.v1 ) ) -
+	                 ( cb.uu*ca.v1*ca.v1 + cb.vv*ca.u1*ca.u1 + cb.k*ca.uv*ca.uv + 2.0f*( ca.uu*ca.v1*cb.v1 + ca.vv*ca.u1*cb.u1 + ca.k*ca.uv*cb.uv ) );
+	const float a0 = ( ca.uu*ca.vv*ca.k + 2.0f*ca.uv*ca.u1*ca.v1 ) - ( ca.uu*ca.v1*ca.v1 + ca.vv*ca.u1*ca.u1 + ca.k*ca.uv*ca.uv );
+	const int pencilRoots = solveCubic( a0, a1, a2, a3, roots );
 
-	if( numCubicRoots == 0 ) {
+	if( pencilRoots == 0 ) {
 		return t;
 	}
 
-	float x = 0.0f;
-	float determinant = inff();
-	float mA, mB, mC, mD, mE, mF;
+	// of those, the member whose quadratic part is most clearly a pair of REAL lines ( uv^2 - uu vv > 0 )
+	float lambda = 0.0f;
+	float smallest = inff();
+	Conic deg;
 
-	for( int i = 0; i < numCubicRoots; i++ ) {
-		mA = a * xs[i] + l;
-		mB = b * xs[i] + m;
-		mD = d * xs[i] + o;
-		const float tmp = mD * mD - mA * mB;
-		x = ( determinant > tmp ) ? xs[i] : x;
-		determinant = fmin1( determinant, tmp );
+	for( int i = 0; i < pencilRoots; i++ ) {
+		deg.uu = ca.uu * roots[i] + cb.uu;
+		deg.vv = ca.vv * roots[i] + cb.vv;
+		deg.uv = ca.uv * roots[i] + cb.uv;
+		const float tmp = deg.uv * deg.uv - deg.uu * deg.vv;
+		lambda = ( smallest > tmp ) ? roots[i] : lambda;
+		smallest = fmin1( smallest, tmp );
 	}
 
-	if( 0.0f >= determinant ) {
+	if( 0.0f >= smallest ) {
 		return t;
 	}
 
@@ -591,73 +600,76 @@ PT_DEV float phongTessTriAndRayIntersect(
 		domain = ( ad.x > ad.z ) ? 0 : 2;
 	}
 
-	mA = a * x + l;
-	mB = b * x + m;
-	mC = c * x + n;
-	mD = d * x + o;
-	mE = e * x + p;
-	mF = f * x + q;
+	deg.uu = ca.uu * lambda + cb.uu;
+	deg.vv = ca.vv * lambda + cb.vv;
+	deg.k = ca.k * lambda + cb.k;
+	deg.uv = ca.uv * lambda + cb.uv;
+	deg.u1 = ca.u1 * lambda + cb.u1;
+	deg.v1 = ca.v1 * lambda + cb.v1;
 
-	const bool AlessB = __builtin_fabsf( mA ) < __builtin_fabsf( mB );
-	const float mBorA = AlessB ? mB : mA;
-	mA = mA / mBorA;
-	mB = mB / mBorA;
-	mC = mC / mBorA;
-	mD = mD / mBorA;
-	mE = mE / mBorA;
-	mF = mF / mBorA;
+	// normalise by the larger square term (solve for the other variable) and split the degenerate conic into its two lines
+	const bool swapUV = __builtin_fabsf( deg.uu ) < __builtin_fabsf( deg.vv );
+	const float pivot = swapUV ? deg.vv : deg.uu;
+	deg.uu = deg.uu / pivot;
+	deg.vv = deg.vv / pivot;
+	deg.k = deg.k / pivot;
+	deg.uv = deg.uv / pivot;
+	deg.u1 = deg.u1 / pivot;
+	deg.v1 = deg.v1 / pivot;
 
-	const float mAorB = AlessB ? mA : mB;
-	const float mEorF = AlessB ? 2.0f * mE : 2.0f * mF;
-	const float mForE = AlessB ? mF : mE;
-	const float ab = AlessB ? a : b;
-	const float ba = AlessB ? b : a;
-	const float ef = AlessB ? e : f;
-	const float fe = AlessB ? f : e;
+	const float quadTerm = swapUV ? deg.uu : deg.vv;
+	const float crossTerm = swapUV ? 2.0f * deg.u1 : 2.0f * deg.v1;
+	const float linTerm = swapUV ? deg.v1 : deg.u1;
+	const float lead = swapUV ? ca.uu : ca.vv;
+	const float trail = swapUV ? ca.vv : ca.uu;
+	const float leadLin = swapUV ? ca.u1 : ca.v1;
+	const float trailLin = swapUV ? ca.v1 : ca.u1;
 
-	const float sqrtAorB = sqrt1( mD * mD - mAorB );
-	const float sqrtC = sqrt1( mForE * mForE - mC );
-	const float lab1 = mD + sqrtAorB;
-	const float lab2 = mD - sqrtAorB;
-	float lc1 = mForE + sqrtC;
-	float lc2 = mForE - sqrtC;
+	const float slopeSpread = sqrt1( deg.uv * deg.uv - quadTerm );
+	const float offsetSpread = sqrt1( linTerm * linTerm - deg.k );
+	const float slopeA = deg.uv + slopeSpread;
+	const float slopeB = deg.uv - slopeSpread;
+	float offsetA = linTerm + offsetSpread;
+	float offsetB = linTerm - offsetSpread;
 
-	if( __builtin_fabsf( mEorF - lab1 * lc1 - lab2 * lc2 ) < __builtin_fabsf( mEorF - lab1 * lc2 - lab2 * lc1 ) ) {
-		const float tmp = lc1;
-		lc1 = lc2;
-		lc2 = tmp;
+	if( __builtin_fabsf( crossTerm - slopeA * offsetA - slopeB * offsetB ) < __builtin_fabsf( crossTerm - slopeA * offsetB - slopeB * offsetA ) ) {
+		const float tmp = offsetA;
+		offsetA = offsetB;
+		offsetB = tmp;
 	}
 
-	for( int loop = 0; loop < 2; loop++ ) {
-		const float g = ( loop == 0 ) ? -lab1 : -lab2;
-		const float h = ( loop == 0 ) ? -lc1 : -lc2;
-		const float c0 = ab + g * ( 2.0f * d + ba * g );
-		const float c1 = 2.0f * ( h * ( d + ba * g ) + ef + fe * g );
-		const float c2 = h * ( ba * h + 2.0f * fe ) + c;
-		const int numResults = solveCubic( 0.0f, c0, c1, c2, xs );
+	// each line, substituted into the first conic, is a quadratic in one barycentric coordinate: its roots inside the
+	// triangle are the ray's intersections with the patch
+	for( int line = 0; line < 2; line++ ) {
+		const float slope = ( line == 0 ) ? -slopeA : -slopeB;
+		const float offset = ( line == 0 ) ? -offsetA : -offsetB;
+		const float q0 = lead + slope * ( 2.0f * ca.uv + trail * slope );
+		const float q1 = 2.0f * ( offset * ( ca.uv + trail * slope ) + leadLin + trailLin * slope );
+		const float q2 = offset * ( trail * offset + 2.0f * trailLin ) + ca.k;
+		const int hits = solveCubic( 0.0f, q0, q1, q2, roots );
 
-		for( int i = 0; i < numResults; i++ ) {
-			float u = xs[i];
-			float v = g * u + h;
+		for( int i = 0; i < hits; i++ ) {
+			float u = roots[i];
+			float v = slope * u + offset;
 			const float w = 1.0f - u - v;
 
 			if( u < 0.0f || v < 0.0f || w < 0.0f ) {
 				continue;
 			}
 
-			if( !AlessB ) {
+			if( !swapUV ) {
 				const float tmp = u;
 				u = v;
 				v = tmp;
 			}
 
-			const f3 pTessellated = phongTessellation( P1, P2, P3, N1, N2, N3, u, v, w, alpha ) - ray.origin;
-			const float num = ( domain == 0 ) ? pTessellated.x : ( domain == 1 ) ? pTessellated.y : pTessellated.z;
+			const f3 toPoint = phongTessellation( P1, P2, P3, N1, N2, N3, u, v, w, alpha ) - ray.origin;
+			const float num = ( domain == 0 ) ? toPoint.x : ( domain == 1 ) ? toPoint.y : toPoint.z;
 			const float den = ( domain == 0 ) ? ray.dir.x : ( domain == 1 ) ? ray.dir.y : ray.dir.z;
-			const float tParam = num / den;
+			const float tHit = num / den;
 
-			if( tParam >= __builtin_fabsf( tNear ) && tParam <= fmin1( t, fmin1( rayT, tFar ) ) ) {
-				t = tParam;
+			if( tHit >= __builtin_fabsf( tNear ) && tHit <= fmin1( t, fmin1( rayT, tFar ) ) ) {
+				t = tHit;
 				normal = getPhongTessNormal( N1, N2, N3, ray.dir, u, v, w, C1, C2, C3, E12, E20 );
 			}
 		}

@@ -2,6 +2,8 @@
 // It exposes the host half of the path — config, scene load / generation, BVH build,
 // buffer packing, camera, PathTracer driver — with plain pointers, so the harness can hand the
 // SAME flat arrays to the HIP core (libpbrhip.so) and to the CPU oracle.
+#include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -421,6 +423,197 @@ int pbrh_write_pfm( const char* path, const float* rgba, uint32_t width, uint32_
 	}
 
 	return ( std::fclose( f ) == 0 ) ? 0 : -1;
+}
+
+// PNG (8-bit RGBA, top row first — what pbr_read_display( top_row_first = 1 ) returns) and OpenEXR (binary32 R, G, B + A =
+// the accumulated first-hit distance; bottom row first in, as pbr_read_output has it) — the two formats SURVEY.md names
+// for this row.  Written here without a library: the PNG's zlib stream uses stored (uncompressed) deflate blocks, the EXR
+// is a single-part scanline file with NO_COMPRESSION.  Both are what any reader expects; neither is small.
+}  // extern "C"
+
+namespace {
+
+uint32_t crc32Of( const uint8_t* data, size_t n, uint32_t crc ) {
+	static uint32_t table[256];
+	static bool ready = false;
+
+	if( !ready ) {
+		for( uint32_t i = 0; i < 256; i++ ) {
+			uint32_t c = i;
+
+			for( int k = 0; k < 8; k++ ) {
+				c = ( c & 1u ) ? ( 0xEDB88320u ^ ( c >> 1 ) ) : ( c >> 1 );
+			}
+
+			table[i] = c;
+		}
+
+		ready = true;
+	}
+
+	crc = ~crc;
+
+	for( size_t i = 0; i < n; i++ ) {
+		crc = table[( crc ^ data[i] ) & 0xFFu] ^ ( crc >> 8 );
+	}
+
+	return ~crc;
+}
+
+void putBE32( std::vector<uint8_t>& out, uint32_t v ) {
+	out.push_back( (uint8_t) ( v >> 24 ) ); out.push_back( (uint8_t) ( v >> 16 ) ); out.push_back( (uint8_t) ( v >> 8 ) ); out.push_back( (uint8_t) v );
+}
+
+bool writeChunk( FILE* f, const char type[4], const std::vector<uint8_t>& body ) {
+	std::vector<uint8_t> head;
+	putBE32( head, (uint32_t) body.size() );
+	std::vector<uint8_t> typed( type, type + 4 );
+	typed.insert( typed.end(), body.begin(), body.end() );
+	std::vector<uint8_t> tail;
+	putBE32( tail, crc32Of( typed.data(), typed.size(), 0u ) );
+	return std::fwrite( head.data(), 1, 4, f ) == 4 && std::fwrite( typed.data(), 1, typed.size(), f ) == typed.size() && std::fwrite( tail.data(), 1, 4, f ) == 4;
+}
+
+template<typename T>
+void putLE( std::vector<uint8_t>& out, T v ) {
+	uint8_t raw[sizeof( T )];
+	std::memcpy( raw, &v, sizeof( T ) );     // the hosts this builds for are little endian, like both file formats' fields here
+	out.insert( out.end(), raw, raw + sizeof( T ) );
+}
+
+void putAttr( std::vector<uint8_t>& out, const char* name, const char* type, const std::vector<uint8_t>& value ) {
+	out.insert( out.end(), name, name + std::strlen( name ) + 1 );
+	out.insert( out.end(), type, type + std::strlen( type ) + 1 );
+	putLE<int32_t>( out, (int32_t) value.size() );
+	out.insert( out.end(), value.begin(), value.end() );
+}
+
+}  // namespace
+
+extern "C" {
+
+int pbrh_write_png( const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height ) {
+	FILE* f = ( path != nullptr && rgba8 != nullptr && width > 0 && height > 0 ) ? std::fopen( path, "wb" ) : nullptr;
+
+	if( f == nullptr ) {
+		gError = std::string( "cannot write " ) + ( path ? path : "(null)" );
+		return -1;
+	}
+
+	// the filtered image: every scanline = filter type 0 + its RGBA bytes
+	std::vector<uint8_t> raw;
+	raw.reserve( (size_t) height * ( (size_t) width * 4 + 1 ) );
+
+	for( uint32_t y = 0; y < height; y++ ) {
+		raw.push_back( 0 );
+		raw.insert( raw.end(), rgba8 + (size_t) y * width * 4, rgba8 + (size_t) ( y + 1 ) * width * 4 );
+	}
+
+	// zlib stream: header, stored deflate blocks of <= 65535 bytes, Adler-32 of the raw bytes
+	std::vector<uint8_t> z;
+	z.push_back( 0x78 ); z.push_back( 0x01 );
+	uint32_t a = 1, b = 0;
+
+	for( size_t at = 0; at < raw.size(); ) {
+		const size_t n = std::min<size_t>( 65535, raw.size() - at );
+		z.push_back( ( at + n == raw.size() ) ? 1 : 0 );
+		z.push_back( (uint8_t) ( n & 0xFF ) ); z.push_back( (uint8_t) ( n >> 8 ) );
+		z.push_back( (uint8_t) ( ~n & 0xFF ) ); z.push_back( (uint8_t) ( ( ~n >> 8 ) & 0xFF ) );
+		z.insert( z.end(), raw.begin() + at, raw.begin() + at + n );
+
+		for( size_t i = at; i < at + n; i++ ) {
+			a = ( a + raw[i] ) % 65521u;
+			b = ( b + a ) % 65521u;
+		}
+
+		at += n;
+	}
+
+	putBE32( z, ( b << 16 ) | a );
+
+	const uint8_t signature[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+	std::vector<uint8_t> ihdr;
+	putBE32( ihdr, width ); putBE32( ihdr, height );
+	ihdr.push_back( 8 ); ihdr.push_back( 6 ); ihdr.push_back( 0 ); ihdr.push_back( 0 ); ihdr.push_back( 0 );   // 8 bits, RGBA, deflate, adaptive, no interlace
+	bool ok = std::fwrite( signature, 1, 8, f ) == 8 && writeChunk( f, "IHDR", ihdr ) && writeChunk( f, "IDAT", z ) && writeChunk( f, "IEND", std::vector<uint8_t>() );
+	ok = ( std::fclose( f ) == 0 ) && ok;
+
+	if( !ok ) {
+		gError = std::string( "short write: " ) + path;
+	}
+
+	return ok ? 0 : -1;
+}
+
+int pbrh_write_exr( const char* path, const float* rgba, uint32_t width, uint32_t height ) {
+	FILE* f = ( path != nullptr && rgba != nullptr && width > 0 && height > 0 ) ? std::fopen( path, "wb" ) : nullptr;
+
+	if( f == nullptr ) {
+		gError = std::string( "cannot write " ) + ( path ? path : "(null)" );
+		return -1;
+	}
+
+	std::vector<uint8_t> head;
+	putLE<uint32_t>( head, 20000630u );      // magic
+	putLE<uint32_t>( head, 2u );             // version 2, single-part scanline, no flags
+
+	std::vector<uint8_t> channels;           // alphabetical: A, B, G, R; FLOAT (2), linear, no subsampling
+	for( const char* name : { "A", "B", "G", "R" } ) {
+		channels.insert( channels.end(), name, name + 2 );
+		putLE<int32_t>( channels, 2 );
+		channels.push_back( 0 ); channels.push_back( 0 ); channels.push_back( 0 ); channels.push_back( 0 );
+		putLE<int32_t>( channels, 1 ); putLE<int32_t>( channels, 1 );
+	}
+	channels.push_back( 0 );
+	putAttr( head, "channels", "chlist", channels );
+	putAttr( head, "compression", "compression", std::vector<uint8_t>( 1, 0 ) );
+	std::vector<uint8_t> window;
+	putLE<int32_t>( window, 0 ); putLE<int32_t>( window, 0 ); putLE<int32_t>( window, (int32_t) width - 1 ); putLE<int32_t>( window, (int32_t) height - 1 );
+	putAttr( head, "dataWindow", "box2i", window );
+	putAttr( head, "displayWindow", "box2i", window );
+	putAttr( head, "lineOrder", "lineOrder", std::vector<uint8_t>( 1, 0 ) );      // increasing y: the top row first
+	std::vector<uint8_t> one; putLE<float>( one, 1.0f );
+	putAttr( head, "pixelAspectRatio", "float", one );
+	std::vector<uint8_t> centre; putLE<float>( centre, 0.0f ); putLE<float>( centre, 0.0f );
+	putAttr( head, "screenWindowCenter", "v2f", centre );
+	putAttr( head, "screenWindowWidth", "float", one );
+	head.push_back( 0 );                     // end of the header
+
+	const size_t lineBytes = (size_t) width * 4 * sizeof( float );
+	uint64_t offset = head.size() + (uint64_t) height * 8;
+
+	for( uint32_t y = 0; y < height; y++ ) {
+		putLE<uint64_t>( head, offset );
+		offset += 8 + lineBytes;
+	}
+
+	bool ok = std::fwrite( head.data(), 1, head.size(), f ) == head.size();
+	std::vector<uint8_t> line;
+
+	for( uint32_t y = 0; ok && y < height; y++ ) {
+		// file row y = image row height - 1 - y: the input's row 0 is the bottom of the picture (pbr_read_output)
+		const float* row = rgba + (size_t) ( height - 1 - y ) * width * 4;
+		line.clear();
+		putLE<int32_t>( line, (int32_t) y );
+		putLE<int32_t>( line, (int32_t) lineBytes );
+		const int order[4] = { 3, 2, 1, 0 };     // A, B, G, R out of R, G, B, A
+
+		for( int c = 0; c < 4; c++ ) {
+			for( uint32_t x = 0; x < width; x++ ) {
+				putLE<float>( line, row[(size_t) x * 4 + order[c]] );
+			}
+		}
+
+		ok = std::fwrite( line.data(), 1, line.size(), f ) == line.size();
+	}
+
+	ok = ( std::fclose( f ) == 0 ) && ok;
+
+	if( !ok ) {
+		gError = std::string( "short write: " ) + path;
+	}
+
+	return ok ? 0 : -1;
 }
 
 }  // extern "C"

@@ -205,3 +205,70 @@ def test_image_writers_round_trip(cfg_defaults, tmp_path):
     assert np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(4, 6, 3), lin[..., :3])
     with pytest.raises(pbr.PbrError):
         pbr.write_ppm(tmp_path / "no" / "dir.ppm", rgba8)
+
+
+def test_png_and_exr_writers(pbr, tmp_path):
+    """pbrh_write_png / pbrh_write_exr — the formats SURVEY.md section 8(f) row 4 names — read back here by a decoder
+    written from the two specifications (zlib for the PNG's stream; the EXR is uncompressed): every pixel, the row
+    order (PNG: top row first as read_display returns it; EXR: the input's row 0 is the BOTTOM, the file's first scanline
+    the top), chunk CRCs, the EXR's header attributes and offset table."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(5)
+    w, h = 37, 21
+    rgba8 = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    pbr.write_png(tmp_path / "a.png", rgba8)
+    raw = (tmp_path / "a.png").read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(raw):
+        n, kind = struct.unpack(">I4s", raw[at:at + 8])
+        body = raw[at + 8:at + 8 + n]
+        assert struct.unpack(">I", raw[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + body)
+        chunks.append((kind, body))
+        at += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 6, 0, 0, 0)
+    lines = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 1 + 4 * w)
+    assert (lines[:, 0] == 0).all() and np.array_equal(lines[:, 1:].reshape(h, w, 4), rgba8)
+    # more than one stored deflate block (65535 bytes each)
+    big = rng.integers(0, 256, (200, 160, 4), dtype=np.uint8)
+    pbr.write_png(tmp_path / "big.png", big)
+    rawb = (tmp_path / "big.png").read_bytes()
+    idat = rawb[rawb.index(b"IDAT") + 4:]
+    assert np.array_equal(np.frombuffer(zlib.decompress(idat[:-16]), np.uint8).reshape(200, 1 + 640)[:, 1:].reshape(200, 160, 4), big)
+
+    lin = rng.normal(size=(h, w, 4)).astype(np.float32)
+    lin[3, 4] = [np.inf, 0.0, -0.0, 1e-40]
+    pbr.write_exr(tmp_path / "b.exr", lin)
+    raw = (tmp_path / "b.exr").read_bytes()
+    assert struct.unpack("<II", raw[:8]) == (20000630, 2)
+    at, attrs = 8, {}
+    while raw[at] != 0:
+        end = raw.index(b"\0", at); name = raw[at:end].decode(); at = end + 1
+        end = raw.index(b"\0", at); kind = raw[at:end].decode(); at = end + 1
+        n = struct.unpack("<i", raw[at:at + 4])[0]
+        attrs[name] = (kind, raw[at + 4:at + 4 + n]); at += 4 + n
+    at += 1
+    assert set(attrs) == {"channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio", "screenWindowCenter", "screenWindowWidth"}
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, w - 1, h - 1) and attrs["displayWindow"] == attrs["dataWindow"]
+    ch, names = attrs["channels"][1], []
+    while ch[0] != 0:
+        end = ch.index(b"\0"); names.append(ch[:end].decode())
+        assert struct.unpack("<i4xii", ch[end + 1:end + 17]) == (2, 1, 1)       # FLOAT, no subsampling
+        ch = ch[end + 17:]
+    assert names == ["A", "B", "G", "R"]
+    offsets = struct.unpack("<%dQ" % h, raw[at:at + 8 * h])
+    got = np.zeros((h, w, 4), np.float32)
+    for y, off in enumerate(offsets):
+        line_y, size = struct.unpack("<ii", raw[off:off + 8])
+        assert (line_y, size) == (y, w * 16)
+        planes = np.frombuffer(raw[off + 8:off + 8 + size], np.float32).reshape(4, w)
+        got[h - 1 - y] = planes[[3, 2, 1, 0]].T                                  # A, B, G, R -> R, G, B, A; file row 0 = the top
+    assert offsets[-1] + 8 + w * 16 == len(raw)
+    assert np.array_equal(got.view(np.uint32), lin.view(np.uint32))                 # bit for bit, -0 and the denormal included
+    with pytest.raises(pbr.PbrError):
+        pbr.write_png(tmp_path / "no" / "dir.png", rgba8)
+    with pytest.raises(pbr.PbrError):
+        pbr.write_exr(tmp_path / "no" / "dir.exr", lin)
