@@ -25,6 +25,8 @@ const char* Cfg::RENDER_BRDF = "render.brdf";
 const char* Cfg::RENDER_MAXADDEDDEPTH = "render.max_added_depth";
 const char* Cfg::RENDER_MAXDEPTH = "render.max_depth";
 const char* Cfg::RENDER_PHONGTESS = "render.phong_tessellation";
+const char* Cfg::HIP_TRAVERSAL = "hip.traversal";
+const char* Cfg::HIP_ARITH = "hip.arith";
 const char* Cfg::RENDER_SAMPLES = "render.samples";
 const char* Cfg::RENDER_SHADOWRAYS = "render.shadow_rays";
 const char* Cfg::WINDOW_HEIGHT = "window.height";
@@ -64,6 +66,8 @@ void Cfg::resetDefaults() {
 	mValues[RENDER_MAXADDEDDEPTH] = "5";
 	mValues[RENDER_MAXDEPTH] = "3";
 	mValues[RENDER_PHONGTESS] = "0.0";
+	mValues[HIP_TRAVERSAL] = "0";
+	mValues[HIP_ARITH] = "0";
 	mValues[RENDER_SAMPLES] = "1";
 	mValues[RENDER_SHADOWRAYS] = "0";
 	mValues[WINDOW_HEIGHT] = "600";

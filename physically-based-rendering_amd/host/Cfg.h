@@ -58,6 +58,10 @@ class Cfg {
 		static const char* RENDER_MAXADDEDDEPTH;
 		static const char* RENDER_MAXDEPTH;
 		static const char* RENDER_PHONGTESS;
+		// Not reference keys: the two opt-in modes of the HIP core (include/pbr_hip.h, pbr_config.traversal / .arith).  A viewer that
+		// keeps the reference's config.json can switch them there: "hip": { "traversal": 2, "arith": 1 }; absent = 0 = the reference's behaviour.
+		static const char* HIP_TRAVERSAL;
+		static const char* HIP_ARITH;
 		static const char* RENDER_SAMPLES;
 		static const char* RENDER_SHADOWRAYS;
 		static const char* WINDOW_HEIGHT;

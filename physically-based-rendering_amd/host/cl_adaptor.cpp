@@ -214,6 +214,8 @@ void CL::uploadScene() {
 	config.sky_light[3] = 0.0f;
 	config.tile_world = 1;
 	config.tile_rank = 0;
+	config.traversal = cfg.value<uint32_t>( pbr::Cfg::HIP_TRAVERSAL );
+	config.arith = cfg.value<uint32_t>( pbr::Cfg::HIP_ARITH );
 
 	// "(float4)( r, g, b, 0.0f )", the numbers printed with %f (PathTracer.cpp:466-472,495-501,515): what the
 	// OpenCL compiler would have read is what is used here

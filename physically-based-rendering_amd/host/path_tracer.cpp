@@ -328,6 +328,8 @@ pbr_config PathTracer::makeConfig( const SceneBuffers& buffers, uint32_t width, 
 
 	cfg.tile_world = 1;
 	cfg.tile_rank = 0;
+	cfg.traversal = Cfg::get().value<uint32_t>( Cfg::HIP_TRAVERSAL );   // 0 unless the caller's configuration asks for a mode
+	cfg.arith = Cfg::get().value<uint32_t>( Cfg::HIP_ARITH );
 	return cfg;
 }
 

@@ -469,7 +469,8 @@ def test_path_tracer_driver_matches_device_calls(pbr, oracle, gpu_device):
     pt2.close()
 
 
-@pytest.mark.parametrize("cfg", [{"render.max_depth": 4}, {"render.max_depth": 3, "render.brdf": 0, "render.samples": 2}])
+@pytest.mark.parametrize("cfg", [{"render.max_depth": 4}, {"render.max_depth": 3, "render.brdf": 0, "render.samples": 2},
+                                 {"render.max_depth": 4, "hip.traversal": 2}])      # the ray-ordered walk, switched in the caller's configuration
 def test_cl_adaptor_driven_like_the_reference(pbr, oracle, gpu_device, cfg):
     """host/cl_adaptor.h: class CL with the reference's public methods over the C ABI, driven by the exact
     call sequence of the reference's PathTracer (createBuffer x 7, setReplacement, images, loadProgram,

@@ -272,3 +272,17 @@ def test_png_and_exr_writers(pbr, tmp_path):
         pbr.write_png(tmp_path / "no" / "dir.png", rgba8)
     with pytest.raises(pbr.PbrError):
         pbr.write_exr(tmp_path / "no" / "dir.exr", lin)
+
+
+def test_mode_keys_reach_the_configuration(cfg_defaults):
+    """"hip.traversal" / "hip.arith" (not reference keys; absent = 0 = the reference's behaviour) are how a viewer that keeps
+    the reference's config.json switches the HIP core's two opt-in modes: PathTracer::makeConfig copies them into pbr_config."""
+    pbr = cfg_defaults
+    sc = pbr.HostScene.generate("cornell", 1, 0)
+    cfg = sc.config(64, 64)
+    assert (cfg.traversal, cfg.arith) == (0, 0)
+    pbr.cfg_set(**{"hip.traversal": 2, "hip.arith": 1})
+    cfg = sc.config(64, 64)
+    assert (cfg.traversal, cfg.arith) == (2, 1)
+    pbr.cfg_reset()
+    assert (sc.config(64, 64).traversal, sc.config(64, 64).arith) == (0, 0)
