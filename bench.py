@@ -408,6 +408,13 @@ def main():
     if world != args.gpus:
         args.gpus = world
 
+    # ONE line on stdout: RCCL prints a five-line version banner to the C-level stdout when a communicator is created
+    # (seen with --force-dist on an MI355X), torch and the HIP runtime may print warnings there too.  From here on file
+    # descriptor 1 is stderr; the JSON line goes to the descriptor the process was started with.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import pbr_loader
     pbr = pbr_loader.load()
 
@@ -646,7 +653,8 @@ def main():
         if baseline is not None:
             out["cpu_baseline"] = baseline
         out["held_frames_untimed"] = held_frames
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
 
     if multi:
         dist.destroy_process_group()

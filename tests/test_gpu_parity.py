@@ -999,7 +999,9 @@ def test_bench_runs_the_rccl_leg_with_one_rank(tmp_path):
     forced = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl",
                              "--dump", str(tmp_path / "dist.npy")] + common, capture_output=True, text=True, timeout=900, env=env)
     assert forced.returncode == 0, forced.stderr[-3000:]
-    line = json.loads([ln for ln in forced.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    # ONE line on stdout, although RCCL prints its version banner to the C-level stdout when the communicator is created
+    assert len(forced.stdout.strip().splitlines()) == 1, forced.stdout[-2000:]
+    line = json.loads(forced.stdout.strip())
     assert line["n_gpus"] == 1 and (line["config"]["width"], line["config"]["height"]) == (1920, 1080)
     assert line["force_dist"] == {"backend": "nccl", "world_size": 1, "gathered_frame_equals_rendered": True, "gather_ms": line["force_dist"]["gather_ms"]}
     assert line["force_dist"]["gather_ms"] > 0 and len(line["per_rank_ms"]["render"]) == 1 and len(line["plan_votes"]) == 1
