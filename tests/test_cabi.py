@@ -174,3 +174,28 @@ def test_the_product_library_reads_no_environment_variable(pbr):
     for f in os.listdir(csrc):
         if f.endswith((".hip", ".hpp")):
             assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_reference_flavour_kernels_are_round_4s_register_for_register():
+    """Round 5 added two opt-in modes as BUILD FLAVOURS precisely so that the reference mode's kernels would not change
+    (csrc/pt_flavour.hpp: as run-time branches the modes cost the 80-register state machine its scratch-free build).  The
+    committed code-object metadata says they did not: every path-tracing kernel of flavour 0 (profiles/r05/isa) has the
+    VGPRs, the scratch and the spilled registers of its round-4 namesake (profiles/r04/isa), and the ordered flavour's
+    80-register state machine is scratch-free too."""
+    import json
+    r4 = {k["kernel"]: k for k in json.load(open(os.path.join(ROOT, "profiles", "r04", "isa", "kernels.json"))) if "pathTracing" in k["kernel"]}
+    r5 = {k["kernel"]: k for k in json.load(open(os.path.join(ROOT, "profiles", "r05", "isa", "kernels.json"))) if "pathTracing" in k["kernel"]}
+    seen = 0
+    for name, old in r4.items():
+        # ptk::pathTracingPhased<1, false, false, 6, 0>(ptk::DevParams) -> ptk_f0::pathTracingPhased<1, false, false, 6>(ptk_f0::DevParams)
+        new_name = name.replace("ptk::", "ptk_f0::").replace(", 0>(", ">(")
+        assert new_name in r5, name
+        new = r5[new_name]
+        for field in ("vgpr_count", "agpr_count", "private_segment_fixed_size", "vgpr_spill_count"):
+            assert new[field] == old[field], (name, field, old[field], new[field])
+        seen += 1
+    assert seen == 48                                       # 8 groups x 6 variants
+    flavours = {f: sum(1 for k in r5 if k.startswith("void ptk_f%d::" % f)) for f in range(4)}
+    assert flavours == {0: 48, 1: 42, 2: 42, 3: 42}, flavours
+    ordered_mid = r5["void ptk_f1::pathTracingPhased<1, false, false, 6>(ptk_f1::DevParams)"]
+    assert ordered_mid["vgpr_count"] <= 80 and ordered_mid["private_segment_fixed_size"] == 0 and ordered_mid["vgpr_spill_count"] == 0

@@ -710,11 +710,15 @@ def test_random_configurations_bit_exact(pbr, oracle, device, seed):
     assert device.counters() == ref.counter_dict(), what
 
 
-def test_guard_build_with_the_cxx_node_phase_gives_the_same_bits(pbr, device, tmp_path):
+@pytest.mark.parametrize("traversal", [0, 2])
+def test_guard_build_with_the_cxx_node_phase_gives_the_same_bits(pbr, device, tmp_path, traversal):
     """libpbrhip_guard.so (-DPBR_GUARD) bounds every device loop and compiles traverse()'s node phase from C++ instead
-    of the hand-scheduled block: same images, no guard trips.  Run in a child process (the library is chosen at import)."""
-    sc = make_scene(pbr, "sponza", 4, 9000, **{"render.max_depth": 3})
+    of the hand-scheduled block: same images, no guard trips — in the reference's walk and in the ray-ordered one (whose
+    forward-only links the bounded traversal loop also holds to "every node at most once").  Run in a child process (the
+    library is chosen at import)."""
+    sc = make_scene(pbr, "sponza", 4, 9000, **{"render.max_depth": 3, "hip.traversal": traversal})
     w, h = 64, 40
+    assert sc.config(w, h).traversal == traversal
     device.upload_scene(sc.desc)
     device.configure(sc.config(w, h))
     device.render(0, pbr.frame_seeds(0, 3), pbr.pixel_dimension(w, h), sc.camera())
@@ -725,7 +729,7 @@ def test_guard_build_with_the_cxx_node_phase_gives_the_same_bits(pbr, device, tm
         "sys.path.insert(0, %r)\n"
         "import pbr_loader\n"
         "pbr = pbr_loader.load()\n"
-        "pbr.cfg_reset(); pbr.cfg_set(**{'render.max_depth': 3})\n"
+        "pbr.cfg_reset(); pbr.cfg_set(**{'render.max_depth': 3, 'hip.traversal': %d})\n"
         "sc = pbr.HostScene.generate('sponza', 4, 9000)\n"
         "dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(sc.config(%d, %d))\n"
         "dev.render(0, pbr.frame_seeds(0, 3), pbr.pixel_dimension(%d, %d), sc.camera())\n"
@@ -736,7 +740,7 @@ def test_guard_build_with_the_cxx_node_phase_gives_the_same_bits(pbr, device, tm
         "    dev.pin_plan(plan); dev.set_knob('drain_mode', mode); dev.reset_accum()\n"
         "    dev.render(0, pbr.frame_seeds(0, 3), pbr.pixel_dimension(%d, %d), sc.camera())\n"
         "    assert dev.guard_trips() == [0, 0, 0], (plan, dev.guard_trips())\n"
-        "    assert np.array_equal(dev.read_output(), first, equal_nan=True), plan\n" % (ROOT, w, h, w, h, str(tmp_path / "guarded.npy"), w, h))
+        "    assert np.array_equal(dev.read_output(), first, equal_nan=True), plan\n" % (ROOT, traversal, w, h, w, h, str(tmp_path / "guarded.npy"), w, h))
     env = dict(os.environ, PBR_GUARD="1", PBR_LAB_ENV="1")
     done = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0, done.stderr[-2000:]
