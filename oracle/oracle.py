@@ -172,7 +172,7 @@ def scene_and_config(desc, cfg):
         c.sky_light[k] = cfg.sky_light[k]
     c.traversal = int(getattr(cfg, "traversal", 0))
     if c.traversal:
-        links, first = walk_orders(desc, c.traversal)
+        links, first = walk_orders(desc, 1 if c.traversal == 3 else c.traversal)     # 3: the stack-based analysis aid, over scheme 1's tables
         s.walk_links, s.walk_first = links.ctypes.data, first.ctypes.data
         s._walk = (links, first)          # the scene struct keeps the tables alive
     return s, c

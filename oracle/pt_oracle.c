@@ -1401,7 +1401,7 @@ int orc_build_walk_orders( const orc_bvh_node* bvh, int numNodes, int scheme, in
 	return 0;
 }
 
-static inline int walkOrderOf( int scheme, v3 d ) {
+static inline int walkOrderOf( int scheme, v3 d ) {   /* (scheme 3, the analysis aid above, walks its shadow rays in six orders) */
 	if( scheme == 2 ) {
 		return ( d.x < 0.0f ) | ( ( d.y < 0.0f ) << 1 ) | ( ( d.z < 0.0f ) << 2 );
 	}
@@ -1425,8 +1425,89 @@ static inline void noteWalk( uint32_t visits ) {
 	}
 }
 
+/* Analysis aid, NOT a mode of the product and not the reference's algorithm (cfg.traversal == 3; pbr_configure rejects it):
+ * the walk a STACK would allow — at every hit container all children are box-tested and the hit ones visited nearest
+ * first (by their boxes' entry distance tNear along THIS ray), a child whose tNear is no longer below ray.t when its turn
+ * comes is dropped without another test.  Its node count (box tests) is the bound the stackless ordered walks are measured
+ * against in profiles/r05/experiments/traversal_order.txt (VERDICT r04 quoted 0.57x / 0.72x / 0.93x for it).  Uses the
+ * scheme-1 tables only to enumerate a container's children ( hit = first child, next = sibling chain ). */
+static void traverseNearFirst( ctx_t* c, ray4* ray ) {
+	const v3 invDir = V3( det_rcp( ray->dir.x ), det_rcp( ray->dir.y ), det_rcp( ray->dir.z ) );
+	const int32_t* L = c->scene->walk_links;   /* order 0 of scheme 1: any order enumerates the children */
+	enum { MAXSTACK = 4096 };
+	int32_t stackNode[MAXSTACK];
+	float stackNear[MAXSTACK], stackFar[MAXSTACK];
+	int top = 0;
+	uint32_t visits = 0;
+	int container = 0;   /* the root: never tested itself (pt_bvh.cl:84) */
+
+	traverseLights( c, ray );
+
+	for( ;; ) {
+		/* test the children of `container`, push the hit ones farthest first */
+		int32_t kids[64];
+		float kNear[64], kFar[64];
+		int n = 0;
+		const int32_t stop = L[2 * container + 1];
+
+		for( int32_t child = L[2 * container]; child > 0 && child != stop && n < 64; child = L[2 * child + 1] ) {
+			const orc_bvh_node node = c->scene->bvh[child];
+			float tNear = 0.0f, tFar = ORC_INF;
+			c->dbg_nodes += 1.0f;
+			visits++;
+
+			if( intersectBox( ray, &invDir, node.bbMin, node.bbMax, &tNear, &tFar ) && tFar > EPSILON5 && ray->t > tNear ) {
+				kids[n] = child; kNear[n] = tNear; kFar[n] = tFar; n++;
+			}
+		}
+
+		for( int i = 1; i < n; i++ ) {   /* insertion sort, farthest first */
+			const int32_t k = kids[i]; const float a = kNear[i], b = kFar[i];
+			int j = i;
+			while( j > 0 && kNear[j - 1] < a ) { kids[j] = kids[j - 1]; kNear[j] = kNear[j - 1]; kFar[j] = kFar[j - 1]; j--; }
+			kids[j] = k; kNear[j] = a; kFar[j] = b;
+		}
+
+		for( int i = 0; i < n && top < MAXSTACK; i++ ) {
+			stackNode[top] = kids[i]; stackNear[top] = kNear[i]; stackFar[top] = kFar[i]; top++;
+		}
+
+		/* next: the nearest pending node that can still hold a closer hit */
+		container = -1;
+
+		while( top > 0 ) {
+			top--;
+
+			if( !( ray->t > stackNear[top] ) ) {
+				continue;
+			}
+
+			const orc_bvh_node node = c->scene->bvh[stackNode[top]];
+
+			if( node.bbMin.w >= 0.0f ) {
+				intersectFaces( c, ray, &node, stackNear[top], stackFar[top] );
+			}
+			else {
+				container = stackNode[top];
+				break;
+			}
+		}
+
+		if( container < 0 ) {
+			break;
+		}
+	}
+
+	noteWalk( visits );
+}
+
 /* traverse (pt_bvh.cl:82-123) with the successors of the ray's order: per visit the reference's statements */
 static void traverseOrdered( ctx_t* c, ray4* ray ) {
+	if( c->cfg->traversal == 3 ) {
+		traverseNearFirst( c, ray );
+		return;
+	}
+
 	const v3 invDir = V3( det_rcp( ray->dir.x ), det_rcp( ray->dir.y ), det_rcp( ray->dir.z ) );
 	const size_t N = (size_t) c->cfg->num_nodes;
 	const int k = walkOrderOf( c->cfg->traversal, ray->dir );

@@ -136,7 +136,7 @@ def test_ordered_walk_finds_the_reference_walks_hits(cfg_defaults, oracle, schem
     assert (c1[:, 0] >= 1).all()
 
 
-@pytest.mark.parametrize("scheme", sorted(SCHEMES))
+@pytest.mark.parametrize("scheme", sorted(SCHEMES) + [3])      # 3: the oracle's stack-based nearest-first walk, an analysis aid (the bound of the study)
 @pytest.mark.parametrize("kind,triangles,brdf,lit", [("cornell", 0, 1, True), ("sponza", 9000, 1, False), ("dragon", 9000, 0, False), ("hairball", 7000, 1, False)])
 def test_frames_in_either_order_agree_within_the_stated_tolerance(cfg_defaults, oracle, scheme, kind, triangles, brdf, lit):
     """|d| <= 1e-4 per channel on >= 99.5 % of the pixels and mean |d| <= 1e-5.  Only exact ties
