@@ -1,4 +1,6 @@
-"""Traversal-only probe, one walk per lane against two (lab build: scripts/lab.sh dual "").
+"""[round 4 only — needs a lab library built from round 4's sources: `git worktree add ../r04 047ae5b`; round 5 removed the
+-DPBR_LAB plumbing (pbr_lab_trace_stream_dual among it) from csrc/.]
+Traversal-only probe, one walk per lane against two (lab build: scripts/lab.sh dual "").
    PBR_HIP_LIB=lab/libpbrhip_dual.so python3 scripts/trace_dual.py [sponza dragon hairball]
 Rays: `coherent` = camera-like bundles (64 consecutive rays share an origin and differ by a small jitter), `random` =
 uniform origins and directions inside the scene's box.  Every variant must give the same (t, face) per ray and the same counts."""
