@@ -14,7 +14,9 @@ for job in (sys.argv[1:] or ["sponza:1", "sponza:8", "sponza:64", "dragon:1", "d
     kind, seed, tris, depth = SCENES[name]
     pbr.cfg_reset(); pbr.cfg_set(**{"render.max_depth": depth})
     sc = pbr.HostScene.generate(kind, seed, tris)
-    dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(sc.config(W, H))
+    cfg = sc.config(W, H)
+    cfg.traversal, cfg.arith = int(os.environ.get("AB_TRAVERSAL", "0")), int(os.environ.get("AB_ARITH", "0"))     # pbr_config's opt-in modes
+    dev = pbr.Device(0); dev.upload_scene(sc.desc); dev.configure(cfg)
     cam, px = sc.camera(), pbr.pixel_dimension(W, H)
     dev.render(0, pbr.frame_seeds(0, 16), px, cam)
     dev.reset_accum()
@@ -29,8 +31,8 @@ for job in (sys.argv[1:] or ["sponza:1", "sponza:8", "sponza:64", "dragon:1", "d
     span = end - first_start
     first_dry = (~raw[6]) & M
     us = lambda t: t / 100.0
-    print("%-8s %3d frame(s) %s kernel %.3f ms | %d waves, span %.0f us, last wave starts at +%.0f us, queue first empty at +%.0f us (%.0f %% of the span), "
+    print("%-8s traversal %d %3d frame(s) %s kernel %.3f ms | %d waves, span %.0f us, last wave starts at +%.0f us, queue first empty at +%.0f us (%.0f %% of the span), "
           "mean wave busy %.1f %% of the span, mean drain per wave %.0f us, longest drain %.0f us" % (
-              name, frames, dev.last_plan()[0], dev.last_trace()[0], waves, us(span), us(last_start - first_start), us(first_dry - first_start),
+              name, cfg.traversal, frames, dev.last_plan()[0], dev.last_trace()[0], waves, us(span), us(last_start - first_start), us(first_dry - first_start),
               100.0 * (first_dry - first_start) / span, 100.0 * raw[12] / (waves * span), us(raw[4] / max(waves, 1)), us(raw[5])), flush=True)
     dev.close()
