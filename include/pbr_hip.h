@@ -126,6 +126,11 @@ typedef struct {
  * plus shaded hits and camera paths) summed over everything rendered since the last reset. */
 typedef struct { uint64_t nodes, tris, hits, paths; } pbr_counters;
 
+/* Which modes this build of the library carries: 1 if every plan's kernels for ( traversal, arith ) were linked in, 0 if not
+ * (a build may leave a mode's translation units out), -1 for values that are no mode.  No device
+ * is needed.  pbr_configure accepts any valid mode; a render in a mode that was not built fails with a message. */
+int pbr_mode_built( uint32_t traversal, uint32_t arith );
+
 /* new CL() — platform / device / context / profiling queue (source/CL.cpp:10-24). */
 int pbr_create( int device, pbr_ctx** out );
 /* ~CL() (source/CL.cpp:30-52) */

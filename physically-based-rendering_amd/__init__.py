@@ -134,6 +134,7 @@ hip.pbr_diag_guard_trips.argtypes = [_vp, _up]
 hip.pbr_diag_last_trace.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
 hip.pbr_diag_last_plan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
 hip.pbr_diag_pin_plan.argtypes = [_vp, ctypes.c_int]
+hip.pbr_mode_built.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
 hip.pbr_diag_last_kernel.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
 hip.pbr_diag_launch_fit.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
 if hasattr(hip, "pbr_diag_set_knob"):       # absent from round 2's library (A/B runs against it: PBR_HIP_LIB)

@@ -802,7 +802,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		status = ( status != PBR_OK ) ? status : makePlan( PTI_REFILL_WIDE, "refill-wide", 0, 0, &plans[1] );
 		status = ( status != PBR_OK ) ? status : makePlan( PTI_PHASED_LEAN, "phased-lean", 16, 32, &plans[2] );
 		status = ( status != PBR_OK ) ? status : makePlan( PTI_PHASED_WIDE, "phased-wide", 16, 48, &plans[3] );
-		status = ( status != PBR_OK ) ? status : makePlan( PTI_PHASED_MID, "phased-mid", 16, 40, &plans[4], kMidBlockThreads );
+		// The state machine's thresholds (lanes that leave a node phase before it ends / lanes that wait before a shade phase):
+		// 16 / 40 in the reference's walk (profiles/r03/experiments/sweep_thresholds.txt).  A ray-ordered walk makes fewer visits per
+		// shading, and its 6-waves build does best at 12 / 48: Dragon-class +1.5 % (exact) / +2.5 % (native), hairball +0.1 … +0.3 %,
+		// Sponza-class -0.3 … -1.2 % — where the two-paths plan wins anyway (profiles/r05/experiments/sweep_thresholds_ordered_walk*.txt).
+		const bool orderedWalk = ( flavour & 1 ) != 0;
+		status = ( status != PBR_OK ) ? status : makePlan( PTI_PHASED_MID, "phased-mid", orderedWalk ? 12 : 16, orderedWalk ? 48 : 40, &plans[4], kMidBlockThreads );
 		status = ( status != PBR_OK ) ? status : makePlan( PTI_REFILL_MID, "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
 		// 28 of a wave's up to 128 walks leave a node phase before it ends; a shade phase waits for 48 lanes (measured:
 		// profiles/r04/experiments/two_paths_per_lane.txt).  Without the hand-scheduled node phase: phased-mid's kernel and thresholds.
@@ -1126,6 +1131,26 @@ int readTiled( pbr_ctx* ctx, const float4* tiles, float* rgba, int tileWorld, in
 
 
 extern "C" {
+
+int pbr_mode_built( uint32_t traversal, uint32_t arith ) {
+	if( traversal > 2 || arith > 1 ) {
+		return -1;
+	}
+
+	const int flavour = ( ( traversal != 0 ) ? 1 : 0 ) | ( ( arith != 0 ) ? 2 : 0 );
+
+	for( int group = 0; group < PTI_GROUPS; group++ ) {
+		// the Phong-tessellation build exists in flavour 0 only; builds without the hand-scheduled node phase have no two-paths kernels
+		if( ( group == PTI_REFILL_PHONG && flavour != 0 ) || ( group == PTI_DUAL && !kDualIsDual ) ) {
+			continue;
+		}
+		if( kPickers[flavour][group] == nullptr ) {
+			return 0;
+		}
+	}
+
+	return 1;
+}
 
 int pbr_create( int device, pbr_ctx** out ) {
 	if( out == nullptr ) {

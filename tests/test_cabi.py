@@ -199,3 +199,12 @@ def test_reference_flavour_kernels_are_round_4s_register_for_register():
     assert flavours == {0: 48, 1: 42, 2: 42, 3: 42}, flavours
     ordered_mid = r5["void ptk_f1::pathTracingPhased<1, false, false, 6>(ptk_f1::DevParams)"]
     assert ordered_mid["vgpr_count"] <= 80 and ordered_mid["private_segment_fixed_size"] == 0 and ordered_mid["vgpr_spill_count"] == 0
+
+
+def test_every_mode_is_built_into_the_product_library(pbr):
+    """pbr_mode_built: the product library carries all four build flavours (reference / ray-ordered walk x exact / native
+    arithmetic); no device needed to ask."""
+    for traversal in (0, 1, 2):
+        for arith in (0, 1):
+            assert pbr.hip.pbr_mode_built(traversal, arith) == 1, (traversal, arith)
+    assert pbr.hip.pbr_mode_built(3, 0) == -1 and pbr.hip.pbr_mode_built(0, 2) == -1
