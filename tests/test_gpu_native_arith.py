@@ -132,3 +132,46 @@ def test_native_arithmetic_is_one_definition_in_every_plan(pbr, device, plan):
     got = device.read_output()
     assert np.array_equal(got, want, equal_nan=True)
     assert device.counters() == counters          # (reset_accum zeroes them)
+
+
+@pytest.mark.parametrize("traversal", [0, 2])
+@pytest.mark.parametrize("brdf", [0, 1])
+@pytest.mark.parametrize("lit,shadow", [(False, 0), (True, 0), (True, 1)])
+def test_every_native_kernel_variant_renders(pbr, device, traversal, brdf, lit, shadow):
+    """The statistical tests above run four configurations; the native flavours hold 2 x 6 x 7 kernels.  Every variant
+    (BRDF 0 / 1 x no lights / orb + point light / + shadow rays, in the reference's walk and in eight orders) in the state
+    machine, the two-paths plan and the lock-step kernel: finite, run-to-run identical, every plan the same bits, the same
+    counters-per-path regime as the exact mode, and an image mean within 2 % of the exact mode's on the same seeds (64 spp
+    over 3072 pixels: the means' own noise is a few tenths of a per cent)."""
+    from test_gpu_parity import PLANS
+    from test_gpu_walk_order import cornell_lights
+    sc = make_scene(pbr, **{"render.max_depth": 4, "render.brdf": brdf})
+    w, h = 64, 48
+    cfg, cam, px, seeds = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h), pbr.frame_seeds(0, 64)
+    desc, keep = (cornell_lights(pbr, sc) if lit else (sc.desc, None))
+    cfg.shadow_rays, cfg.traversal = shadow, traversal
+    device.upload_scene(desc)
+    device.configure(cfg)
+    device.render(0, seeds, px, cam)
+    exact, exact_counters = device.read_output()[..., :3].astype(np.float64), device.counters()
+    native = pbr.Config.from_buffer_copy(cfg)
+    native.arith = 1
+    device.configure(native)
+    first = None
+    for plan in ("phased-mid", "phased-dual", "refill-mid", "phased-mid"):
+        device.pin_plan(PLANS[plan])
+        device.reset_accum()
+        device.render(0, seeds, px, cam)
+        got, counters = device.read_output(), device.counters()
+        assert device.last_plan()[0] == plan and device.last_kernel().startswith("ptk_f%d::" % (2 | (1 if traversal else 0)))
+        assert np.isfinite(got[..., :3]).all(), plan
+        if first is None:
+            first = (got, counters)
+        assert np.array_equal(got, first[0]) and counters == first[1], plan       # every plan, and the same plan again
+    got = first[0][..., :3].astype(np.float64)
+    finite = np.isfinite(exact).all(axis=2)
+    assert finite.mean() > 0.99           # (the EXACT mode leaves a handful of pixels non-finite with BRDF 0 + shadow rays: the reference's own NaN)
+    assert abs(got[finite].mean() - exact[finite].mean()) <= 0.02 * exact[finite].mean(), (got[finite].mean(), exact[finite].mean())
+    assert first[1]["paths"] == exact_counters["paths"]
+    for k in ("nodes", "tris", "hits"):
+        assert abs(first[1][k] - exact_counters[k]) <= 0.02 * exact_counters[k], (k, first[1][k], exact_counters[k])

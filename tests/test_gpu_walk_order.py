@@ -168,7 +168,7 @@ def test_mode_validation(pbr, device, tmp_path):
 def test_random_configurations_in_an_ordered_mode(pbr, oracle, device, seed):
     """The seeded differential sweep of test_gpu_parity.py in the two ordered modes: scene kind / size, image shape,
     depths, samples, BRDF, anti-aliasing, lights + shadow rays, plan, LDS share, frames per launch pair.  96 seeds in the
-    suite; PBR_WALK_SOAK_SEEDS=n runs the first n (a soak of 6000 is logged in profiles/r05/soak_walk.txt)."""
+    suite; PBR_WALK_SOAK_SEEDS=n runs the first n (a soak of 30 000 is logged in profiles/r05/soak_walk.txt)."""
     rng = np.random.default_rng(77000 + seed)
     mode = 1 + seed % 2
     kind = ["cornell", "sponza", "dragon", "hairball"][rng.integers(4)]
