@@ -56,12 +56,16 @@ def look(pbr, eye, center):
     return cam
 
 
-def test_single_triangle_distances_by_hand(pbr, device):
+@pytest.mark.parametrize("traversal", [0, 1, 2])
+def test_single_triangle_distances_by_hand(pbr, device, traversal):
     """flatTriAndRayIntersect (pt_intersect.cl:92-129) through the stackless walk: rays straight down on the triangle
     hit at their height, rays beside it or from below its plane's far side in the wrong direction miss; one node visit
     and one face test each (node 1 is always visited, pt_bvh.cl:84-88)."""
     desc, keep = one_triangle_scene(pbr)
     device.upload_scene(desc)
+    cfg = plain_config(pbr, 8, 8)
+    cfg.traversal = traversal                        # the ray-ordered walks (round 5) over a tree of one leaf: the same known answers
+    device.configure(cfg)
     heights = np.array([0.5, 1.0, 2.0, 3.0, 8.0, 64.0], np.float32)
     rays = []
     for z in heights:
@@ -83,9 +87,10 @@ def test_single_triangle_distances_by_hand(pbr, device):
     assert abs(float(t[-1]) - 2.0) <= 1e-6 and face[-1] == 0
 
 
+@pytest.mark.parametrize("traversal,arith", [(0, 0), (2, 0), (0, 1), (2, 1)])
 @pytest.mark.parametrize("brdf", [1, 0])
 @pytest.mark.parametrize("frames", [1, 5])
-def test_sky_only_frames_are_the_sky_colour_exactly(pbr, device, brdf, frames):
+def test_sky_only_frames_are_the_sky_colour_exactly(pbr, device, brdf, frames, traversal, arith):
     """A camera that sees no geometry: every path leaves at depth 0 with color = 1, so finalColor = SKY_LIGHT
     (pathtracing.cl:263-266,320-323), secondaryPaths = 1, and the running mean of equal frames is that value
     (pt_rgb.cl:9-21: c + ( prev - c ) * w with prev == c); .w = the first-hit distance = INFINITY."""
@@ -93,6 +98,7 @@ def test_sky_only_frames_are_the_sky_colour_exactly(pbr, device, brdf, frames):
     sky = (0.75, 0.5, 0.25)
     cfg = plain_config(pbr, 64, 40, brdf=brdf, sky=sky)
     cfg.anti_aliasing = 1.0
+    cfg.traversal, cfg.arith = traversal, arith      # exact in every mode: no arithmetic touches the colour ( x * rcp( 1 ) = x )
     cam = look(pbr, (0.3, 0.3, 5.0), (0.3, 0.3, 0.0))                        # the view direction is eye - center (Camera.cpp): away from the triangle
     device.upload_scene(desc)
     device.configure(cfg)
@@ -104,8 +110,9 @@ def test_sky_only_frames_are_the_sky_colour_exactly(pbr, device, brdf, frames):
     assert c == {"nodes": 64 * 40 * frames, "tris": 0, "hits": 0, "paths": 64 * 40 * frames}
 
 
+@pytest.mark.parametrize("traversal,arith", [(0, 0), (2, 0), (0, 1), (2, 1)])
 @pytest.mark.parametrize("brdf", [1, 0])
-def test_depth_exhausted_paths_contribute_nothing(pbr, device, brdf):
+def test_depth_exhausted_paths_contribute_nothing(pbr, device, brdf, traversal, arith):
     """MAX_DEPTH = 1, no added depth: a path whose first hit is an opaque surface ends there with no contribution
     (pathtracing.cl:274-276) — the pixel is exactly 0 with a finite first-hit distance — and a path that misses is the
     sky.  (BRDF 0 draws extendDepth's random number first, pt_utils.cl:89-96: rough = 1 never extends.)"""
@@ -113,6 +120,7 @@ def test_depth_exhausted_paths_contribute_nothing(pbr, device, brdf):
     sky = (0.75, 0.5, 0.25)
     w, h = 96, 64
     cfg = plain_config(pbr, w, h, brdf=brdf, depth=1, added=0, sky=sky)
+    cfg.traversal, cfg.arith = traversal, arith
     cam = look(pbr, (0.3, 0.3, 2.0), (0.3, 0.3, 4.0))                        # straight down on the triangle (view direction = eye - center)
     device.upload_scene(desc)
     device.configure(cfg)
@@ -129,13 +137,17 @@ def test_depth_exhausted_paths_contribute_nothing(pbr, device, brdf):
     assert c["paths"] == w * h * 3 and c["nodes"] == c["paths"] and c["hits"] == int(hit.sum()) * 3
 
 
-def test_closest_hits_against_brute_force_in_float64(pbr, device):
+@pytest.mark.parametrize("traversal", [0, 1, 2])
+def test_closest_hits_against_brute_force_in_float64(pbr, device, traversal):
     """The walk over the host-built BVH (20 k triangles) returns the geometric closest hit: Moeller-Trumbore over ALL
     triangles in float64 numpy, no tree, no oracle."""
     pbr.cfg_reset()
     sc = pbr.HostScene.generate("dragon", 9, 20000)
     arr = sc.arrays()
     device.upload_scene(sc.desc)
+    cfg = sc.config(8, 8)
+    cfg.traversal = traversal
+    device.configure(cfg)
     rng = np.random.default_rng(3)
     v = arr["vertices"][:, :3]
     n = 400
