@@ -883,12 +883,15 @@ def test_full_hd_sharded_equals_unsharded(pbr, device):
     d.close()
 
 
-def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
+@pytest.mark.parametrize("mode", [[], ["--traversal", "eight-order", "--arith", "native"]])
+def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path, mode):
     """bench.py's N > 1 path (tile sharding + all-gather + scatter) rehearsed with two processes on
-    ONE GPU (gloo): the gathered frame is the single-rank frame, bit for bit, and every path is counted."""
+    ONE GPU (gloo): the gathered frame is the single-rank frame, bit for bit, and every path is counted — in the default
+    mode and with both opt-in modes on (every plan of a mode renders the same bits, so the vote's outcome does not show)."""
     import json
     import subprocess
-    common = ["--steps", "3", "--warmup", "1", "--width", "256", "--height", "144", "--cpu-seconds", "0", "--repeats", "2", "--triangles", "20000"]
+    common = ["--steps", "3", "--warmup", "1", "--width", "256", "--height", "144", "--cpu-seconds", "0", "--repeats", "2", "--triangles", "20000",
+              "--hold-seconds", "0"] + mode
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dump", str(tmp_path / "one.npy")] + common,
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -905,6 +908,8 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
     assert j2["roofline"]["algorithmic_GBs"] > 0 and j2["value"] > 0
     assert j1["repeats"] == j2["repeats"] == 2 and len(j2["per_rank_ms"]["render"]) == 2
     assert j1["config"]["scene"] == "sponza" and j2["schedule_tuned"]     # the elected plan, pinned on both ranks
+    assert j2["config"]["traversal"] == ("eight-order" if mode else "reference") and j2["config"]["arith"] == ("native" if mode else "exact")
+    assert j2["roofline"]["kernel"].startswith("ptk_f3::" if mode else "ptk_f0::")
     assert len(j2["plan_votes"]) == 2 and j2["schedule"] in [pbr_plan_name(v) for v in j2["plan_votes"]]
     assert same_values(np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy"))
 
