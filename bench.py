@@ -622,6 +622,8 @@ def main():
                 "host_bvh_build_s": round(t_build, 3),
                 # the two opt-in modes of round 5 (include/pbr_hip.h); "reference" / "exact" is the reference's behaviour and the headline
                 "traversal": args.traversal, "arith": args.arith,
+                # what the mode costs in node memory: the reference-order stream, and the ordered walk's six / eight streams
+                "scene_device_bytes": dev.scene_bytes(),
             },
             "repeats": repeats, "ms_per_step_all": [round(r[0] * 1e3 / args.steps, 5) for r in per_run],
             "setup_frames": setup_frames, "setup_s": round(t_setup, 3),

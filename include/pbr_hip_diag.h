@@ -46,6 +46,10 @@ int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t r
  * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
 int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
 
+/* Device memory of the uploaded scene's arrays, bytes: [0] the node stream in the reference's order, [1] the streams of
+ * the ray-ordered walk (0 until a render in such a mode has built them: six or eight times [0]), [2] the face records. */
+int pbr_diag_scene_bytes( pbr_ctx* ctx, uint64_t out[3] );
+
 /* The kernel behind pbr_diag_last_plan's schedule, as a profiler prints its symbol (without "void " and the argument
  * list): "ptk_f0::pathTracingDual<1, false, false>" — namespace ptk_f<flavour> (bit 0: ray-ordered walk, bit 1: native
  * arithmetic; csrc/pt_flavour.hpp), template arguments BRDF, SHADOW_RAYS, LIGHTS[, waves per SIMD[, PHONGTESS]]. */

@@ -134,6 +134,7 @@ hip.pbr_diag_guard_trips.argtypes = [_vp, _up]
 hip.pbr_diag_last_trace.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
 hip.pbr_diag_last_plan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
 hip.pbr_diag_pin_plan.argtypes = [_vp, ctypes.c_int]
+hip.pbr_diag_scene_bytes.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64)]
 hip.pbr_mode_built.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
 hip.pbr_diag_last_kernel.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
 hip.pbr_diag_launch_fit.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
@@ -497,6 +498,12 @@ class Device:
         name, tuned = ctypes.create_string_buffer(48), ctypes.c_int(-1)
         self._check(hip.pbr_diag_last_plan(self._ctx, name, 48, ctypes.byref(tuned)))
         return name.value.decode(), int(tuned.value)
+
+    def scene_bytes(self):
+        """Device bytes of the scene: {"nodes": reference-order stream, "walk_streams": the ordered walk's (0 until built), "faces"}."""
+        out = (ctypes.c_uint64 * 3)()
+        self._check(hip.pbr_diag_scene_bytes(self._ctx, out))
+        return {"nodes": int(out[0]), "walk_streams": int(out[1]), "faces": int(out[2])}
 
     def last_kernel(self):
         """The symbol of the kernel behind last_plan()[0], as a profiler prints it: "ptk_f0::pathTracingDual<1, false, false>"."""

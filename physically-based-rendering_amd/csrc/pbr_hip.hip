@@ -79,6 +79,7 @@ struct pbr_ctx {
 	uint32_t walkBuilt = 0;        // the scheme dNodesWalk holds (0: none)
 	uint32_t walkHotAvail = 0;     // records at the head of dNodesWalk that are ranked for LDS staging (all orders interleaved)
 	int walkFirst[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	uint64_t nodeBytes = 0, walkBytes = 0, triBytes = 0;   // device bytes of the reference-order stream, the ordered streams, the face records
 	uint32_t numNodes = 0, numFaces = 0, numMaterials = 0, numLights = 0;
 	uint32_t sceneBrdf = 1;
 
@@ -479,6 +480,7 @@ int buildWalkStreams( pbr_ctx* ctx, uint32_t scheme ) {
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dNodesWalk, sizeof( float4 ) * storage.size() ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dNodesWalk, storage.data(), sizeof( float4 ) * storage.size(), hipMemcpyHostToDevice ) );
 	ctx->walkHotAvail = hotPerOrder * (uint32_t) K;
+	ctx->walkBytes = sizeof( float4 ) * storage.size();
 	ctx->walkBuilt = scheme;
 	return PBR_OK;
 }
@@ -1520,6 +1522,9 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dMats, sizeof( float4 ) * mats.size() ) );
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dLights, sizeof( float4 ) * lights.size() ) );
 	HIP_TRY( ctx, hipMemcpy( ctx->dNodes, nodes.data(), sizeof( float4 ) * nodes.size(), hipMemcpyHostToDevice ) );
+	ctx->nodeBytes = sizeof( float4 ) * nodes.size();
+	ctx->triBytes = sizeof( float4 ) * tris.size();
+	ctx->walkBytes = 0;
 
 	HIP_TRY( ctx, hipMemcpy( ctx->dTris, tris.data(), sizeof( float4 ) * tris.size(), hipMemcpyHostToDevice ) );
 
@@ -1850,19 +1855,14 @@ struct DevBuf {
 	hipError_t alloc( size_t bytes ) { return hipMalloc( &p, bytes ? bytes : 4 ); }
 };
 
-// The scene for the diagnostic and denoise kernels.  They walk in the configured order (pbr_config.traversal) when its
-// streams can be built, in the reference's otherwise; hotAvail: the ranked prefix of that stream.
-DevParams sceneParams( pbr_ctx* ctx, uint32_t* hotAvail = nullptr ) {
+// The scene for the diagnostic and denoise kernels, walked in the configured order (pbr_config.traversal); hotAvail: the
+// ranked prefix of that stream.  *status: PBR_OK, or why the configured walk's streams could not be built (the caller fails
+// with it — no silent walk in another order).
+DevParams sceneParams( pbr_ctx* ctx, int* status, uint32_t* hotAvail = nullptr ) {
 	DevParams P;
 	std::memset( &P, 0, sizeof( P ) );
 	uint32_t hot = 0;
-
-	if( applyWalk( ctx, &P, &hot ) != PBR_OK ) {
-		P.nodes = ctx->dNodes;
-		P.firstRef = ctx->firstRef;
-		P.walkScheme = 0;
-		hot = ctx->numHotAvail;
-	}
+	*status = applyWalk( ctx, &P, &hot );
 
 	if( hotAvail != nullptr ) {
 		*hotAvail = hot;
@@ -1923,7 +1923,12 @@ int pbr_denoise( pbr_ctx* ctx, float pxDim, const pbr_camera* cam, const pbr_den
 	HIP_TRY( ctx, dPing.alloc( sizeof( float4 ) * pixels ) );
 	HIP_TRY( ctx, dPong.alloc( sizeof( float4 ) * pixels ) );
 
-	DevParams P = sceneParams( ctx );
+	int walkStatus = PBR_OK;
+	DevParams P = sceneParams( ctx, &walkStatus );
+
+	if( walkStatus != PBR_OK ) {
+		return walkStatus;
+	}
 	const float* src[4] = { &cam->eye.x, &cam->w.x, &cam->u.x, &cam->v.x };
 	float* dst[4] = { P.eye, P.cw, P.cu, P.cv };
 
@@ -2270,7 +2275,12 @@ int pbr_diag_trace( pbr_ctx* ctx, const float* rays, int n, float* out_t, int32_
 	HIP_TRY( ctx, dCounts.alloc( sizeof( unsigned ) * 2 * (size_t) n ) );
 	HIP_TRY( ctx, hipMemcpy( dRays.p, rays, sizeof( float ) * 6 * (size_t) n, hipMemcpyHostToDevice ) );
 
-	const DevParams P = sceneParams( ctx );
+	int walkStatus = PBR_OK;
+	const DevParams P = sceneParams( ctx, &walkStatus );
+
+	if( walkStatus != PBR_OK ) {
+		return walkStatus;
+	}
 	const dim3 grid( (unsigned) ( ( n + 63 ) / 64 ) ), block( 64 );
 
 	if( ctx->numLights > 0 ) {
@@ -2307,7 +2317,12 @@ int diagPerItem( pbr_ctx* ctx, const float* in, int n, float* out, int inWidth, 
 	HIP_TRY( ctx, dOut.alloc( sizeof( float ) * outWidth * (size_t) n ) );
 	HIP_TRY( ctx, hipMemcpy( dIn.p, in, sizeof( float ) * inWidth * (size_t) n, hipMemcpyHostToDevice ) );
 
-	const DevParams P = sceneParams( ctx );
+	int walkStatus = PBR_OK;
+	const DevParams P = sceneParams( ctx, &walkStatus );
+
+	if( walkStatus != PBR_OK ) {
+		return walkStatus;
+	}
 	const dim3 grid( (unsigned) ( ( n + 63 ) / 64 ) ), block( 64 );
 
 	if( newRay ) {
@@ -2357,7 +2372,12 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 	HIP_TRY( ctx, hipMemcpy( dRays.p, rays8, sizeof( float ) * 8 * (size_t) n, hipMemcpyHostToDevice ) );
 
 	uint32_t hotAvail = 0;
-	DevParams P = sceneParams( ctx, &hotAvail );
+	int walkStatus = PBR_OK;
+	DevParams P = sceneParams( ctx, &walkStatus, &hotAvail );
+
+	if( walkStatus != PBR_OK ) {
+		return walkStatus;
+	}
 	P.workCounter = ctx->dWork;
 	P.counters = ctx->dCounters;
 	ctx->workClean = false;   // this probe uses the queue heads its own way
@@ -2463,6 +2483,17 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned ) 
 		*tuned = ctx->tunedPlan;
 	}
 
+	return PBR_OK;
+}
+
+int pbr_diag_scene_bytes( pbr_ctx* ctx, uint64_t out[3] ) {
+	if( ctx == nullptr || out == nullptr || !ctx->hasScene ) {
+		return fail( ctx, PBR_ESTATE, "diag_scene_bytes: no scene" );
+	}
+
+	out[0] = ctx->nodeBytes;
+	out[1] = ctx->walkBytes;
+	out[2] = ctx->triBytes;
 	return PBR_OK;
 }
 

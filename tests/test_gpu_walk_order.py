@@ -102,6 +102,10 @@ def test_the_tuner_and_a_mode_switch(pbr, oracle, device, mode):
         assert spent == ref.counter_dict()
         images[m] = spent
     assert images[mode]["nodes"] < images[0]["nodes"]
+    # what the mode costs in node memory: six / eight streams of the same records + the 32-byte table of first references
+    mem = device.scene_bytes()
+    orders = {1: 6, 2: 8}[mode]
+    assert mem["nodes"] == 32 * sc.desc.num_nodes and mem["walk_streams"] == orders * (mem["nodes"] - 32) + 32 + 32, mem
 
 
 @pytest.mark.parametrize("mode", sorted(MODES))
