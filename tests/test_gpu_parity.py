@@ -224,13 +224,16 @@ def test_schedule_tuner_through_a_viewer_then_a_batch(pbr, oracle, device):
     device.upload_scene(sc.desc)
     device.configure(cfg)
     first = 0
-    for n in [1] * 30 + [60, 40]:
+    # screening 7 plans x 2 launches, refinement <= 3 finalists x 4 launches — and once more when the best two end within
+    # 5 % of each other (a close call, decided by this box's timing): 26 or 38 launches.  (Round 5: the assertion stood at 30
+    # and failed once in a dozen full-suite runs.)
+    for n in [1] * 44 + [60, 40]:
         seeds = pbr.frame_seeds(first, n)
         want = ref.render(first, seeds, px, cam)
         device.render(first, seeds, px, cam)
         first += n
-        if n == 1 and first == 30:
-            assert device.last_plan()[1] >= 0, "30 single-frame launches settle the tuner"
+        if n == 1 and first == 44:
+            assert device.last_plan()[1] >= 0, "44 single-frame launches settle the tuner"
     assert device.last_plan()[1] >= 0
     got = device.read_output()
     assert same_values(got, want), describe_mismatch(got, want)
