@@ -8,6 +8,11 @@
  * file:line it restates, pt_phongtess.cl (PHONGTESS=1, off in the reference's
  * config.json:105) included.
  *
+ * ONE section is NOT a restatement of the reference: "Ray-ordered walk" (cfg.traversal != 0) states the product's
+ * opt-in walk order over the same flat tree, so that the HIP path of that mode has a bit-exact checker; it is marked
+ * where it stands, the default (cfg.traversal == 0) never enters it, and what it owes the reference's own order is tested
+ * separately (tests/test_walk_order_cpu.py).
+ *
  * Build: gcc -O2 -std=c11 -ffp-contract=off -mfma -fopenmp -shared -fPIC
  */
 #include "pt_oracle.h"
