@@ -175,3 +175,48 @@ def test_every_native_kernel_variant_renders(pbr, device, traversal, brdf, lit, 
     assert first[1]["paths"] == exact_counters["paths"]
     for k in ("nodes", "tris", "hits"):
         assert abs(first[1][k] - exact_counters[k]) <= 0.02 * exact_counters[k], (k, first[1][k], exact_counters[k])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PBR_NATIVE_SOAK_SEEDS", "48"))))
+def test_random_configurations_in_the_native_arithmetic(pbr, device, seed):
+    """The configuration sweep of test_gpu_parity.py with arith = native (and a random traversal): there is no bit-exact
+    checker for this mode, so what is held is what must hold for ANY arithmetic — the render completes (no fault, no guard
+    trip), is deterministic (the same call twice: the same bits and counters), counts every path once, and stays finite
+    wherever it is not black-walled by the mode's own firewall.  48 seeds in the suite; PBR_NATIVE_SOAK_SEEDS=n for more."""
+    from test_gpu_parity import force_schedule
+    from test_gpu_walk_order import cornell_lights
+    rng = np.random.default_rng(505000 + seed)
+    kind = ["cornell", "sponza", "dragon", "hairball"][rng.integers(4)]
+    tris = 0 if kind == "cornell" else int(rng.integers(300, 6000))
+    keys = {
+        "render.max_depth": int(rng.integers(1, 6)), "render.max_added_depth": int(rng.integers(0, 4)),
+        "render.samples": int(rng.integers(1, 4)), "render.brdf": int(rng.integers(2)),
+        "render.antialiasing": float(rng.choice([0.0, 0.7, 1.5])), "bvh.skip_ahead": bool(rng.integers(2)),
+    }
+    schedule = [None, "refill-lean", "refill-wide", "phased-lean", "phased-wide", "phased-mid", "refill-mid", "phased-dual"][rng.integers(8)]
+    force_schedule(device, schedule)
+    if rng.integers(3) == 0:
+        device.set_knob("lds_slots", int(rng.integers(0, 200)))
+    if rng.integers(2):
+        device.set_knob("chunk_frames", int(rng.integers(1, 4)))
+    w, h = 8 * int(rng.integers(1, 12)), 8 * int(rng.integers(1, 9))
+    frames, first = int(rng.integers(1, 6)), int(rng.integers(0, 3))
+    sc = make_scene(pbr, kind, int(rng.integers(1, 100)), tris, **keys)
+    cfg, desc, keep = sc.config(w, h), sc.desc, None
+    cfg.arith, cfg.traversal = 1, int(rng.integers(3))
+    if kind == "cornell" and rng.integers(2):
+        desc, keep = cornell_lights(pbr, sc)
+        cfg.shadow_rays = int(rng.integers(2))
+    cam, px, seeds = sc.camera(), pbr.pixel_dimension(w, h), pbr.frame_seeds(first, frames)
+    device.upload_scene(desc)
+    device.configure(cfg)
+    device.render(first, seeds, px, cam)
+    a, ca = device.read_output(), device.counters()
+    assert device.guard_trips() == [0, 0, 0]
+    device.reset_accum()
+    device.render(first, seeds, px, cam)
+    b, cb = device.read_output(), device.counters()
+    what = "%s tris=%d %dx%d frames=%d %s schedule=%s traversal=%d" % (kind, tris, w, h, frames, keys, schedule, cfg.traversal)
+    assert np.array_equal(a, b, equal_nan=True) and ca == cb, what
+    assert ca["paths"] == w * h * frames * keys["render.samples"], what
+    assert np.isfinite(a[..., :3]).all(), what            # the firewall: a frame that is not finite contributes black
