@@ -7,7 +7,7 @@ import numpy as np
 import pbr_loader
 pbr = pbr_loader.load()
 SCENES = {"cornell": ("cornell", 1, 0, 8), "sponza": ("sponza", 2, 260000, 3), "dragon": ("dragon", 1, 870000, 3), "hairball": ("hairball", 3, 2000000, 3)}
-W, H, FRAMES = 1920, 1080, 16
+W, H, FRAMES = 1920, 1080, 32
 for name in (sys.argv[1:] or ["sponza", "dragon", "hairball"]):
     kind, seed, tris, depth = SCENES[name]
     pbr.cfg_reset(); pbr.cfg_set(**{"render.max_depth": depth})
@@ -16,14 +16,18 @@ for name in (sys.argv[1:] or ["sponza", "dragon", "hairball"]):
     dev = pbr.Device(0)
     t0 = time.perf_counter(); nodes, fv, fn = dev.build_bvh(arr["vertices"], arr["facesV"], arr["facesN"]); wall = time.perf_counter() - t0
     build_ms = dev.last_kernel_ms()
-    cfg, cam, px = sc.config(W, H), sc.camera(), pbr.pixel_dimension(W, H)
+    cam, px = sc.camera(), pbr.pixel_dimension(W, H)
     rates = {}
-    for label, desc in (("host SAH replica", sc.desc), ("device build", None)):
-        if desc is None:
-            desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
-            desc.bvh, desc.num_nodes, desc.facesV, desc.facesN = nodes.ctypes.data, nodes.shape[0], fv.ctypes.data, fn.ctypes.data
+    device_desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
+    device_desc.bvh, device_desc.num_nodes, device_desc.facesV, device_desc.facesN = nodes.ctypes.data, nodes.shape[0], fv.ctypes.data, fn.ctypes.data
+    # round 5: both trees also in the ray-ordered walk (pbr_config.traversal = eight orders) — a tree whose stored child order is
+    # arbitrary (the clustering builder's) loses nothing to a walk that orders the children by the ray
+    for label, desc, traversal in (("host SAH replica", sc.desc, 0), ("device build", device_desc, 0),
+                                   ("host SAH replica, eight orders", sc.desc, 2), ("device build, eight orders", device_desc, 2)):
+        cfg = sc.config(W, H)
+        cfg.traversal = traversal
         dev.upload_scene(desc); dev.configure(cfg)
-        dev.render(0, pbr.frame_seeds(0, 112), px, cam)
+        dev.render(0, pbr.frame_seeds(0, 2 * dev.tune_budget()), px, cam)     # the tuner's whole budget (a close call included), then some
         dev.reset_accum(); c0 = dev.counters()
         dev.render(0, pbr.frame_seeds(0, FRAMES), px, cam)
         c1 = dev.counters(); ms = dev.last_kernel_ms()
@@ -31,5 +35,5 @@ for name in (sys.argv[1:] or ["sponza", "dragon", "hairball"]):
     print("%-9s %8d faces: host build (scene generation + SAH replica) %.1f s; device build %.2f ms on the device, %.0f ms with transfers, %d nodes" % (
         name, arr["facesV"].shape[0], host_s, build_ms, wall * 1e3, nodes.shape[0]))
     for label, (rate, visits, plan) in rates.items():
-        print("    %-18s %8.1f Msamples/s  %6.1f node visits/sample  (%s)" % (label, rate, visits, plan))
+        print("    %-32s %8.1f Msamples/s  %6.1f node visits/sample  (%s)" % (label, rate, visits, plan))
     dev.close()
