@@ -538,14 +538,17 @@ def check_flat_tree(nodes, facesV_out, facesV_in, vertices):
         assert np.array_equal(nodes[i, 0:3], nodes[sub, 0:3].min(0)) and np.array_equal(nodes[i, 4:7], nodes[sub, 4:7].max(0))
 
 
+@pytest.mark.parametrize("traversal", [0, 2])
 @pytest.mark.parametrize("builder", ["ploc", "lbvh"])
 @pytest.mark.parametrize("kind,triangles", [("cornell", 0), ("sponza", 6000), ("hairball", 30001)])
-def test_device_bvh_build_emits_the_reference_format(pbr, oracle, device, kind, triangles, builder):
+def test_device_bvh_build_emits_the_reference_format(pbr, oracle, device, kind, triangles, builder, traversal):
     """pbr_build_bvh: the tree built on the device (locally-ordered clustering, or round 1's radix tree with
     knob bvh_builder = 1) is a valid tree in the reference's flat format (structure, exact boxes, every face once);
-    HIP and oracle agree bit for bit when both walk it; and the hits are the geometric closest hits (brute force)."""
+    HIP and oracle agree bit for bit when both walk it — in the reference's order and in eight ray-ordered ones (round 5:
+    the ordered walk is what makes such a tree, whose stored child order is arbitrary, as good as the host's in the reference's
+    walk) —; and the hits are the geometric closest hits (brute force)."""
     device.set_knob("bvh_builder", {"ploc": 0, "lbvh": 1}[builder])
-    sc = make_scene(pbr, kind, 5, triangles, **{"render.max_depth": 3})
+    sc = make_scene(pbr, kind, 5, triangles, **{"render.max_depth": 3, "hip.traversal": traversal})
     arr = sc.arrays()
     nodes, fv, fn = device.build_bvh(arr["vertices"], arr["facesV"], arr["facesN"])
     check_flat_tree(nodes, fv, arr["facesV"], arr["vertices"])
