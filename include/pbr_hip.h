@@ -213,6 +213,8 @@ int pbr_denoise( pbr_ctx* ctx, float pxDim, const pbr_camera* cam, const pbr_den
  * (accelstructures/BVH.cpp, replicated on the host in host/bvh_builder.cpp): same format, different tree, so images agree
  * statistically, not bit for bit.  All pointers are host memory; nodes_out needs pbr_bvh_node_capacity( num_faces )
  * entries (2 * num_faces - 1: the count actually used comes back in *num_nodes_out).  Vertices must be finite.
+ * The clustering's search radius follows the traversal the context is configured with at the time of the call (32 for the
+ * reference's walk, 3 for a ray-ordered one, which such a tree is best walked in: DESIGN.md section 5.4).
  * pbr_last_kernel_ms then reports the device time of the build. */
 uint32_t pbr_bvh_node_capacity( uint32_t num_faces );
 int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertices, const pbr_uint4* facesV, const pbr_uint4* facesN,

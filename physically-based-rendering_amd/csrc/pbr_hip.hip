@@ -2080,7 +2080,13 @@ int buildClustered( pbr_ctx* ctx, const ptb::BuildArrays& A, uint32_t num_faces,
 	B.facesVOut = A.facesVOut;
 	B.facesNOut = A.facesNOut;
 
-	int radius = 32;   // 4 .. 64 measured: within 3 % of each other on the Sponza- / Dragon-class scenes, 32 the best on the hairball
+	// The search radius.  For the reference's walk: 32 (round 2: 4 .. 64 within 3 % of each other on the Sponza- / Dragon-class
+	// scenes, 32 the best on the hairball — where the numbers are noisy, because the stackless walk's fixed child order decides more
+	// than the tree's area).  For a ray-ordered walk (round 5: the context is configured with pbr_config.traversal != 0) the child
+	// order is out of the picture and the radius moves visits and speed monotonically — SMALLER is better: 3 gives 2183 / 2331 /
+	// 1800 Msamples/s on the Sponza- / Dragon-class scenes and the hairball against 2112 / 2246 / 1414 at 32
+	// (profiles/r05/experiments/ploc_radius_ordered_walk.txt).
+	int radius = ( ctx->configured && ctx->cfg.traversal != 0 ) ? 3 : 32;
 
 	if( ctx->knobs.plocRadius >= 1 ) {
 		radius = ctx->knobs.plocRadius;

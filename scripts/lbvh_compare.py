@@ -14,26 +14,31 @@ for name in (sys.argv[1:] or ["sponza", "dragon", "hairball"]):
     t0 = time.perf_counter(); sc = pbr.HostScene.generate(kind, seed, tris); host_s = time.perf_counter() - t0
     arr = sc.arrays()
     dev = pbr.Device(0)
-    t0 = time.perf_counter(); nodes, fv, fn = dev.build_bvh(arr["vertices"], arr["facesV"], arr["facesN"]); wall = time.perf_counter() - t0
-    build_ms = dev.last_kernel_ms()
     cam, px = sc.camera(), pbr.pixel_dimension(W, H)
-    rates = {}
-    device_desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
-    device_desc.bvh, device_desc.num_nodes, device_desc.facesV, device_desc.facesN = nodes.ctypes.data, nodes.shape[0], fv.ctypes.data, fn.ctypes.data
+    rates, builds = {}, {}
     # round 5: both trees also in the ray-ordered walk (pbr_config.traversal = eight orders) — a tree whose stored child order is
-    # arbitrary (the clustering builder's) loses nothing to a walk that orders the children by the ray
-    for label, desc, traversal in (("host SAH replica", sc.desc, 0), ("device build", device_desc, 0),
-                                   ("host SAH replica, eight orders", sc.desc, 2), ("device build, eight orders", device_desc, 2)):
+    # arbitrary (the clustering builder's) loses nothing to a walk that orders the children by the ray; pbr_build_bvh takes its
+    # search radius from the traversal the context is configured with (32 / 3), so the device tree is built once per mode
+    for traversal in (0, 2):
         cfg = sc.config(W, H)
         cfg.traversal = traversal
-        dev.upload_scene(desc); dev.configure(cfg)
-        dev.render(0, pbr.frame_seeds(0, 2 * dev.tune_budget()), px, cam)     # the tuner's whole budget (a close call included), then some
-        dev.reset_accum(); c0 = dev.counters()
-        dev.render(0, pbr.frame_seeds(0, FRAMES), px, cam)
-        c1 = dev.counters(); ms = dev.last_kernel_ms()
-        rates[label] = (W * H * FRAMES / ms / 1e3, (c1["nodes"] - c0["nodes"]) / (W * H * FRAMES), dev.last_plan()[0])
+        dev.configure(cfg)
+        t0 = time.perf_counter(); nodes, fv, fn = dev.build_bvh(arr["vertices"], arr["facesV"], arr["facesN"]); wall = time.perf_counter() - t0
+        builds[traversal] = (dev.last_kernel_ms(), wall, nodes.shape[0])
+        device_desc = pbr.SceneDesc.from_buffer_copy(sc.desc)
+        device_desc.bvh, device_desc.num_nodes, device_desc.facesV, device_desc.facesN = nodes.ctypes.data, nodes.shape[0], fv.ctypes.data, fn.ctypes.data
+        for label, desc in (("host SAH replica", sc.desc), ("device build", device_desc)):
+            label += ", eight orders" if traversal else ""
+            dev.upload_scene(desc); dev.configure(cfg)
+            dev.render(0, pbr.frame_seeds(0, 2 * dev.tune_budget()), px, cam)     # the tuner's whole budget (a close call included), then some
+            dev.reset_accum(); c0 = dev.counters()
+            dev.render(0, pbr.frame_seeds(0, FRAMES), px, cam)
+            c1 = dev.counters(); ms = dev.last_kernel_ms()
+            rates[label] = (W * H * FRAMES / ms / 1e3, (c1["nodes"] - c0["nodes"]) / (W * H * FRAMES), dev.last_plan()[0])
+    build_ms, wall, n_nodes = builds[0]
     print("%-9s %8d faces: host build (scene generation + SAH replica) %.1f s; device build %.2f ms on the device, %.0f ms with transfers, %d nodes" % (
-        name, arr["facesV"].shape[0], host_s, build_ms, wall * 1e3, nodes.shape[0]))
+        name, arr["facesV"].shape[0], host_s, build_ms, wall * 1e3, n_nodes))
+    print("    (built for the ordered walk, radius 3: %.2f ms, %d nodes)" % (builds[2][0], builds[2][2]))
     for label, (rate, visits, plan) in rates.items():
         print("    %-32s %8.1f Msamples/s  %6.1f node visits/sample  (%s)" % (label, rate, visits, plan))
     dev.close()
