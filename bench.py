@@ -368,6 +368,69 @@ def wait_ranks(procs, poll_s=0.05, limit_s=None, previous=None):
     return code
 
 
+MODE_LEGS = (
+    # (key in the line, traversal, arith, what the mode's parity claim is)
+    ("eight-order", 2, 0, "tolerance"),            # same closest hits as the reference order except between faces at equal distance
+    ("eight-order+native", 2, 1, "statistical"),   # native sin / cos / rcp / sqrt / log / exp: another sample of the same estimator
+)
+
+
+def mode_leg(pbr, scene, base_cfg, cam, px, args, device, depth, traversal, arith, parity, min_repeats=5):
+    """One opt-in mode of the library on the headline's workload, same --steps: its own context, its own schedule tuning
+    (untimed set-up, as for the headline), W warm-up frames, then the K-step render repeated at least `min_repeats` times —
+    the median counts.  N = 1 only.  `roofline` is priced only from the mode's OWN committed PMC record (recorded_traffic
+    matches traversal and arith; roofline_block refuses another build's or schedule's counters)."""
+    cfg = type(base_cfg).from_buffer_copy(base_cfg)
+    cfg.traversal, cfg.arith = traversal, arith
+    w, h = int(cfg.width), int(cfg.height)
+    dev = pbr.Device(device)
+    try:
+        dev.upload_scene(scene.desc)
+        dev.configure(cfg)
+        t_setup, setup_frames = time.perf_counter(), 0
+        if args.plan >= 0:
+            dev.pin_plan(args.plan)
+        else:
+            budget = dev.tune_budget()
+            while setup_frames < budget or dev.last_plan()[1] < 0:
+                n = max(1, min(args.steps, 4 * budget - setup_frames))
+                dev.render(setup_frames, pbr.frame_seeds(setup_frames, n), px, cam)
+                setup_frames += n
+                if setup_frames >= 4 * budget:
+                    break
+        t_setup = time.perf_counter() - t_setup
+        dev.reset_accum()
+        if args.warmup > 0:
+            dev.render(0, pbr.frame_seeds(0, args.warmup), px, cam)
+        before, runs, first = dev.counters(), [], args.warmup
+        while len(runs) < min_repeats or (sum(r[0] for r in runs) < 0.25 and len(runs) < 15):
+            t0 = time.perf_counter()
+            dev.render(first, pbr.frame_seeds(first, args.steps), px, cam)
+            elapsed = time.perf_counter() - t0
+            trace_ms, launches = dev.last_trace()
+            runs.append((elapsed, trace_ms / launches / 1e3, launches))
+            first += args.steps
+        counters = {k: v / len(runs) for k, v in diff(dev.counters(), before).items()}
+        elapsed, kernel_s, launches = sorted(runs)[len(runs) // 2]
+        samples = w * h * args.steps * int(cfg.samples)
+        assert counters["paths"] == samples, (counters, samples)
+        algo = algorithmic_bytes(counters, w * h * args.steps)
+        plan = dev.last_plan()[0]
+        traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), traversal, arith)
+        return {
+            "value": samples / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed * 1e3 / args.steps,
+            "repeats": len(runs), "ms_per_step_all": [round(r[0] * 1e3 / args.steps, 5) for r in runs],
+            "parity": parity, "traversal": ("reference", "six-order", "eight-order")[traversal], "arith": ("exact", "native")[arith],
+            "schedule": plan, "deal": dev.last_deal()[0], "setup_frames": setup_frames, "setup_s": round(t_setup, 3),
+            "per_sample": {"node_visits": counters["nodes"] / samples, "triangle_tests": counters["tris"] / samples,
+                           "shaded_hits": counters["hits"] / samples, "algorithmic_bytes": algo / samples},
+            "scene_device_bytes": dev.scene_bytes(),
+            "roofline": roofline_block(args.scene, plan, traffic, algo / launches, samples / launches, kernel_s, stamp=library_stamp(), kernel=dev.last_kernel()),
+        }
+    finally:
+        dev.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -392,6 +455,8 @@ def main():
                     help="pbr_config.arith: every builtin one exact definition (default, the headline), or gfx950's native sin / cos / rcp / sqrt / log / exp")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: run the multi-GPU leg all the same — init_process_group(backend, world_size=1), the all-gather on pbr_export_tiles / pbr_import_tiles device pointers — and check the gathered frame")
+    ap.add_argument("--modes", default="auto", choices=["auto", "off"],
+                    help="auto: a one-GPU run of the default mode also times the opt-in modes (eight-order, eight-order + native) on the same workload and steps and reports them under \"modes\"; `value` stays the default mode")
     ap.add_argument("--dump", default="", help="rank 0 writes the gathered / rendered frame to this .npy")
     ap.add_argument("--rank-limit", type=float, default=1500.0, help="self-launched ranks (--gpus N without a launcher): wall-clock seconds after which the parent ends them and fails")
     ap.add_argument("--hold-seconds", type=float, default=3.0, help="N = 1: keep the GPU rendering (untimed) this long after the timed region, so that an outside utilisation sampler sees the GPU leg at all")
@@ -534,7 +599,9 @@ def main():
         kernel_ms = dev.last_kernel_ms()            # the whole render: path tracing + foldFrames
         trace_ms, trace_launches = dev.last_trace()  # the path-tracing launches alone
         gather()
-        sync()
+        # the closing side: the all-gather IS the barrier (no rank has its frame before every rank has contributed its tiles)
+        # and gather() ends in a device synchronize; a second dist.barrier() here only added its own latency to a
+        # region of a few milliseconds.  The maximum over the ranks is taken below (all_reduce MAX of the per-run times).
         elapsed = time.perf_counter() - t0
         runs.append({"elapsed": elapsed, "render": t_render, "kernel_ms": kernel_ms, "trace_ms": trace_ms, "launches": trace_launches})
         first += args.steps
@@ -559,6 +626,15 @@ def main():
     counters = diff(dev.counters(), before)
     if rank == 0 and args.dump:
         np.save(args.dump, dev.read_full() if multi else dev.read_output())
+    # the opt-in modes on the same workload and steps (N = 1, default-mode runs only): extra keys, `value` is untouched
+    modes = None
+    if world == 1 and not multi and args.modes == "auto" and (args.traversal, args.arith) == ("reference", "exact"):
+        modes = {}
+        for key, traversal, arith, parity in MODE_LEGS:
+            if pbr.hip.pbr_mode_built(traversal, arith) != 1:
+                modes[key] = {"value": None, "note": "this library was built without that mode"}
+                continue
+            modes[key] = mode_leg(pbr, scene, cfg, cam, px, args, local_rank, depth, traversal, arith, parity)
     # untimed: keep rendering for --hold-seconds, so that a sampler with a period of a second or two sees the GPU leg at all
     # (the timed region of the driver's command is 0.3 s)
     held_frames = 0
@@ -628,6 +704,7 @@ def main():
             "repeats": repeats, "ms_per_step_all": [round(r[0] * 1e3 / args.steps, 5) for r in per_run],
             "setup_frames": setup_frames, "setup_s": round(t_setup, 3),
             "kernel_ms": kernel_ms, "schedule": plan, "schedule_tuned": tuned >= 0, "trace_launches": trace_launches,
+            "deal": dev.last_deal()[0],      # the order the queue dealt its tiles in: "spatial", or "cost-classes" (short launches)
             "per_sample": {
                 "node_visits": counters["nodes"] / samples, "triangle_tests": counters["tris"] / samples,
                 "shaded_hits": counters["hits"] / samples, "algorithmic_bytes": algo / samples,
@@ -643,10 +720,11 @@ def main():
             # + the drain of its longest paths, independent of N) next to 1 / N of the work W, so N ranks reach
             # ( W + D ) / ( W + N D ) of N x one GPU.  W from the slowest rank's measured render R: W = N ( R - D ).
             if fit is not None and world > 1:
-                R, D = max(rank_ms["render"]), fit[0]
+                # D is paid once per LAUNCH, and a render that is chunked (frame buffer cap, tuner) has trace_launches of them
+                R, D = max(rank_ms["render"]), fit[0] * trace_launches
                 W = world * max(R - D, 0.0)
                 out["expected_linear_frac"] = round((W + D) / (W + world * D), 4) if W + world * D > 0 else None
-                out["expected_linear_frac_note"] = "( W + D ) / ( W + N D ): D = rank 0's fitted fixed cost per launch, W = N ( slowest rank's render - D ); the all-gather is not in it"
+                out["expected_linear_frac_note"] = "( W + D ) / ( W + N D ): D = rank 0's fitted fixed cost per launch x the render's %d launch(es), W = N ( slowest rank's render - D ); the all-gather is not in it" % trace_launches
         if gathered_ok is not None:
             out["force_dist"] = {"backend": args.backend, "world_size": world, "gathered_frame_equals_rendered": gathered_ok,
                                  "gather_ms": round(per_run[median][3] * 1e3, 3)}
@@ -654,6 +732,8 @@ def main():
             out["plan_votes"] = plan_votes
         if baseline is not None:
             out["cpu_baseline"] = baseline
+        if modes is not None:
+            out["modes"] = modes
         out["held_frames_untimed"] = held_frames
         sys.stdout.flush()
         os.write(line_fd, (json.dumps(out) + "\n").encode())

@@ -72,6 +72,7 @@ int pbr_diag_launch_fit( pbr_ctx* ctx, double* fixed_ms, double* per_frame_ms );
  *   "face_normals"  0 = recompute the face normal on every hit (takes effect at the next pbr_upload_scene)
  *   "bvh_builder"   pbr_build_bvh: 0 clustering (default), 1 round 1's radix tree; "ploc_radius": its search radius
  *   "tune_log"      1 = the schedule tuner logs its launches to stderr
+ *   "deal_order"    the queue's dealing order: 0 always spatial, 1 always cost-ordered (once learnt), -1 by the launch's size
  * Setting a knob rebuilds the plans and restarts the schedule tuner. */
 int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value );
 
@@ -81,6 +82,24 @@ int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value );
  * none is a straggler of the closing all-gather because its own timing noise picked a slower plan.  Survives
  * pbr_upload_scene / pbr_configure. */
 int pbr_diag_pin_plan( pbr_ctx* ctx, int plan );
+
+/* The dealing order of the work queue (csrc/pt_kernel.hpp, nextSlot).  The local tiles form a grid that is cut into 8 bands
+ * of rows with one queue head each; band b's tiles are dealt in the order the stretch [band_first[b], band_first[b + 1]) of
+ * the table names them (local tile indices; the table has one entry per local tile).
+ * Placement is for speed only: every (pixel, frame) unit is handed out exactly once in any order, images and counters
+ * do not depend on it (tested).  get: which = 0 the spatial (or pinned) table, 1 the library's cost-ordered table (PBR_ESTATE
+ * until one has been learnt); *count = entries, order[] filled when non-null.  set: `order` must hold, per band, a
+ * permutation of that band's own tiles (else PBR_EINVAL) and then stays in force until pbr_configure (the library's
+ * own cost-ordered dealing is off meanwhile); NULL = back to the library's choice. */
+int pbr_diag_get_tile_order( pbr_ctx* ctx, int which, uint32_t* order, uint32_t capacity, uint32_t* count, uint32_t band_first[9] );
+int pbr_diag_set_tile_order( pbr_ctx* ctx, const uint32_t* order, uint32_t count );
+
+/* The order the (largest launch of the) last render was dealt in: "spatial" — inside a band column by column —, "cost-classes"
+ * — per band eight classes of falling cost, spatial inside a class; the library's choice for launches of up to 128 Ki
+ * tiles x frames once it has learnt the tiles' costs from a debug image (csrc/pbr_hip.hip, learnTileCosts) — or "pinned"
+ * (pbr_diag_set_tile_order).  *learnt = whether a cost order exists.  Knob "deal_order": 0 always spatial, 1 always
+ * cost-ordered once learnt, -1 by size. */
+int pbr_diag_last_deal( pbr_ctx* ctx, char* name, size_t capacity, int* learnt );
 
 /* How many frames of the configured size the schedule tuner wants to see before it settles (its launch lengths are
  * fixed in 1080p-frame equivalents, so a rank of an N-GPU run needs N times as many): a benchmark renders that many

@@ -134,12 +134,19 @@ hip.pbr_diag_guard_trips.argtypes = [_vp, _up]
 hip.pbr_diag_last_trace.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
 hip.pbr_diag_last_plan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
 hip.pbr_diag_pin_plan.argtypes = [_vp, ctypes.c_int]
-hip.pbr_diag_scene_bytes.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64)]
-hip.pbr_mode_built.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
-hip.pbr_diag_last_kernel.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
-hip.pbr_diag_launch_fit.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-if hasattr(hip, "pbr_diag_set_knob"):       # absent from round 2's library (A/B runs against it: PBR_HIP_LIB)
-    hip.pbr_diag_set_knob.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int]
+# entry points that older builds of the library lack are bound only when they are there: lab runs load other builds of the
+# library for A/B comparisons (PBR_HIP_LIB), and a missing symbol must fail where it is called, not at import
+for _name, _args in (
+        ("pbr_diag_scene_bytes", [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+        ("pbr_mode_built", [ctypes.c_uint32, ctypes.c_uint32]),
+        ("pbr_diag_last_kernel", [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+        ("pbr_diag_launch_fit", [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+        ("pbr_diag_set_knob", [_vp, ctypes.c_char_p, ctypes.c_int]),                 # absent from round 2's library
+        ("pbr_diag_get_tile_order", [_vp, ctypes.c_int, _up, ctypes.c_uint32, _up, _up]),          # round 6
+        ("pbr_diag_set_tile_order", [_vp, _up, ctypes.c_uint32]),
+        ("pbr_diag_last_deal", [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)])):
+    if hasattr(hip, _name):
+        getattr(hip, _name).argtypes = _args
 hip.pbr_diag_tune_budget.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint32)]
 
 host.pbrh_last_error.restype = ctypes.c_char_p
@@ -310,6 +317,7 @@ _ENV_KNOBS = {
     "PBR_LDS_SLOTS": "lds_slots", "PBR_BLOCKS_PER_CU": "blocks_per_cu", "PBR_PH_PARK": "ph_park", "PBR_PH_SHADE": "ph_shade",
     "PBR_PARK_EIGHTHS": "park_eighths", "PBR_DRAIN_MODE": "drain_mode", "PBR_REFILL_BATCH": "refill_batch",
     "PBR_CHUNK_FRAMES": "chunk_frames", "PBR_FACE_NORMALS": "face_normals", "PBR_PLOC_RADIUS": "ploc_radius", "PBR_TUNE_LOG": "tune_log",
+    "PBR_DEAL_ORDER": "deal_order",
 }
 
 
@@ -523,6 +531,31 @@ class Device:
     def pin_plan(self, plan):
         """Render with schedule `plan` (index into PLAN_NAMES) without tuning; -1 = let the tuner choose."""
         self._check(hip.pbr_diag_pin_plan(self._ctx, int(plan)))
+
+    def tile_order(self, cost_ordered=False):
+        """pbr_diag_get_tile_order: (order, band_first) — the local tiles in the order the queue deals them, band b's
+        stretch = order[band_first[b]:band_first[b + 1]]; cost_ordered: the library's learnt cost order instead of the spatial
+        (or pinned) one."""
+        n, first, which = ctypes.c_uint32(), (ctypes.c_uint32 * 9)(), 1 if cost_ordered else 0
+        self._check(hip.pbr_diag_get_tile_order(self._ctx, which, None, 0, ctypes.byref(n), first))
+        order = np.empty(n.value, np.uint32)
+        self._check(hip.pbr_diag_get_tile_order(self._ctx, which, order.ctypes.data_as(_up), n.value, ctypes.byref(n), first))
+        return order, np.array(first[:], np.int64)
+
+    def set_tile_order(self, order):
+        """pbr_diag_set_tile_order: deal the tiles in this order (per band a permutation of the band's own tiles) until the next
+        pbr_configure; None hands the order back to the library."""
+        if order is None:
+            self._check(hip.pbr_diag_set_tile_order(self._ctx, None, 0))
+        else:
+            order = np.ascontiguousarray(order, np.uint32)
+            self._check(hip.pbr_diag_set_tile_order(self._ctx, order.ctypes.data_as(_up), order.size))
+
+    def last_deal(self):
+        """pbr_diag_last_deal: (the order the last render's largest launch was dealt in, whether a cost order has been learnt)."""
+        name, learnt = ctypes.create_string_buffer(16), ctypes.c_int(0)
+        self._check(hip.pbr_diag_last_deal(self._ctx, name, 16, ctypes.byref(learnt)))
+        return name.value.decode(), bool(learnt.value)
 
     def tune_budget(self):
         """Frames of the configured size after which the schedule tuner has settled."""

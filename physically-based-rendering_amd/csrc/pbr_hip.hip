@@ -50,6 +50,7 @@ struct Knobs {
 	int bvhBuilder = -1;    // pbr_build_bvh: 1 = round 1's radix tree instead of the clustering builder
 	int plocRadius = -1;    // pbr_build_bvh: search radius of the clustering builder
 	int tuneLog = -1;       // 1 = the schedule tuner logs its launches to stderr
+	int dealOrder = -1;     // the queue's dealing order: 0 always spatial, 1 always cost-ordered (once learnt), -1 by the launch's size
 };
 
 struct pbr_ctx {
@@ -92,6 +93,24 @@ struct pbr_ctx {
 	float4* dImgDbg = nullptr;
 	float4* dRows = nullptr;       // W x H row-major staging for read-back / write_input
 	float4* dFull = nullptr;       // all tiles of the frame, filled by pbr_import_tiles
+	// the banded queue's dealing order (pt_kernel.hpp, nextSlot): the local tiles as a queueRows x queueWidth grid cut into
+	// PT_BANDS bands of rows; hTileOrder / dTileOrder name, per band, its tiles in the order they are dealt
+	int queueWidth = 1, queueRows = 1;
+	unsigned bandFirst[PT_BANDS + 1] = {};
+	std::vector<unsigned> hTileOrder;
+	unsigned* dTileOrder = nullptr;
+	bool orderPinned = false;      // pbr_diag_set_tile_order: the caller's order stays (tests, A/B runs)
+	// cost-ordered dealing for SHORT launches (round 6, learnTileCosts): per band the tiles in kCostClasses classes of
+	// falling cost, spatial order inside a class; learnt from the debug image (node visits per pixel of a launch's last frame)
+	std::vector<unsigned> hCostOrder;
+	unsigned* dCostOrder = nullptr;
+	float* dTileCost = nullptr;    // node visits per local tile
+	std::vector<float> hTileCost;
+	bool costLearnt = false;       // dCostOrder holds an order learnt for costCam
+	pbr_camera costCam = {};       // the camera (and pixel size) the costs were measured with
+	float costPxDim = 0.0f;
+	uint32_t launchesSinceLearn = 0;
+	char lastDeal[16] = "spatial"; // the order the largest chunk of the last render was dealt in
 	bool focusGiven = false;       // pbr_set_focus_depth: the focus pixel's previous-frame distance for the next frame
 	float focusDepth = 0.0f;
 	float4* dFrameBuf = nullptr;   // frame-parallel launches: {finalColor, focus} per frame and local pixel slot
@@ -191,6 +210,15 @@ void freeImages( pbr_ctx* ctx ) {
 	(void) hipFree( ctx->dFrameBuf );
 	ctx->dFrameBuf = nullptr;
 	ctx->frameBufFrames = 0;
+	(void) hipFree( ctx->dTileOrder );
+	(void) hipFree( ctx->dCostOrder );
+	(void) hipFree( ctx->dTileCost );
+	ctx->dTileOrder = ctx->dCostOrder = nullptr;
+	ctx->dTileCost = nullptr;
+	ctx->hTileOrder.clear();
+	ctx->hCostOrder.clear();
+	ctx->costLearnt = false;
+	ctx->orderPinned = false;
 	ctx->dImgIn = ctx->dImgOut = ctx->dImgDbg = ctx->dRows = ctx->dFull = nullptr;
 	ctx->configured = false;
 }
@@ -513,6 +541,145 @@ int applyWalk( pbr_ctx* ctx, DevParams* P, uint32_t* hotAvail ) {
 	return PBR_OK;
 }
 
+// ---- the dealing order of the banded queue (pt_kernel.hpp, nextSlot) -------------------------------------------------
+// The local tiles form a queueRows x queueWidth grid (row-major local tile index; its true shape when unsharded, about that
+// when sharded).  Band b holds the rows [ b * queueRows / PT_BANDS, ( b + 1 ) * queueRows / PT_BANDS ); its stretch of the order
+// table is [ bandFirst[b], bandFirst[b + 1] ) and names exactly the band's tiles (the ragged end of the grid is left out).
+//
+// The spatial order (rounds 1 - 5's only one): inside a band column by column, so that the tiles the waves of one XCD hold
+// at a time form a compact block of the image, not a strip as wide as the frame.
+void spatialTileOrder( pbr_ctx* ctx, std::vector<unsigned>* order ) {
+	order->clear();
+	order->reserve( (size_t) ctx->numLocalTiles );
+
+	for( int band = 0; band < PT_BANDS; band++ ) {
+		const unsigned row0 = ( (unsigned) band * (unsigned) ctx->queueRows ) / PT_BANDS;
+		const unsigned rows = ( (unsigned) ( band + 1 ) * (unsigned) ctx->queueRows ) / PT_BANDS - row0;
+		ctx->bandFirst[band] = (unsigned) order->size();
+
+		for( unsigned col = 0; col < (unsigned) ctx->queueWidth; col++ ) {
+			for( unsigned row = 0; row < rows; row++ ) {
+				const unsigned tile = ( row0 + row ) * (unsigned) ctx->queueWidth + col;
+
+				if( tile < (unsigned) ctx->numLocalTiles ) {
+					order->push_back( tile );
+				}
+			}
+		}
+	}
+
+	ctx->bandFirst[PT_BANDS] = (unsigned) order->size();
+}
+
+int uploadTileOrder( pbr_ctx* ctx ) {
+	HIP_TRY( ctx, hipMemcpyAsync( ctx->dTileOrder, ctx->hTileOrder.data(), sizeof( unsigned ) * ctx->hTileOrder.size(), hipMemcpyHostToDevice, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );   // the source is pageable: do not let it change under the copy
+	return PBR_OK;
+}
+
+// Cost-ordered dealing.  A launch ends at the pace of its longest paths ("How a launch ends"): when the queue runs
+// dry every lane holds a path, and the machine empties while the longest of them finish — 0.5 ms on a Sponza-class scene,
+// whatever the launch's length.  Dealt expensive tiles first, the paths that start last are short ones.  Measured (round 6,
+// profiles/r06/experiments/deal_order*.txt; round 4 had measured the unsharded half of it, profiles/r04/experiments/
+// heaviest_tiles_first.txt): rank 0's share of a 20-frame render split 8 ways -3.5 ... -8 % (Sponza-class 3.14 -> 3.00 ms,
+// Dragon-class 3.85 -> 3.72, hairball 6.97 -> 6.72, Cornell 1.50 -> 1.42), its single frame -2 ... -10 %; but a long launch
+// LOSES 1 - 8 % because the tiles an XCD holds at one time are no longer neighbours (Sponza-class 64 frames 60.5 -> 61.1 ms,
+// hairball 127.9 -> 131.5) and a single full frame neither gains nor loses.  So the order is chosen per launch by its size:
+// cost classes up to kCostOrderTileFrames tiles x frames, the spatial order above.  Eight classes by the band's own cost
+// octiles — the finer the classes the less locality is left, a full sort is the worst on long launches and no better on short.
+const unsigned kCostClasses = 8;
+const size_t kCostOrderTileFrames = 128 * 1024;
+
+// per band: the spatial order, stably partitioned into kCostClasses classes of falling cost (class edges = the band's octiles)
+void costTileOrder( pbr_ctx* ctx, const std::vector<unsigned>& spatial, const std::vector<float>& cost, std::vector<unsigned>* order ) {
+	order->assign( spatial.size(), 0u );
+	std::vector<float> sorted;
+	std::vector<unsigned> fill( kCostClasses );
+
+	for( int band = 0; band < PT_BANDS; band++ ) {
+		const unsigned first = ctx->bandFirst[band], n = ctx->bandFirst[band + 1] - first;
+
+		if( n == 0 ) {
+			continue;
+		}
+
+		sorted.resize( n );
+
+		for( unsigned k = 0; k < n; k++ ) {
+			sorted[k] = cost[spatial[first + k]];
+		}
+
+		std::sort( sorted.begin(), sorted.end() );
+		float edge[kCostClasses - 1];
+
+		for( unsigned c = 0; c + 1 < kCostClasses; c++ ) {
+			edge[c] = sorted[std::min<size_t>( n - 1, ( (size_t) ( c + 1 ) * n ) / kCostClasses )];
+		}
+
+		// class 0 = the most expensive: a tile's class counts the edges its cost stays below
+		auto classOf = [&]( float v ) {
+			unsigned below = 0;
+
+			for( unsigned c = 0; c + 1 < kCostClasses; c++ ) {
+				below += ( v < edge[c] ) ? 1u : 0u;
+			}
+
+			return below;
+		};
+
+		std::fill( fill.begin(), fill.end(), 0u );
+
+		for( unsigned k = 0; k < n; k++ ) {
+			fill[classOf( cost[spatial[first + k]] )]++;
+		}
+
+		unsigned at = 0;
+
+		for( unsigned c = 0; c < kCostClasses; c++ ) {
+			const unsigned size = fill[c];
+			fill[c] = at;
+			at += size;
+		}
+
+		for( unsigned k = 0; k < n; k++ ) {
+			const unsigned tile = spatial[first + k];
+			( *order )[first + fill[classOf( cost[tile] )]++] = tile;
+		}
+	}
+}
+
+// After a launch: node visits per local tile from the debug image (the launch's last frame), then the cost order.  Runs when
+// there is no order yet or the camera has moved since it was learnt (then at most every 16th launch: an order learnt a few
+// frames ago is nearly as good, and the read-back is a synchronisation a frame-by-frame caller should not pay per frame).
+int learnTileCosts( pbr_ctx* ctx, const pbr_camera* cam, float pxDim ) {
+	if( ctx->orderPinned || ctx->knobs.dealOrder == 0 || ctx->dCostOrder == nullptr ) {
+		return PBR_OK;
+	}
+
+	const bool moved = !ctx->costLearnt || std::memcmp( &ctx->costCam, cam, sizeof( pbr_camera ) ) != 0 || ctx->costPxDim != pxDim;
+
+	if( !moved || ( ctx->costLearnt && ctx->launchesSinceLearn < 16u ) ) {
+		return PBR_OK;
+	}
+
+	const unsigned tiles = (unsigned) ctx->numLocalTiles;
+	hipLaunchKernelGGL( ptk::tileCosts, dim3( ( tiles + 3u ) / 4u ), dim3( 256 ), 0, ctx->stream, (const float4*) ctx->dImgDbg, ctx->dTileCost, tiles );
+	HIP_TRY( ctx, hipGetLastError() );
+	ctx->hTileCost.resize( tiles );
+	HIP_TRY( ctx, hipMemcpyAsync( ctx->hTileCost.data(), ctx->dTileCost, sizeof( float ) * tiles, hipMemcpyDeviceToHost, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	std::vector<unsigned> spatial;
+	spatialTileOrder( ctx, &spatial );
+	costTileOrder( ctx, spatial, ctx->hTileCost, &ctx->hCostOrder );
+	HIP_TRY( ctx, hipMemcpyAsync( ctx->dCostOrder, ctx->hCostOrder.data(), sizeof( unsigned ) * ctx->hCostOrder.size(), hipMemcpyHostToDevice, ctx->stream ) );
+	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
+	ctx->costLearnt = true;
+	ctx->costCam = *cam;
+	ctx->costPxDim = pxDim;
+	ctx->launchesSinceLearn = 0;
+	return PBR_OK;
+}
+
 uint32_t tuneScaleOf( size_t localPixels ) {
 	const size_t reference = (size_t) 1920 * 1080;
 	const size_t scale = ( reference + localPixels / 2 ) / std::max<size_t>( localPixels, 1 );
@@ -633,17 +800,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	P.tilesX = ctx->tilesX;
 	invariantDivisor( (unsigned) ctx->tilesX, P.tilesXDiv );
 	P.numLocalTiles = ctx->numLocalTiles;
-	// the local tiles as a grid for the banded queue: its true shape when unsharded, about that when sharded
-	P.queueWidth = std::max( 1, ( ctx->tilesX + (int) ctx->cfg.tile_world - 1 ) / (int) ctx->cfg.tile_world );
-	P.queueRows = ( ctx->numLocalTiles + P.queueWidth - 1 ) / P.queueWidth;
+	P.tileOrder = ctx->dTileOrder;
 
-	for( int band = 0; band < PT_BANDS; band++ ) {   // nextSlot divides by a band's rows (same arithmetic as there) ...
-		const unsigned row0 = ( (unsigned) band * (unsigned) P.queueRows ) / PT_BANDS;
-		const unsigned rows = ( (unsigned) ( band + 1 ) * (unsigned) P.queueRows ) / PT_BANDS - row0;
-		invariantDivisor( rows, &P.bandDiv[band * 2] );
+	for( int band = 0; band < PT_BANDS; band++ ) {
+		P.bandFirst[band] = ctx->bandFirst[band];
+		P.bandTiles[band] = ctx->bandFirst[band + 1] - ctx->bandFirst[band];
 	}
 
-	invariantDivisor( 1u, P.framesDiv );   // ... and by the frames of the launch (set per chunk below)
+	invariantDivisor( 1u, P.framesDiv );   // nextSlot divides by the frames of the launch (set per chunk below)
 	P.tileWorld = (int) ctx->cfg.tile_world;
 	P.tileRank = (int) ctx->cfg.tile_rank;
 	P.numNodes = (int) ctx->numNodes;
@@ -867,7 +1031,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	size_t chunkCap = std::max<size_t>( 1, kFrameBufBytes / frameBytes );
 	chunkCap = std::min<size_t>( chunkCap, nFrames );
 	// the queue heads count pixel slots x frames of a band in 32 bits
-	chunkCap = std::min<size_t>( chunkCap, std::max<size_t>( 1, 0x7FFFFFFFull / ( pixelSlots + 64 * (size_t) P.queueWidth ) ) );
+	chunkCap = std::min<size_t>( chunkCap, std::max<size_t>( 1, 0x7FFFFFFFull / ( pixelSlots + 64 * (size_t) ctx->queueWidth ) ) );
 
 	if( knobs.chunkFrames >= 1 ) {    // tests: force several launch pairs
 		chunkCap = std::min<size_t>( chunkCap, (size_t) knobs.chunkFrames );
@@ -1006,6 +1170,11 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		invariantDivisor( n, P.framesDiv );
 		P.firstCount = (int) ( firstCount + done );
 		P.seeds = ctx->dSeeds + done;
+		// the dealing order, by the launch's size (costTileOrder): short launches end sooner with the expensive tiles first,
+		// long ones are faster in the spatial order
+		const bool costOrdered = !ctx->orderPinned && ctx->costLearnt && knobs.dealOrder != 0 &&
+			( knobs.dealOrder == 1 || (size_t) ctx->numLocalTiles * n <= kCostOrderTileFrames );
+		P.tileOrder = costOrdered ? ctx->dCostOrder : ctx->dTileOrder;
 
 
 		HIP_TRY( ctx, hipEventRecord( ctx->evTraceStart, ctx->stream ) );
@@ -1030,6 +1199,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 		if( n > largest ) {
 			largest = n;
+			std::snprintf( ctx->lastDeal, sizeof( ctx->lastDeal ), "%s", ctx->orderPinned ? "pinned" : ( costOrdered ? "cost-classes" : "spatial" ) );
 			std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "%s", plan.name );
 			std::snprintf( ctx->lastKernel, sizeof( ctx->lastKernel ), "%s", plan.kernelName );
 		}
@@ -1095,6 +1265,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	ctx->lastKernelMs = (double) ms;
 	ctx->lastTraceMs = traceMs;
 	ctx->lastTraceLaunches = launches;
+	ctx->launchesSinceLearn += launches;
 
 	// [1] the path loop (or a record slot of the asynchronous node phase that never filled), [2] a traversal that took more
 	// steps than the tree has nodes (PBR_GUARD builds): either way a walk was cut short and the image is wrong
@@ -1107,7 +1278,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		return fail( ctx, PBR_EDEVICE, "the staged node prefix does not start at LDS address 0 (pt_kernel.hpp, stageHotNodes): this build of the kernels cannot be trusted" );
 	}
 
-	return PBR_OK;
+	return learnTileCosts( ctx, cam, pxDim );
 }
 
 int readTiled( pbr_ctx* ctx, const float4* tiles, float* rgba, int tileWorld, int tileRank ) {
@@ -1617,6 +1788,23 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	HIP_TRY( ctx, hipMemset( ctx->dImgDbg, 0, fullBytes ) );
 	HIP_TRY( ctx, hipMemset( ctx->dCounters, 0, sizeof( unsigned long long ) * kCounterSlots ) );
 	HIP_TRY( ctx, hipDeviceSynchronize() );   // the memsets ran on the null stream; launches use ctx->stream
+
+	// the local tiles as a grid for the banded queue: its true shape when unsharded, about that when sharded
+	ctx->queueWidth = std::max( 1, ( ctx->tilesX + (int) cfg->tile_world - 1 ) / (int) cfg->tile_world );
+	ctx->queueRows = ( ctx->numLocalTiles + ctx->queueWidth - 1 ) / ctx->queueWidth;
+	spatialTileOrder( ctx, &ctx->hTileOrder );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dTileOrder, sizeof( unsigned ) * ctx->hTileOrder.size() ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dCostOrder, sizeof( unsigned ) * ctx->hTileOrder.size() ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dTileCost, sizeof( float ) * std::max<size_t>( 1, ctx->hTileOrder.size() ) ) );
+	ctx->costLearnt = false;
+	ctx->launchesSinceLearn = 0;
+	{
+		const int uploaded = uploadTileOrder( ctx );
+
+		if( uploaded != PBR_OK ) {
+			return uploaded;
+		}
+	}
 	ctx->plansBuilt = false;
 	resetTuning( ctx );   // a new scene / configuration is tuned afresh
 	ctx->configured = true;
@@ -2492,6 +2680,20 @@ int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned ) 
 	return PBR_OK;
 }
 
+int pbr_diag_last_deal( pbr_ctx* ctx, char* name, size_t capacity, int* learnt ) {
+	if( ctx == nullptr || name == nullptr || capacity == 0 ) {
+		return fail( ctx, PBR_EINVAL, "diag_last_deal: null argument" );
+	}
+
+	std::snprintf( name, capacity, "%s", ctx->lastDeal );
+
+	if( learnt != nullptr ) {
+		*learnt = ctx->costLearnt ? 1 : 0;
+	}
+
+	return PBR_OK;
+}
+
 int pbr_diag_scene_bytes( pbr_ctx* ctx, uint64_t out[3] ) {
 	if( ctx == nullptr || out == nullptr || !ctx->hasScene ) {
 		return fail( ctx, PBR_ESTATE, "diag_scene_bytes: no scene" );
@@ -2550,7 +2752,7 @@ int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value ) {
 		{ "lds_slots", &k.ldsSlots }, { "blocks_per_cu", &k.blocksPerCU }, { "ph_park", &k.phPark }, { "ph_shade", &k.phShade },
 		{ "park_eighths", &k.parkEighths }, { "drain_mode", &k.drainMode }, { "refill_batch", &k.refillBatch },
 		{ "chunk_frames", &k.chunkFrames }, { "face_normals", &k.faceNormals }, { "bvh_builder", &k.bvhBuilder },
-		{ "ploc_radius", &k.plocRadius }, { "tune_log", &k.tuneLog },
+		{ "ploc_radius", &k.plocRadius }, { "tune_log", &k.tuneLog }, { "deal_order", &k.dealOrder },
 	};
 
 	for( const auto& entry : table ) {
@@ -2565,6 +2767,83 @@ int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value ) {
 	}
 
 	return fail( ctx, PBR_EINVAL, "diag_set_knob: unknown knob '%s'", name );
+}
+
+int pbr_diag_get_tile_order( pbr_ctx* ctx, int which, uint32_t* order, uint32_t capacity, uint32_t* count, uint32_t band_first[PT_BANDS + 1] ) {
+	if( ctx == nullptr || !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "diag_get_tile_order before pbr_configure" );
+	}
+	if( which != 0 && !ctx->costLearnt ) {
+		return fail( ctx, PBR_ESTATE, "diag_get_tile_order: no cost order has been learnt yet (it is built after the first render)" );
+	}
+
+	const std::vector<unsigned>& table = ( which != 0 ) ? ctx->hCostOrder : ctx->hTileOrder;
+	const uint32_t n = (uint32_t) table.size();
+
+	if( count != nullptr ) {
+		*count = n;
+	}
+
+	if( band_first != nullptr ) {
+		for( int band = 0; band <= PT_BANDS; band++ ) {
+			band_first[band] = ctx->bandFirst[band];
+		}
+	}
+
+	if( order != nullptr ) {
+		if( capacity < n ) {
+			return fail( ctx, PBR_EINVAL, "diag_get_tile_order: %u entries do not fit a buffer of %u", n, capacity );
+		}
+
+		std::memcpy( order, table.data(), sizeof( uint32_t ) * n );
+	}
+
+	return PBR_OK;
+}
+
+int pbr_diag_set_tile_order( pbr_ctx* ctx, const uint32_t* order, uint32_t count ) {
+	if( ctx == nullptr || !ctx->configured ) {
+		return fail( ctx, PBR_ESTATE, "diag_set_tile_order before pbr_configure" );
+	}
+
+	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+	std::vector<unsigned> spatial;
+	spatialTileOrder( ctx, &spatial );
+
+	if( order == nullptr ) {
+		ctx->hTileOrder = spatial;
+		ctx->orderPinned = false;
+		return uploadTileOrder( ctx );
+	}
+
+	if( count != (uint32_t) spatial.size() ) {
+		return fail( ctx, PBR_EINVAL, "diag_set_tile_order: %u entries, the queue has %zu tiles", count, spatial.size() );
+	}
+
+	// every band's stretch must be a permutation of that band's own tiles: a unit dealt twice or never is a wrong image
+	std::vector<unsigned char> bandOf( spatial.size(), 0 );
+
+	for( int band = 0; band < PT_BANDS; band++ ) {
+		for( unsigned k = ctx->bandFirst[band]; k < ctx->bandFirst[band + 1]; k++ ) {
+			bandOf[spatial[k]] = (unsigned char) ( band + 1 );
+		}
+	}
+
+	for( int band = 0; band < PT_BANDS; band++ ) {
+		for( unsigned k = ctx->bandFirst[band]; k < ctx->bandFirst[band + 1]; k++ ) {
+			const uint32_t tile = order[k];
+
+			if( tile >= (uint32_t) bandOf.size() || bandOf[tile] != (unsigned char) ( band + 1 ) ) {
+				return fail( ctx, PBR_EINVAL, "diag_set_tile_order: entry %u (tile %u) is not a tile of band %d, or is named twice", k, tile, band );
+			}
+
+			bandOf[tile] = 0;
+		}
+	}
+
+	ctx->hTileOrder.assign( order, order + count );
+	ctx->orderPinned = true;
+	return uploadTileOrder( ctx );
 }
 
 int pbr_diag_pin_plan( pbr_ctx* ctx, int plan ) {

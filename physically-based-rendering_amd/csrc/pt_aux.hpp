@@ -41,6 +41,26 @@ __global__ __launch_bounds__( 256 ) void foldFrames( const DevParams P, const fl
 	dst[slot] = acc;
 }
 
+// Node visits per local tile: the sum of the debug image's node counts (K18, pathtracing.cl:73-78: visits / 1265) over a
+// tile's 64 pixels — the cost the queue's dealing order is built from (pbr_hip.hip, learnTileCosts).  One wave per tile.
+__global__ __launch_bounds__( 256 ) void tileCosts( const float4* dbg, float* cost, unsigned numTiles ) {
+	const unsigned tile = blockIdx.x * 4u + ( threadIdx.x >> 6 );
+
+	if( tile >= numTiles ) {
+		return;
+	}
+
+	float v = dbg[(size_t) tile * 64u + ( threadIdx.x & 63u )].y * 1265.0f;
+
+	for( int step = 32; step >= 1; step >>= 1 ) {
+		v += __shfl_xor( v, step, 64 );
+	}
+
+	if( ( threadIdx.x & 63u ) == 0u ) {
+		cost[tile] = v;
+	}
+}
+
 // ---------------------------------------------------------------------------------------
 // Scene preparation (pbr_upload_scene): per-face and per-material values the shading would otherwise
 // recompute on every hit — evaluated here by the same device functions, so the bits are the same

@@ -121,10 +121,12 @@ struct DevParams {
 	float lenseFocal, lenseAperture;
 
 	int width, height, tilesX, numLocalTiles, tileWorld, tileRank;
-	unsigned bandDiv[PT_BANDS * 2];   // per queue band: {magic, shifts} to divide by its rows (nextSlot, divInvariant)
+	const unsigned* tileOrder;        // the dealing order (nextSlot): per band of the queue its local tiles in the order they are dealt,
+	                                  // band after band.  Placement only — every unit is handed out exactly once in any order.
+	unsigned bandFirst[PT_BANDS];     // ... where a band's stretch of tileOrder starts
+	unsigned bandTiles[PT_BANDS];     // ... and how many tiles it has
 	unsigned framesDiv[2];            // {magic, shifts} to divide by nFrames (nextSlot)
 	unsigned tilesXDiv[2];  // {magic, shifts} to divide by tilesX (pixelOfSlot, divInvariant)
-	int queueWidth, queueRows;   // the local tiles as a queueRows x queueWidth grid (row-major local tile index), see nextSlot
 	float phongAlpha;            // PHONGTESS_ALPHA (kernels built with PHONG = true only)
 	int parkEighths;             // traverse(): a node phase ends once this many eighths of the lanes that entered it have left it
 	int drainMode;               // phased schedule, once lanes are DONE: bit 0 scale phPark, bit 1 scale phShade with the lanes still at work
@@ -1941,21 +1943,15 @@ PT_DEV unsigned divInvariant( unsigned n, unsigned magic, unsigned shifts ) {
 }
 
 PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, unsigned& frame ) {
-	const unsigned width = (unsigned) P.queueWidth;
-	const unsigned rowsTotal = (unsigned) P.queueRows;
-	const unsigned tiles = (unsigned) P.numLocalTiles;
-
 	while( wc.exhausted != ( 1u << PT_BANDS ) - 1u ) {
 		// first band, starting at home, that this lane has not seen empty
 		const unsigned rotated = ( ( wc.exhausted >> wc.home ) | ( wc.exhausted << ( PT_BANDS - wc.home ) ) ) & ( ( 1u << PT_BANDS ) - 1u );
 		const int mine = ( wc.home + __builtin_ctz( ~rotated ) ) & ( PT_BANDS - 1 );
 		const int band = __builtin_amdgcn_readfirstlane( mine );
 		const unsigned q = atomicAdd( P.workCounter + band * PT_BAND_STRIDE, 1u );
-		const unsigned row0 = ( (unsigned) band * rowsTotal ) / PT_BANDS;
-		const unsigned rows = ( (unsigned) ( band + 1 ) * rowsTotal ) / PT_BANDS - row0;
 
 		// frame-parallel launches: `frames` units per pixel slot of the band
-		const unsigned bandSlots = rows * width * 64u;
+		const unsigned bandSlots = P.bandTiles[band] * 64u;
 
 		if( q >= bandSlots * frames ) {
 			wc.exhausted |= 1u << band;
@@ -1965,14 +1961,9 @@ PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, u
 		// unit q of the band = frame ( q mod frames ) of its pixel slot q / frames: a pixel through all frames, then the next pixel
 		const unsigned qf = ( frames > 1u ) ? divInvariant( q, P.framesDiv[0], P.framesDiv[1] ) : q;
 		frame = q - qf * frames;
-		const unsigned tq = qf >> 6;
-		const unsigned col = divInvariant( tq, P.bandDiv[band * 2 + 0], P.bandDiv[band * 2 + 1] );
-		const unsigned row = tq - col * rows;
-		const unsigned tile = ( row0 + row ) * width + col;
-
-		if( tile < tiles ) {
-			return tile * 64u + ( qf & 63u );
-		}
+		// (a 32-bit byte offset from a scalar base: one global_load_dword with an SGPR pair, no 64-bit address in vector registers)
+		const unsigned tile = *(const unsigned*) ( (const char*) P.tileOrder + ( ( P.bandFirst[band] + ( qf >> 6 ) ) << 2 ) );
+		return tile * 64u + ( qf & 63u );
 	}
 
 	return PT_NO_WORK;

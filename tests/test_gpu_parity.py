@@ -1025,6 +1025,20 @@ def test_bench_runs_the_rccl_leg_with_one_rank(tmp_path):
                            capture_output=True, text=True, timeout=900, env=env)
     assert plain.returncode == 0, plain.stderr[-3000:]
     assert same_values(np.load(tmp_path / "dist.npy"), np.load(tmp_path / "plain.npy"))
+    # round 6: a plain one-GPU run of the default mode also times the two opt-in modes on the same workload and steps — extra
+    # keys of the SAME single line; `value` stays the default mode's
+    assert len(plain.stdout.strip().splitlines()) == 1, plain.stdout[-2000:]
+    plain_line = json.loads(plain.stdout.strip())
+    assert (plain_line["config"]["traversal"], plain_line["config"]["arith"]) == ("reference", "exact")
+    assert plain_line["roofline"]["kernel"].startswith("ptk_f0::") and plain_line["deal"] in ("spatial", "cost-classes")
+    assert sorted(plain_line["modes"]) == ["eight-order", "eight-order+native"]
+    for key, flavour, parity in (("eight-order", "ptk_f1::", "tolerance"), ("eight-order+native", "ptk_f3::", "statistical")):
+        leg = plain_line["modes"][key]
+        assert leg["parity"] == parity and leg["repeats"] >= 5 and leg["value"] > 0 and leg["unit"] == "Msamples/s"
+        assert leg["roofline"]["kernel"].startswith(flavour), leg["roofline"]["kernel"]
+        assert leg["per_sample"]["node_visits"] < plain_line["per_sample"]["node_visits"]       # the ordered walk visits fewer nodes
+        assert leg["scene_device_bytes"]["walk_streams"] > 0
+    assert "modes" not in line                                     # the collective leg's line is the default mode alone
 
 
 def test_configs_0_as_baseline_json_writes_it(pbr, oracle, device):
