@@ -23,6 +23,8 @@ HIP_LIB = os.path.join(CSRC, "libpbrhip.so")
 HIP_GUARD_LIB = os.path.join(CSRC, "libpbrhip_guard.so")   # same source, -DPBR_GUARD: every device loop bounded
 HOST_LIB = os.path.join(HOST, "libpbrhost.so")
 
+MULTI_LIB = os.path.join(HOST, "libpbrmulti.so")          # N contexts in one process + RCCL (include/pbr_multi.h)
+MULTI_SOURCES = ["multi_path_tracer.cpp"]
 HOST_SOURCES = ["Cfg.cpp", "model_io.cpp", "bvh_builder.cpp", "scene_gen.cpp", "path_tracer.cpp", "cl_adaptor.cpp", "host_capi.cpp"]
 
 
@@ -245,8 +247,36 @@ def _build_host_locked(sources):
     return HOST_LIB
 
 
+def build_multi(force=False):
+    """host/libpbrmulti.so: the in-process multi-GPU driver (host/multi_path_tracer.cpp) — g++ against the HIP runtime API
+    and RCCL's headers, linked with libpbrhip, librccl and libamdhip64.  Its own library: only a multi-GPU caller pays for
+    loading RCCL."""
+    sources = [os.path.join(HOST, f) for f in ("multi_path_tracer.cpp", "multi_path_tracer.h")] + \
+        [os.path.join(INCLUDE, f) for f in ("pbr_multi.h", "pbr_hip.h", "pbr_hip_diag.h")]
+    build_hip()
+    if not force and (not _stale(MULTI_LIB, sources) or _keep_prebuilt(MULTI_LIB, "g++")):
+        return MULTI_LIB
+    with _locked(MULTI_LIB):
+        if not force and not _stale(MULTI_LIB, sources):
+            return MULTI_LIB
+        tmp = "%s.%d.tmp" % (MULTI_LIB, os.getpid())
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-pthread", "-D__HIP_PLATFORM_AMD__",
+               "-I", INCLUDE, "-I", HOST, "-I", "/opt/rocm/include",
+               *[os.path.join(HOST, f) for f in MULTI_SOURCES], "-o", tmp,
+               "-L", CSRC, "-lpbrhip", "-L", "/opt/rocm/lib", "-lrccl", "-lamdhip64",
+               "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath,/opt/rocm/lib"]
+        try:
+            _run(cmd)
+            os.replace(tmp, MULTI_LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        _stamp(MULTI_LIB, sources)
+        return MULTI_LIB
+
+
 def build_all(force=False):
-    return build_hip(force), build_host(force)
+    return build_hip(force), build_host(force), build_multi(force)
 
 
 if __name__ == "__main__":

@@ -220,3 +220,60 @@ def test_random_configurations_in_the_native_arithmetic(pbr, device, seed):
     assert np.array_equal(a, b, equal_nan=True) and ca == cb, what
     assert ca["paths"] == w * h * frames * keys["render.samples"], what
     assert np.isfinite(a[..., :3]).all(), what            # the firewall: a frame that is not finite contributes black
+
+
+@pytest.mark.parametrize("traversal", [0, 2])
+def test_native_arithmetic_at_the_headline_configuration(pbr, device, traversal):
+    """the statistical contract at a BASELINE size — configs[3], the Sponza-class scene of 260 k triangles at
+    1920 x 1080, the configuration every bench line of this mode is quoted on.  Everything on the GPU; the exact mode is the
+    oracle bit for bit at this very size (tests/test_gpu_full_configs.py).
+
+      * 64 single-sample frames in the exact arithmetic give, per 8 x 8 tile and channel, the mean and the variance of a frame's
+        tile mean; the native 64-spp render's tile means (other seeds) lie within 3 sigma of the difference of two such means
+        as often as an exact control render's (a third set of seeds) do, to within half a point;
+      * the native image's RMSE against an exact 1024-spp render is at most 1.05 x the control's;
+      * no pixel of the native render is non-finite, and the image means agree within 3 sigma of their difference."""
+    w, h, spp, long_spp = 1920, 1080, 64, 1024
+    sc = make_scene(pbr, "sponza", 2, 260000, **{"render.max_depth": 3, "render.brdf": 1})
+    cfg, cam, px = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h)
+    cfg.traversal = traversal
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+
+    def tiles_of(img):
+        return img[..., :3].astype(np.float64).reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
+
+    device.render(0, pbr.frame_seeds(0, long_spp), px, cam)                  # frames 0 .. 1023, exact
+    long_run = device.read_output()[..., :3].astype(np.float64)
+    assert np.isfinite(long_run).all()
+    # 64 single-sample frames (frames 2000 ..): per tile the mean and the variance of ONE frame's tile mean
+    s1 = np.zeros((h // 8, w // 8, 3)); s2 = np.zeros_like(s1); mean_px = np.zeros((h, w, 3))
+    for seed in pbr.frame_seeds(2000, spp):
+        device.render_frame(float(seed), 0.0, px, cam)
+        frame = device.read_output()
+        t = tiles_of(frame)
+        s1 += t; s2 += t * t; mean_px += frame[..., :3]
+    mean_t = s1 / spp
+    var_t = (s2 - spp * mean_t * mean_t) / (spp - 1)
+    mean_px /= spp
+    sigma = np.sqrt(2.0 * np.maximum(var_t, 0.0) / spp)                      # of the difference of two independent 64-frame means
+    device.reset_accum()
+    device.render(0, pbr.frame_seeds(4000, spp), px, cam)                    # the control: exact, a third set of seeds
+    control = device.read_output()[..., :3].astype(np.float64)
+    native_cfg = _with(pbr, cfg, arith=1)
+    device.configure(native_cfg)
+    device.render(0, pbr.frame_seeds(6000, spp), px, cam)
+    got = device.read_output()[..., :3].astype(np.float64)
+    assert device.last_kernel().startswith("ptk_f%d::" % (2 | (1 if traversal else 0)))
+    assert np.isfinite(got).all()
+
+    inside = np.abs(tiles_of(got) - mean_t) <= 3.0 * sigma + 2e-6
+    inside_control = np.abs(tiles_of(control) - mean_t) <= 3.0 * sigma + 2e-6
+    rmse = np.sqrt(np.mean((got - long_run) ** 2))
+    rmse_control = np.sqrt(np.mean((control - long_run) ** 2))
+    print("sponza 260k 1920x1080 traversal %d: %.2f %% of %d tile channels within 3 sigma (control: %.2f %%); RMSE vs %d spp: native %.5f, exact control %.5f (%.3fx)" % (
+        traversal, 100 * inside.mean(), inside.size, 100 * inside_control.mean(), long_spp, rmse, rmse_control, rmse / rmse_control))
+    assert inside.mean() >= inside_control.mean() - 0.005 and inside.mean() >= 0.97
+    assert rmse <= 1.05 * rmse_control
+    sigma_image = np.sqrt(2.0 * var_t.mean(axis=(0, 1)) / (spp * (w // 8) * (h // 8)))
+    assert np.all(np.abs(got.mean(axis=(0, 1)) - mean_px.mean(axis=(0, 1))) <= 3.0 * sigma_image + 1e-6), (got.mean(axis=(0, 1)), mean_px.mean(axis=(0, 1)), sigma_image)
