@@ -20,4 +20,14 @@ for name in ("libpbrhip.so", "libpbrhip_ref.so"):
     l.pbr_mode_built.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     print(name, {(t, a): l.pbr_mode_built(t, a) for t in (0, 1, 2) for a in (0, 1)})
 PY
+# the in-process multi-GPU driver and its example program, compiled and linked against RCCL
+H=$R/physically-based-rendering_amd/host
+g++ -O2 -std=c++17 -fPIC -shared -pthread -D__HIP_PLATFORM_AMD__ -I $R/include -I $H -I /opt/rocm/include $H/multi_path_tracer.cpp -o libpbrmulti.so \
+    -L . -lpbrhip -L /opt/rocm/lib -lrccl -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared -I $R/include -I $H -I /opt/rocm/include $H/Cfg.cpp $H/model_io.cpp $H/bvh_builder.cpp $H/scene_gen.cpp \
+    $H/path_tracer.cpp $H/cl_adaptor.cpp $H/host_capi.cpp -o libpbrhost.so -L . -lpbrhip
+g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I $R/include -I $H -I /opt/rocm/include $H/examples/multi_gpu_render.cpp -o multi_gpu_render \
+    -L . -lpbrmulti -lpbrhost -lpbrhip -L /opt/rocm/lib -lrccl -lamdhip64 -pthread -Wl,-rpath,$T -Wl,-rpath,/opt/rocm/lib
+echo "multi_gpu_render links against: $(readelf -d multi_gpu_render | grep -o 'lib[a-z0-9]*\.so[.0-9]*' | tr '\n' ' ')"
+if [ "$1" = "--run" ]; then ./multi_gpu_render cornell 16 640 360; fi
 cd /; rm -rf $T
