@@ -420,7 +420,7 @@ def mode_leg(pbr, scene, base_cfg, cam, px, args, device, depth, traversal, arit
         return {
             "value": samples / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed * 1e3 / args.steps,
             "repeats": len(runs), "ms_per_step_all": [round(r[0] * 1e3 / args.steps, 5) for r in runs],
-            "parity": parity, "traversal": ("reference", "six-order", "eight-order")[traversal], "arith": ("exact", "native")[arith],
+            "parity": parity, "traversal": ("reference", "six-order", "eight-order", "eight-order-compact")[traversal], "arith": ("exact", "native")[arith],
             "schedule": plan, "deal": dev.last_deal()[0], "setup_frames": setup_frames, "setup_s": round(t_setup, 3),
             "per_sample": {"node_visits": counters["nodes"] / samples, "triangle_tests": counters["tris"] / samples,
                            "shaded_hits": counters["hits"] / samples, "algorithmic_bytes": algo / samples},
@@ -449,7 +449,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="repetitions of the K-step render (0 = until 250 ms have been timed, at most 15); the median is reported")
     ap.add_argument("--plan", type=int, default=-1,
                     help="pin schedule 0..6 (refill-lean, refill-wide, phased-lean, phased-wide, phased-mid, refill-mid, phased-dual) instead of tuning; profiling runs")
-    ap.add_argument("--traversal", default="reference", choices=["reference", "six-order", "eight-order"],
+    ap.add_argument("--traversal", default="reference", choices=["reference", "six-order", "eight-order", "eight-order-compact"],
                     help="pbr_config.traversal: the reference's one walk order (default, the headline), or the opt-in ray-ordered walk over the same flat BVH")
     ap.add_argument("--arith", default="exact", choices=["exact", "native"],
                     help="pbr_config.arith: every builtin one exact definition (default, the headline), or gfx950's native sin / cos / rcp / sqrt / log / exp")
@@ -513,7 +513,7 @@ def main():
     w, h = args.width, args.height
     cfg, cam, px = scene.config(w, h), scene.camera(), pbr.pixel_dimension(w, h)
     cfg.tile_world, cfg.tile_rank = world, rank
-    cfg.traversal = {"reference": 0, "six-order": 1, "eight-order": 2}[args.traversal]
+    cfg.traversal = {"reference": 0, "six-order": 1, "eight-order": 2, "eight-order-compact": 3}[args.traversal]
     cfg.arith = {"exact": 0, "native": 1}[args.arith]
 
     dev = pbr.Device(local_rank)

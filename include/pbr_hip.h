@@ -30,6 +30,13 @@
 extern "C" {
 #endif
 
+/* The layout of this header's structs and the meaning of its calls, as a number: bumped whenever a struct grows or an
+ * entry point changes (round 5 grew pbr_config from 60 to 68 bytes).  A caller that loads the library at run time — or
+ * links a libpbrhip.so it did not build — compares pbr_abi_version() with the PBR_ABI_VERSION it was compiled against
+ * BEFORE it hands the library a struct: pbr_configure reads sizeof( pbr_config ) bytes of ITS version. */
+#define PBR_ABI_VERSION 6
+uint32_t pbr_abi_version( void );
+
 #define PBR_OK 0
 #define PBR_EINVAL (-1)   /* bad argument / scene fails validation */
 #define PBR_EDEVICE (-2)  /* HIP error (message has the HIP error string) */
@@ -107,6 +114,11 @@ typedef struct {
 	 *            PBR_WALK_EIGHT_ORDERS (2): likewise with eight successor sets, one per sign octant of the ray direction;
 	 *            every container orders its children along ITS axis (the one their centres spread furthest on).
 	 *            Both cost node memory (6 / 8 streams of 32-byte records instead of one).
+	 *            PBR_WALK_EIGHT_ORDERS_COMPACT (3, round 6): the eight-order walk — same visits, same counters, same hits —
+	 *            over ONE 64-byte record per node shared by the eight orders (two hit candidates picked by a sign bit,
+	 *            eight `next` words): twice the reference stream's node memory instead of eight times, and scenes up to
+	 *            the wire format's own 2^24 nodes (eight streams: 8.3 M); one more 4-byte load and five more vector
+	 *            instructions per visit.
 	 * arith      PBR_ARITH_EXACT (0): every builtin has one correctly rounded / fixed definition.
 	 *            PBR_ARITH_NATIVE (1): what the reference asks its device for — native_sin / native_cos / native_tan /
 	 *            native_recip / native_divide / native_sqrt (pt_utils.cl:39-44, pt_brdf.cl:306-321, pt_intersect.cl:104,
@@ -119,6 +131,7 @@ typedef struct {
 #define PBR_WALK_REFERENCE 0u
 #define PBR_WALK_SIX_ORDERS 1u
 #define PBR_WALK_EIGHT_ORDERS 2u
+#define PBR_WALK_EIGHT_ORDERS_COMPACT 3u
 #define PBR_ARITH_EXACT 0u
 #define PBR_ARITH_NATIVE 1u
 

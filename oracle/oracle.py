@@ -170,12 +170,18 @@ def scene_and_config(desc, cfg):
     c.phong_tessellation = getattr(cfg, "phong_tessellation", 0.0)
     for k in range(4):
         c.sky_light[k] = cfg.sky_light[k]
-    c.traversal = int(getattr(cfg, "traversal", 0))
+    # pbr_config.traversal -> the oracle's walk.  The product's 3 (PBR_WALK_EIGHT_ORDERS_COMPACT) is the eight-order walk
+    # in another memory layout: the same visits, so the oracle's scheme 2 checks it.  STACK_AID selects the oracle-only
+    # analysis walk (pt_oracle.c: cfg.traversal == 3), which is no mode of the product.
+    c.traversal = {0: 0, 1: 1, 2: 2, 3: 2, STACK_AID: 3}[int(getattr(cfg, "traversal", 0))]
     if c.traversal:
         links, first = walk_orders(desc, 1 if c.traversal == 3 else c.traversal)     # 3: the stack-based analysis aid, over scheme 1's tables
         s.walk_links, s.walk_first = links.ctypes.data, first.ctypes.data
         s._walk = (links, first)          # the scene struct keeps the tables alive
     return s, c
+
+
+STACK_AID = 99      # cfg.traversal value (oracle only): the stack-based nearest-child-first walk, an analysis aid
 
 
 def walk_orders(desc, scheme):

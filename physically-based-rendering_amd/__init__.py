@@ -94,6 +94,16 @@ except Exception as exc:  # no fallback by design
 _fp = ctypes.POINTER(ctypes.c_float)
 _vp = ctypes.c_void_p
 
+# the struct mirrors below are written against this version of include/pbr_hip.h (pbr_config: 68 bytes since version 5).
+# A library of another ABI version must not be handed them; lab runs that load an older build on purpose (PBR_HIP_LIB) say so.
+ABI_VERSION = 6
+if hasattr(hip, "pbr_abi_version"):
+    hip.pbr_abi_version.restype = ctypes.c_uint32
+    if hip.pbr_abi_version() != ABI_VERSION and not _lab:
+        raise ImportError("libpbrhip.so speaks ABI version %d, this harness %d (include/pbr_hip.h, PBR_ABI_VERSION)" % (hip.pbr_abi_version(), ABI_VERSION))
+elif not _lab:
+    raise ImportError("libpbrhip.so has no pbr_abi_version(): a build older than round 6")
+
 hip.pbr_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
 hip.pbr_destroy.argtypes = [_vp]
 hip.pbr_destroy.restype = None

@@ -141,7 +141,8 @@ def build_hip(force=False, guard=False):
 #   flavour bit 0: ray-ordered walk (pbr_config.traversal)     bit 1: native arithmetic (pbr_config.arith)
 #   groups 0-2 pathTracing<.., 4 | 6 | 8>, 3 its Phong-tessellation build (flavour 0 only), 4-6 pathTracingPhased<.., 4 | 6 | 8>,
 #   7 pathTracingDual (not in PBR_GUARD builds: it has no C++ node phase)
-FLAVOURS = (0, 1, 2, 3)
+#   flavour bit 2 (with bit 0): the compact record of the eight-order walk — flavours 5 and 7 (no two-paths kernel: group 7)
+FLAVOURS = (0, 1, 2, 3, 5, 7)
 GROUPS = (0, 1, 2, 3, 4, 5, 6, 7)
 # what native arithmetic means to the compiler: `/` and sqrtf() become v_rcp_f32 / v_sqrt_f32 sequences without the
 # correction steps (the reference asks for native_divide / native_recip / native_sqrt); everything else is in pt_math.hpp
@@ -154,7 +155,7 @@ def instance_units(guard):
         for g in GROUPS:
             if g == 3 and f != 0:
                 continue                 # Phong tessellation: reference walk + exact arithmetic only
-            if g == 7 and guard:
+            if g == 7 and (guard or f & 4):
                 continue
             units.append((f, g))
     return units

@@ -249,8 +249,11 @@ PTI_DECLARE_FLAVOUR( 0 )
 PTI_DECLARE_FLAVOUR( 1 )
 PTI_DECLARE_FLAVOUR( 2 )
 PTI_DECLARE_FLAVOUR( 3 )
+PTI_DECLARE_FLAVOUR( 5 )     // the compact record of the eight-order walk (flavour bit 2; only together with bit 0)
+PTI_DECLARE_FLAVOUR( 7 )
 #define PTI_ROW( f ) { PTI_NAME( f, 0 ), PTI_NAME( f, 1 ), PTI_NAME( f, 2 ), PTI_NAME( f, 3 ), PTI_NAME( f, 4 ), PTI_NAME( f, 5 ), PTI_NAME( f, 6 ), PTI_NAME( f, 7 ) }
-const pti_picker kPickers[PTI_FLAVOURS][PTI_GROUPS] = { PTI_ROW( 0 ), PTI_ROW( 1 ), PTI_ROW( 2 ), PTI_ROW( 3 ) };
+#define PTI_NO_ROW { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }
+const pti_picker kPickers[PTI_FLAVOURS][PTI_GROUPS] = { PTI_ROW( 0 ), PTI_ROW( 1 ), PTI_ROW( 2 ), PTI_ROW( 3 ), PTI_NO_ROW, PTI_ROW( 5 ), PTI_NO_ROW, PTI_ROW( 7 ) };
 
 KernelFn pickKernel( int flavour, int group, uint32_t brdf, bool shadow, bool lights ) {
 	const pti_picker pick = kPickers[flavour][group];
@@ -258,9 +261,17 @@ KernelFn pickKernel( int flavour, int group, uint32_t brdf, bool shadow, bool li
 }
 
 // the flavour a configuration renders with
-int flavourOf( const pbr_config& cfg ) {
-	return ( ( cfg.traversal != 0 ) ? 1 : 0 ) | ( ( cfg.arith != 0 ) ? 2 : 0 );
+int flavourOf( uint32_t traversal, uint32_t arith ) {
+	return ( ( traversal != 0 ) ? 1 : 0 ) | ( ( arith != 0 ) ? 2 : 0 ) | ( ( traversal == PBR_WALK_EIGHT_ORDERS_COMPACT ) ? 4 : 0 );
 }
+
+int flavourOf( const pbr_config& cfg ) {
+	return flavourOf( cfg.traversal, cfg.arith );
+}
+
+// The two-paths-per-lane kernel (pt_dual.hpp) exists where its hand-scheduled two-walk node phase does: not in builds
+// without the assembly node phases, not over compact records — those render plan 6 with the 6-waves state machine.
+bool dualIsDual( int flavour );
 
 // the "mid" budget: <= 80 VGPRs, launched as two 768-thread blocks per CU = 6 waves / SIMD
 const int kMidBlockThreads = 768;
@@ -273,6 +284,10 @@ const bool kDualIsDual =
 #else
 	false;
 #endif
+
+bool dualIsDual( int flavour ) {
+	return kDualIsDual && ( flavour & 4 ) == 0;
+}
 
 // Scenes whose tree does not fit the staged LDS prefix ("large": the walk is most of a bounce) and those whose tree
 // does ("small": shading is): the lock-step walk's park share and refill batch differ between the two.
@@ -326,7 +341,10 @@ void invariantDivisor( unsigned d, unsigned out[2] ) {
 //
 // Layout: [ the ranked nodes, rank by rank, all orders of a rank next to each other (any prefix a block stages in LDS
 // serves every order alike) ][ order 0's other nodes in that order's depth-first sequence ][ order 1's ] ...
-int buildWalkStreams( pbr_ctx* ctx, uint32_t scheme ) {
+int buildWalkStreams( pbr_ctx* ctx, uint32_t layout ) {
+	// layout 3 = scheme 2's eight orders in the compact record (pt_kernel.hpp, "the compact record"): the successors are the same
+	const bool compact = ( layout == PBR_WALK_EIGHT_ORDERS_COMPACT );
+	const uint32_t scheme = compact ? 2u : layout;
 	const int K = ( scheme == 1 ) ? 6 : 8;
 	const uint32_t N = ctx->numNodes;
 	const std::vector<pbr_bvh_node>& bvh = ctx->hostNodes;
@@ -335,8 +353,11 @@ int buildWalkStreams( pbr_ctx* ctx, uint32_t scheme ) {
 	if( bvh.size() != N || N < 2 ) {
 		return fail( ctx, PBR_ESTATE, "ray-ordered walk: no host copy of the scene's tree" );
 	}
-	if( (size_t) K * N * 32 >= ( (size_t) 1 << 31 ) ) {
-		return fail( ctx, PBR_EINVAL, "ray-ordered walk: %d streams of %u records exceed 2 GiB (record references are 31-bit byte offsets)", K, N );
+	if( !compact && (size_t) K * N * 32 >= ( (size_t) 1 << 31 ) ) {
+		return fail( ctx, PBR_EINVAL, "ray-ordered walk: %d streams of %u records exceed 2 GiB (record references are 31-bit byte offsets); traversal = PBR_WALK_EIGHT_ORDERS_COMPACT holds 2^24 nodes", K, N );
+	}
+	if( compact && (size_t) N * 64 >= ( (size_t) 1 << 31 ) ) {
+		return fail( ctx, PBR_EINVAL, "ray-ordered walk: %u compact records exceed 2 GiB (record references are 31-bit byte offsets)", N );
 	}
 
 	// where every subtree ends
@@ -367,6 +388,7 @@ int buildWalkStreams( pbr_ctx* ctx, uint32_t scheme ) {
 	// per order and node: the node to go to when it is a hit container, and the node to go to otherwise (-1: end)
 	std::vector<int> onHit( (size_t) K * N, -1 ), onNext( (size_t) K * N, -1 );
 	std::vector<uint32_t> children, inOrder;
+	std::vector<unsigned char> axisOf( compact ? N : 0, 0 );   // compact: the axis a container sorts its children on
 
 	for( uint32_t i = 0; i < N; i++ ) {
 		if( face0s[i] >= 0 ) {
@@ -397,6 +419,14 @@ int buildWalkStreams( pbr_ctx* ctx, uint32_t scheme ) {
 					widest = hi - lo;
 					ownAxis = axis;
 				}
+			}
+		}
+
+		if( compact ) {
+			axisOf[i] = (unsigned char) ownAxis;
+
+			if( children.empty() ) {
+				return fail( ctx, PBR_EINVAL, "ray-ordered walk, compact records: container %u has no child (a record names its two first children)", i );
 			}
 		}
 
@@ -432,6 +462,87 @@ int buildWalkStreams( pbr_ctx* ctx, uint32_t scheme ) {
 				onNext[base + inOrder[j]] = ( j + 1 < inOrder.size() ) ? (int) inOrder[j + 1] : next;
 			}
 		}
+	}
+
+	if( compact ) {
+		// ONE record per node: the ranked nodes first (any prefix a block stages in LDS serves every order), the rest along
+		// order 0's depth-first sequence (all-ascending: a hit container's ascending first child is then the adjacent record)
+		const uint32_t maxHotRecords = ( 160 * 1024 - 256 ) / 64;
+		const uint32_t hot = (uint32_t) std::min<size_t>( ctx->hostRanked.size(), maxHotRecords );
+		std::vector<int> recordOf( N, -1 );
+		size_t nextRecord = 0;
+
+		for( uint32_t r = 0; r < hot; r++ ) {
+			recordOf[ctx->hostRanked[r]] = (int) nextRecord++;
+		}
+
+		for( int k = 0; k < K; k++ ) {      // every order must reach every node (a tree that is not properly nested fails here)
+			const size_t base = (size_t) k * N;
+			size_t seen = 0;
+
+			for( int node = onHit[base]; node > 0; node = ( face0s[node] < 0 ) ? onHit[base + node] : onNext[base + node] ) {
+				if( ++seen >= N ) {
+					return fail( ctx, PBR_ESTATE, "ray-ordered walk: order %d does not visit every node once", k );
+				}
+				if( k == 0 && recordOf[(size_t) node] < 0 ) {
+					recordOf[(size_t) node] = (int) nextRecord++;
+				}
+			}
+
+			if( seen != N - 1 ) {
+				return fail( ctx, PBR_ESTATE, "ray-ordered walk: order %d reaches %zu of %u nodes", k, seen, N - 1 );
+			}
+		}
+
+		// 32 bytes of header (the eight first references), then 64-byte records: 4 x float4 each; one record of padding
+		const size_t numRecords = nextRecord + 1;
+		std::vector<float4> storage( 2 + numRecords * 4, make_float4( 0.0f, 0.0f, 0.0f, 0.0f ) );
+		float4* const nodes = storage.data() + 2;
+		auto refOf = [&]( int node ) { return ( node > 0 ) ? recordOf[(size_t) node] * 64 : -1; };
+		auto asFloat = []( int v ) { return __builtin_bit_cast( float, v ); };
+
+		for( uint32_t i = 1; i < N; i++ ) {
+			const pbr_bvh_node& n = bvh[i];
+			int h0, h1;
+
+			if( face0s[i] < 0 ) {
+				// order 0 sorts every container ascending, order 7 every container descending
+				h0 = refOf( onHit[(size_t) 0 * N + i] );
+				h1 = refOf( onHit[(size_t) 7 * N + i] ) | ( 4 << axisOf[i] );
+			}
+			else {
+				h0 = (int) ( 0x80000000u | ( ( ctx->hostLinks[i] >= 0 ) ? 0x40000000u : 0u ) | (uint32_t) face0s[i] );
+				h1 = 0;
+			}
+
+			int next[8];
+
+			for( int k = 0; k < 8; k++ ) {
+				next[k] = refOf( onNext[(size_t) k * N + i] );
+			}
+
+			float4* rec = nodes + (size_t) recordOf[i] * 4;
+			rec[0] = make_float4( n.bbMin.x, n.bbMin.y, n.bbMax.x, n.bbMax.y );
+			rec[1] = make_float4( n.bbMin.z, n.bbMax.z, asFloat( h0 ), asFloat( h1 ) );
+			rec[2] = make_float4( asFloat( next[0] ), asFloat( next[1] ), asFloat( next[2] ), asFloat( next[3] ) );
+			rec[3] = make_float4( asFloat( next[4] ), asFloat( next[5] ), asFloat( next[6] ), asFloat( next[7] ) );
+		}
+
+		for( int k = 0; k < 8; k++ ) {
+			ctx->walkFirst[k] = refOf( onHit[(size_t) k * N] );
+		}
+
+		std::memcpy( storage.data(), ctx->walkFirst, sizeof( ctx->walkFirst ) );
+		HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+		(void) hipFree( ctx->dNodesWalk );
+		ctx->dNodesWalk = nullptr;
+		ctx->walkBuilt = 0;
+		HIP_TRY( ctx, hipMalloc( (void**) &ctx->dNodesWalk, sizeof( float4 ) * storage.size() ) );
+		HIP_TRY( ctx, hipMemcpy( ctx->dNodesWalk, storage.data(), sizeof( float4 ) * storage.size(), hipMemcpyHostToDevice ) );
+		ctx->walkHotAvail = hot * 2u;      // in 32-byte slots, the unit of a plan's LDS share
+		ctx->walkBytes = sizeof( float4 ) * storage.size();
+		ctx->walkBuilt = layout;
+		return PBR_OK;
 	}
 
 	// records: the ranked nodes interleaved, then every order's remaining nodes along its own depth-first sequence
@@ -509,7 +620,7 @@ int buildWalkStreams( pbr_ctx* ctx, uint32_t scheme ) {
 	HIP_TRY( ctx, hipMemcpy( ctx->dNodesWalk, storage.data(), sizeof( float4 ) * storage.size(), hipMemcpyHostToDevice ) );
 	ctx->walkHotAvail = hotPerOrder * (uint32_t) K;
 	ctx->walkBytes = sizeof( float4 ) * storage.size();
-	ctx->walkBuilt = scheme;
+	ctx->walkBuilt = layout;
 	return PBR_OK;
 }
 
@@ -872,6 +983,9 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		if( knobs.ldsSlots >= 0 ) {
 			slots = std::min<size_t>( slots, (size_t) knobs.ldsSlots );
 		}
+		if( flavour & 4 ) {
+			slots &= ~(size_t) 1;      // compact records are two slots each: a staged prefix ends on a record
+		}
 
 		// the limit is a property of the kernel function, shared by every context of the process: always the block's whole
 		// share, so that a context with a small scene never lowers it under another context's cached plan
@@ -977,7 +1091,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		status = ( status != PBR_OK ) ? status : makePlan( PTI_REFILL_MID, "refill-mid", 0, 0, &plans[5], kMidBlockThreads );
 		// 28 of a wave's up to 128 walks leave a node phase before it ends; a shade phase waits for 48 lanes (measured:
 		// profiles/r04/experiments/two_paths_per_lane.txt).  Without the hand-scheduled node phase: phased-mid's kernel and thresholds.
-		status = ( status != PBR_OK ) ? status : ( kDualIsDual
+		status = ( status != PBR_OK ) ? status : ( dualIsDual( flavour )
 			? makePlan( PTI_DUAL, "phased-dual", 28, 48, &plans[6], PBR_BLOCK, (size_t) 2 * 4 * 16 * PBR_BLOCK )
 			: makePlan( PTI_PHASED_MID, "phased-dual", 16, 40, &plans[6], kMidBlockThreads ) );
 
@@ -1305,16 +1419,21 @@ int readTiled( pbr_ctx* ctx, const float4* tiles, float* rgba, int tileWorld, in
 
 extern "C" {
 
+uint32_t pbr_abi_version( void ) {
+	return PBR_ABI_VERSION;
+}
+
 int pbr_mode_built( uint32_t traversal, uint32_t arith ) {
-	if( traversal > 2 || arith > 1 ) {
+	if( traversal > 3 || arith > 1 ) {
 		return -1;
 	}
 
-	const int flavour = ( ( traversal != 0 ) ? 1 : 0 ) | ( ( arith != 0 ) ? 2 : 0 );
+	const int flavour = flavourOf( traversal, arith );
 
 	for( int group = 0; group < PTI_GROUPS; group++ ) {
-		// the Phong-tessellation build exists in flavour 0 only; builds without the hand-scheduled node phase have no two-paths kernels
-		if( ( group == PTI_REFILL_PHONG && flavour != 0 ) || ( group == PTI_DUAL && !kDualIsDual ) ) {
+		// the Phong-tessellation build exists in flavour 0 only; builds without the hand-scheduled node phase, and the compact
+		// record's flavours, have no two-paths kernels
+		if( ( group == PTI_REFILL_PHONG && flavour != 0 ) || ( group == PTI_DUAL && !dualIsDual( flavour ) ) ) {
 			continue;
 		}
 		if( kPickers[flavour][group] == nullptr ) {
@@ -1757,8 +1876,8 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	if( cfg->phong_tessellation > 0.0f && ctx->hasScene && ctx->dTriPN == nullptr ) {
 		return fail( ctx, PBR_EINVAL, "Phong tessellation needs vertex normals: the uploaded scene's facesN / normals are missing or out of range" );
 	}
-	if( cfg->traversal > 2 || cfg->arith > 1 ) {
-		return fail( ctx, PBR_EINVAL, "traversal must be 0 (the reference's walk), 1 (six orders) or 2 (eight orders); arith 0 (exact) or 1 (native)" );
+	if( cfg->traversal > 3 || cfg->arith > 1 ) {
+		return fail( ctx, PBR_EINVAL, "traversal must be 0 (the reference's walk), 1 (six orders), 2 (eight orders) or 3 (eight orders, compact records); arith 0 (exact) or 1 (native)" );
 	}
 	if( cfg->phong_tessellation > 0.0f && ( cfg->traversal != 0 || cfg->arith != 0 ) ) {
 		return fail( ctx, PBR_EINVAL, "Phong tessellation is built for the reference's walk and the exact arithmetic only" );
@@ -2585,6 +2704,7 @@ int pbr_diag_trace_stream( pbr_ctx* ctx, int mode, const float* rays8, uint32_t 
 		const int blocksPerCU = 2048 / PBR_BLOCK;
 		size_t slots = std::min<size_t>( (size_t) mode, hotAvail );
 		slots = std::min<size_t>( slots, ( 160 * 1024 / (size_t) blocksPerCU - 256 ) / 32 );
+		slots &= ( P.walkScheme == 3 ) ? ~(size_t) 1 : ~(size_t) 0;      // compact records are two slots each
 		P.numHot = (int) slots;
 		P.numHotBytes = (int) slots * 32;
 		const dim3 grid( (unsigned) ( ctx->numCUs * blocksPerCU ) ), block( PBR_BLOCK );

@@ -11,6 +11,8 @@
 //
 //   PT_FLAVOUR  bit 0  ray-ordered walk: a walk starts at the first record of the ray's order (firstNode)
 //               bit 1  native arithmetic: v_rcp / v_sqrt / v_sin / v_cos / v_log / v_exp instead of the exact definitions
+//               bit 2  (with bit 0, round 6) the COMPACT record of the eight-order walk: one 64-byte record per node shared by
+//                      the eight orders instead of eight streams of 32-byte records (pt_kernel.hpp, "the compact record")
 //   undefined          the translation unit of pbr_hip.hip: no path-tracing kernel is instantiated there; its diagnostic and
 //                      denoise kernels take the walk from DevParams.walkScheme at run time and compute exactly
 #pragma once
@@ -23,7 +25,9 @@
 #define ptm PT_CAT( ptm_f, PT_FLAVOUR )
 #define PT_WALK_MODE ( PT_FLAVOUR & 1 )           // 0: the reference's order only; 1: a ray-ordered walk only
 #define PT_ARITH_NATIVE ( ( PT_FLAVOUR >> 1 ) & 1 )
+#define PT_WALK_COMPACT ( ( PT_FLAVOUR >> 2 ) & 1 )   // 1: the node stream holds compact 64-byte records (walkScheme 3)
 #else
 #define PT_WALK_MODE 2                             // decided per launch (DevParams.walkScheme)
 #define PT_ARITH_NATIVE 0
+#define PT_WALK_COMPACT 2                          // decided per launch (DevParams.walkScheme == 3)
 #endif

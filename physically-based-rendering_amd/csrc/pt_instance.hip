@@ -1,5 +1,5 @@
 // One group of path-tracing kernels in one build flavour (pt_instances.hpp, pt_flavour.hpp):
-//   hipcc -c -DPT_FLAVOUR=<0..3> -DPT_GROUP=<0..7> pt_instance.hip
+//   hipcc -c -DPT_FLAVOUR=<0..3 | 5 | 7> -DPT_GROUP=<0..7> pt_instance.hip
 #if !defined( PT_FLAVOUR ) || !defined( PT_GROUP )
 #error "pt_instance.hip is compiled once per (PT_FLAVOUR, PT_GROUP) pair: see build.py"
 #endif
@@ -7,6 +7,9 @@
 #include "pt_kernel.hpp"
 #include "pt_instances.hpp"
 
+#if PT_GROUP == PTI_DUAL && PT_WALK_COMPACT == 1
+#error "pathTracingDual has no node phase for the compact record: the compact flavours render plan 6 with the 6-waves state machine"
+#endif
 #if PT_GROUP == PTI_DUAL && !defined( PT_NODE_PHASE_ASM )
 #error "pathTracingDual has no C++ node phase: PBR_GUARD builds render plan 6 with the 6-waves state machine"
 #endif

@@ -6,7 +6,7 @@
 
 #include <stdint.h>
 
-#define PTI_FLAVOURS 4   // bit 0: ray-ordered walk, bit 1: native arithmetic
+#define PTI_FLAVOURS 8   // bit 0: ray-ordered walk, bit 1: native arithmetic, bit 2: compact record of the eight-order walk (only with bit 0: flavours 5 and 7)
 #define PTI_REFILL_LEAN 0    // pathTracing<.., 4>            lock step per bounce, <= 128 VGPRs
 #define PTI_REFILL_MID 1     // pathTracing<.., 6>            <= 80
 #define PTI_REFILL_WIDE 2    // pathTracing<.., 8>            <= 64

@@ -841,7 +841,7 @@ PT_DEV int walkOrderOf( int scheme, const f3 d ) {
 	const float ax = __builtin_fabsf( d.x ), ay = __builtin_fabsf( d.y ), az = __builtin_fabsf( d.z );
 	const bool xDominates = ( ax >= ay && ax >= az ), yDominates = ( ay >= az );
 	const int six = xDominates ? ( ( d.x < 0.0f ) ? 1 : 0 ) : ( yDominates ? ( ( d.y < 0.0f ) ? 3 : 2 ) : ( ( d.z < 0.0f ) ? 5 : 4 ) );
-	return ( scheme == 2 ) ? eight : six;
+	return ( scheme >= 2 ) ? eight : six;
 }
 
 PT_DEV Cursor firstNode( const DevParams& P, const f3 dir ) {
@@ -862,6 +862,55 @@ PT_DEV Cursor firstNode( const DevParams& P, const f3 dir ) {
 	}
 #endif
 	return c;
+}
+
+// ---- the compact record of the eight-order walk (round 6; walkScheme 3, build flavour bit 2) -----------------------
+// The eight-order walk as eight streams of 32-byte records costs eight times the node memory.  A container sorts its
+// children on ITS OWN axis, ascending or descending by one bit of the ray's order k — so whatever k is, a hit container
+// continues at one of TWO children, and only the word "where to continue after this node" differs between all eight orders
+// (the last child of a container inherits its parent's, which depends on the ancestors' axes).  One 64-byte record per node:
+//   n0 = {min.x, min.y, max.x, max.y}     n1 = {min.z, max.z, h0, h1}     next[8]
+//   container  h0 = its first child in ascending order, h1 = its first child in descending order | 4 << axis
+//   leaf       h0 = the leaf word (as in the 32-byte record: 1 << 31 | hasSecondFace << 30 | face0), h1 = 0
+//   next[k]    the record to continue at in order k when the box is missed, or the node is a leaf
+// References are byte offsets of 64-byte records (bits 0 - 5 clear).  A ray of order k carries kOff = 32 + 4 k: the byte
+// offset of ITS next word within a record and, in bits 2 - 4, its order as a mask against h1's axis bit:
+//   descending = h1 & kOff;  child = ( descending ? h1 : h0 ) - descending.
+// Same visits, same tests, same hits as the eight streams (the oracle's ray-ordered walk states both): a quarter of the memory,
+// one more load (4 bytes) and five more vector instructions per visit.
+#define PT_COMPACT_ON( P ) ( PT_WALK_COMPACT == 1 || ( PT_WALK_COMPACT == 2 && ( P ).walkScheme == 3 ) )
+
+PT_DEV int walkCompactOffset( const f3 d ) {
+	return 32 + 4 * ( ( ( d.x < 0.0f ) ? 1 : 0 ) | ( ( d.y < 0.0f ) ? 2 : 0 ) | ( ( d.z < 0.0f ) ? 4 : 0 ) );
+}
+
+template<bool USE_LDS>
+PT_DEV void fetchNodeCompact( const DevParams& P, const float4* lds, Cursor c, int kOff, float4* n0, float4* n1, int* next ) {
+	if( USE_LDS && c.ref < P.numHotBytes ) {
+		const char* rec = (const char*) lds + c.ref;
+		*n0 = ( (const float4*) rec )[0];
+		*n1 = ( (const float4*) rec )[1];
+		*next = *(const int*) ( rec + kOff );
+	}
+	else {
+		const char* rec = (const char*) P.nodes + (size_t) (unsigned) c.ref;
+		*n0 = ( (const float4*) rec )[0];
+		*n1 = ( (const float4*) rec )[1];
+		*next = *(const int*) ( rec + kOff );
+	}
+}
+
+PT_DEV NodeLinks decodeNodeCompact( const float4 n1, int next, int kOff ) {
+	const int h0 = __float_as_int( n1.z );
+	const int h1 = __float_as_int( n1.w );
+	const int descending = h1 & kOff;
+	NodeLinks n;
+	n.leaf = ( h0 < 0 );
+	n.face0 = leafFace0( h0 );
+	n.face1 = leafFace1( h0 );
+	n.onHit.ref = n.leaf ? next : ( ( descending != 0 ) ? h1 : h0 ) - descending;
+	n.onMiss.ref = next;
+	return n;
 }
 
 // ---- the node phase, hand-scheduled -------------------------------------------------------------
@@ -1007,6 +1056,108 @@ PT_DEV void nodePhaseAsm(
 #undef PT_NODE_PHASE_OPERANDS
 }
 
+// The same node phase over compact records (above): the cursor lives in v45 — the load of the ray's own next word overwrites
+// it (a load may overwrite a register that earlier loads of the same phase used as their address: they have issued), so a
+// missed box or a leaf finds its successor in place, and a hit container takes one of its two first children instead.
+// 27 vector + 8 scalar instructions and three loads per visit.
+template<bool ANYHIT>
+PT_DEV void nodePhaseAsmCompact(
+	const DevParams& P, const f2v oxy, const f2v ozz, const f2v ixy, const f2v izz, float rayT, int keep, int kOff,
+	int& ref, unsigned& visits, int& leafWord, float& leafTNear, float& leafTFar, int& parked
+) {
+	const float eps = EPSILON5;
+	keep = __builtin_amdgcn_readfirstlane( keep );
+	unsigned long long saved, active, parkMask, mA, mB;
+	int count;
+
+#define PT_NODE_PHASE_FETCH \
+		"v_add_u32 v62, v45, %[kOff]\n" \
+		"v_cmp_gt_i32 vcc, %[numHotBytes], v45\n" \
+		"s_and_saveexec_b64 %[active], vcc\n" \
+		"ds_read_b128 v[46:49], v45\n" \
+		"ds_read_b128 v[50:53], v45 offset:16\n" \
+		"ds_read_b32 v45, v62\n" \
+		"s_xor_b64 exec, exec, %[active]\n" \
+		"global_load_dwordx4 v[46:49], v45, %[nodes]\n" \
+		"global_load_dwordx4 v[50:53], v45, %[nodes] offset:16\n" \
+		"global_load_dword v45, v62, %[nodes]\n" \
+		"s_mov_b64 exec, %[active]\n"
+#define PT_NODE_PHASE_VISIT( cull ) \
+		"v_add_u32 %[visits], 1, %[visits]\n" \
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
+		"v_pk_add_f32 v[54:55], v[46:47], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n" \
+		"v_pk_add_f32 v[56:57], v[48:49], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n" \
+		"v_pk_add_f32 v[58:59], v[50:51], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n" \
+		"v_pk_mul_f32 v[54:55], %[ixy], v[54:55]\n" \
+		"v_pk_mul_f32 v[56:57], %[ixy], v[56:57]\n" \
+		"v_pk_mul_f32 v[58:59], %[izz], v[58:59]\n" \
+		"v_min_f32 v60, v54, v56\n" \
+		"v_min_f32 v61, v55, v57\n" \
+		"v_min_f32 v62, v58, v59\n" \
+		"v_max3_f32 v60, v60, v61, v62\n" \
+		"v_max_f32 v61, v54, v56\n" \
+		"v_max_f32 v63, v58, v59\n" \
+		"v_max_f32 v62, v55, v57\n" \
+		"v_min3_f32 v61, v61, v62, v63\n" \
+		"v_cmpx_lt_f32 %[eps], v61\n" \
+		cull \
+		"v_cmp_gt_i32 vcc, 0, v52\n" \
+		"v_and_b32 v62, v53, %[kOff]\n" \
+		"v_cmp_ne_u32 %[mB], 0, v62\n" \
+		"v_cndmask_b32 v63, v52, v53, %[mB]\n" \
+		"v_sub_u32 v63, v63, v62\n" \
+		"v_cndmask_b32 v45, v63, v45, vcc\n" \
+		"s_or_b64 %[parkMask], %[parkMask], vcc\n" \
+		"s_mov_b64 exec, %[active]\n" \
+		"v_cmp_le_i32 %[mA], 0, v45\n" \
+		"s_andn2_b64 exec, %[mA], vcc\n"
+#define PT_NODE_PHASE_LOOP( cull ) \
+		"s_mov_b64 %[saved], exec\n" \
+		"s_mov_b64 %[parkMask], 0\n" \
+		"v_mov_b32 v45, %[ref]\n" \
+		PT_NODE_PHASE_FETCH \
+	"1:\n" \
+		PT_NODE_PHASE_VISIT( cull ) \
+		"s_cbranch_scc0 3f\n" \
+		PT_NODE_PHASE_FETCH \
+		"s_bcnt1_i32_b64 %[count], exec\n" \
+		"s_cmp_gt_i32 %[count], %[keep]\n" \
+		"s_cbranch_scc1 1b\n" \
+		PT_NODE_PHASE_VISIT( cull ) \
+	"3:\n" \
+		"s_mov_b64 exec, %[saved]\n" \
+		"v_mov_b32 %[ref], v45\n" \
+		"v_cndmask_b32 %[parked], 0, 1, %[parkMask]\n" \
+		"v_mov_b32 %[leafWord], v52\n" \
+		"v_mov_b32 %[leafTNear], v60\n" \
+		"v_mov_b32 %[leafTFar], v61\n"
+
+#define PT_NODE_PHASE_OPERANDS \
+		: [ref] "+v"( ref ), [visits] "+v"( visits ), [leafWord] "=v"( leafWord ), [leafTNear] "=v"( leafTNear ), [leafTFar] "=v"( leafTFar ), [parked] "=v"( parked ), \
+		  [saved] "=&s"( saved ), [active] "=&s"( active ), [parkMask] "=&s"( parkMask ), [mA] "=&s"( mA ), [mB] "=&s"( mB ), [count] "=&s"( count ) \
+		: [oxy] "v"( oxy ), [ozz] "v"( ozz ), [ixy] "v"( ixy ), [izz] "v"( izz ), [rayT] "v"( rayT ), [kOff] "v"( kOff ), [keep] "s"( keep ), \
+		  [numHotBytes] "s"( P.numHotBytes ), [nodes] "s"( P.nodes ), [eps] "s"( eps ) \
+		: "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc"
+
+	if( ANYHIT ) {
+		asm volatile(
+			PT_NODE_PHASE_LOOP( "v_cmpx_le_f32 v60, v61\n" )
+			PT_NODE_PHASE_OPERANDS
+		);
+	}
+	else {
+		asm volatile(
+			PT_NODE_PHASE_LOOP( "v_cmpx_gt_f32 %[rayT], v60\n" "v_cmpx_le_f32 v60, v61\n" )
+			PT_NODE_PHASE_OPERANDS
+		);
+	}
+
+#undef PT_NODE_PHASE_FETCH
+#undef PT_NODE_PHASE_VISIT
+#undef PT_NODE_PHASE_LOOP
+#undef PT_NODE_PHASE_OPERANDS
+}
+
 // Round 4 measured more node phases — the adjacent record fetched along (nodePhasePair), paired half-record fetches
 // (nodePhaseHalves), polled LDS-DMA slots (nodePhaseAsync) and two walks per lane (nodePhaseDual) — all bit-identical; for ONE walk
 // per lane none is faster than this one (lab/src/pt_r04_node_phases.hpp, profiles/r04/experiments/; lab builds, -DPBR_LAB, compile
@@ -1048,6 +1199,8 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 	const f2v ixy = { invDir.x, invDir.y };
 	const f2v izz = { invDir.z, invDir.z };
 #endif
+	const int kOff = PT_COMPACT_ON( P ) ? walkCompactOffset( ray.dir ) : 0;
+	(void) kOff;
 	bool walking = true;   // the walk always visits node 1 (pt_bvh.cl:84-88)
 	unsigned visits = 0;
 	int leafWord = 0;
@@ -1065,7 +1218,12 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 			if( USE_LDS ) {
 				int parkedFlag;
 				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );
-				nodePhaseAsm<ANYHIT>( P, oxy, ozz, ixy, izz, hit.t, keep, cur.ref, visits, leafWord, leafTNear, leafTFar, parkedFlag );
+				if( PT_COMPACT_ON( P ) ) {
+					nodePhaseAsmCompact<ANYHIT>( P, oxy, ozz, ixy, izz, hit.t, keep, kOff, cur.ref, visits, leafWord, leafTNear, leafTFar, parkedFlag );
+				}
+				else {
+					nodePhaseAsm<ANYHIT>( P, oxy, ozz, ixy, izz, hit.t, keep, cur.ref, visits, leafWord, leafTNear, leafTFar, parkedFlag );
+				}
 				__builtin_amdgcn_s_setprio( 0 );
 				parked = ( parkedFlag != 0 );
 				walking = alive( cur );
@@ -1085,9 +1243,22 @@ PT_DEV void traverse( const DevParams& P, const float4* lds, const Ray& ray, Hit
 				PT_LAB_NODE_ITERATION
 
 				float4 n0, n1;
-				fetchNode<USE_LDS>( P, lds, cur, &n0, &n1 );
-				const int w0 = __float_as_int( n1.z );
-				const int w1 = __float_as_int( n1.w );
+				int w0, w1;
+
+				if( PT_COMPACT_ON( P ) ) {
+					// the compact record: w0 = the leaf word or the ray's first child, w1 = the ray's next word
+					int next;
+					fetchNodeCompact<USE_LDS>( P, lds, cur, kOff, &n0, &n1, &next );
+					const NodeLinks links = decodeNodeCompact( n1, next, kOff );
+					w0 = links.leaf ? __float_as_int( n1.z ) : links.onHit.ref;
+					w1 = next;
+				}
+				else {
+					fetchNode<USE_LDS>( P, lds, cur, &n0, &n1 );
+					w0 = __float_as_int( n1.z );
+					w1 = __float_as_int( n1.w );
+				}
+
 				float tNear, tFar;
 
 				// hit container -> w0; miss, or leaf -> w1
@@ -2210,7 +2381,12 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				int leafWord = 0, parkedFlag;
 				float unusedTFar;
 				__builtin_amdgcn_s_setprio( PT_WALK_PRIO );   // through the leaf phase below
+#if PT_WALK_COMPACT == 1
+				// (the ray's order, from its direction, per node phase: five instructions against a register carried through the whole loop)
+				nodePhaseAsmCompact<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, walkCompactOffset( st.ray.dir ), w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
+#else
 				nodePhaseAsm<false>( P, oxy, ozz, ixy, izz, w.hit.t, ( keep < 0 ) ? 0 : keep, w.cur.ref, visits, leafWord, w.leafTNear, unusedTFar, parkedFlag );
+#endif
 				st.dbgNodes += visits;
 				PT_LAB_PHASED_NODE_MID
 
@@ -2231,8 +2407,15 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 				PT_LAB_PHASED_STAT( 0 )
 
 				float4 n0, n1;
+#if PT_WALK_COMPACT == 1
+				int nextWord;
+				const int kOff = walkCompactOffset( st.ray.dir );
+				fetchNodeCompact<true>( P, lds, w.cur, kOff, &n0, &n1, &nextWord );
+				const NodeLinks node = decodeNodeCompact( n1, nextWord, kOff );
+#else
 				fetchNode<true>( P, lds, w.cur, &n0, &n1 );
 				const NodeLinks node = decodeNode( n1 );
+#endif
 				float tNear;
 
 				if( boxHit<false>( n0, n1, st.ray, w.invDir, w.hit.t, &tNear ) ) {
@@ -2315,6 +2498,8 @@ __global__ __launch_bounds__( PBR_BLOCK, MINW ) void pathTracingPhased( const De
 }
 
 
+#if PT_WALK_COMPACT != 1
 #include "pt_dual.hpp"               // pathTracingDual: the lane state machine with two paths per lane (plan 6, "phased-dual")
+#endif                               // (no two-walk node phase over compact records: those flavours render plan 6 with the 6-waves state machine)
 
 }  // namespace ptk

@@ -433,11 +433,10 @@ int pbrh_write_pfm( const char* path, const float* rgba, uint32_t width, uint32_
 
 namespace {
 
-uint32_t crc32Of( const uint8_t* data, size_t n, uint32_t crc ) {
-	static uint32_t table[256];
-	static bool ready = false;
+struct Crc32Table {
+	uint32_t at[256];
 
-	if( !ready ) {
+	Crc32Table() {
 		for( uint32_t i = 0; i < 256; i++ ) {
 			uint32_t c = i;
 
@@ -445,12 +444,14 @@ uint32_t crc32Of( const uint8_t* data, size_t n, uint32_t crc ) {
 				c = ( c & 1u ) ? ( 0xEDB88320u ^ ( c >> 1 ) ) : ( c >> 1 );
 			}
 
-			table[i] = c;
+			at[i] = c;
 		}
-
-		ready = true;
 	}
+};
 
+uint32_t crc32Of( const uint8_t* data, size_t n, uint32_t crc ) {
+	static const Crc32Table built;        // a function-local static: initialised once, thread-safe (C++11)
+	const uint32_t* table = built.at;
 	crc = ~crc;
 
 	for( size_t i = 0; i < n; i++ ) {

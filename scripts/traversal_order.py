@@ -34,7 +34,7 @@ def main():
     pbr.cfg_reset()
     pbr.cfg_set(**{"render.max_depth": 3})
     print("# oracle, %dx%d, %d frames, depth 3, BRDF 1; per path: node visits (box tests) / face tests; longest single walk" % (args.width, args.height, args.frames))
-    print("# 'stack, nearest first' is an analysis aid (oracle only, cfg.traversal = 3): every hit container's children box-tested, visited nearest first by entry distance — the bound a stackless ordered walk can approach")
+    print("# 'stack, nearest first' is an analysis aid (oracle only, cfg.traversal = oracle.STACK_AID): every hit container's children box-tested, visited nearest first by entry distance — the bound a stackless ordered walk can approach")
     for kind, seed, tris in SCENES:
         if kind not in args.scenes.split(","):
             continue
@@ -42,7 +42,7 @@ def main():
         cam, px = scene.camera(), pbr.pixel_dimension(args.width, args.height)
         seeds = pbr.frame_seeds(0, args.frames)
         rows = {}
-        for mode, name in ((0, "reference order"), (1, "six orders"), (2, "eight orders"), (3, "stack, nearest first")):
+        for mode, name in ((0, "reference order"), (1, "six orders"), (2, "eight orders"), (oracle.STACK_AID, "stack, nearest first")):
             cfg = scene.config(args.width, args.height)
             cfg.traversal = mode
             t0 = time.time()

@@ -29,6 +29,14 @@ def test_library_exports_every_declared_symbol(pbr):
         assert hasattr(pbr.hip, name), "libpbrhip.so does not export %s" % name
 
 
+def test_abi_version_is_checked(pbr):
+    """pbr_config grew in round 5 with nothing a caller could check: the header carries PBR_ABI_VERSION, the
+    library answers pbr_abi_version(), the harness refuses a mismatch at import."""
+    header = open(os.path.join(ROOT, "include", "pbr_hip.h")).read()
+    declared = int(re.search(r"#define PBR_ABI_VERSION (\d+)", header).group(1))
+    assert pbr.hip.pbr_abi_version() == declared == pbr.ABI_VERSION
+
+
 def test_wire_struct_sizes_match_the_reference(pbr):
     # camera_cl 80 B, bvhNode_cl 32 B, light_cl 48 B, materials 48 / 64 B (source/PathTracer.h:25-73)
     assert ctypes.sizeof(pbr.Camera) == 80
@@ -202,9 +210,9 @@ def test_reference_flavour_kernels_are_round_4s_register_for_register():
 
 
 def test_every_mode_is_built_into_the_product_library(pbr):
-    """pbr_mode_built: the product library carries all four build flavours (reference / ray-ordered walk x exact / native
-    arithmetic); no device needed to ask."""
-    for traversal in (0, 1, 2):
+    """pbr_mode_built: the product library carries all six build flavours (reference / ray-ordered walk / ray-ordered walk over
+    compact records x exact / native arithmetic); no device needed to ask."""
+    for traversal in (0, 1, 2, 3):
         for arith in (0, 1):
             assert pbr.hip.pbr_mode_built(traversal, arith) == 1, (traversal, arith)
-    assert pbr.hip.pbr_mode_built(3, 0) == -1 and pbr.hip.pbr_mode_built(0, 2) == -1
+    assert pbr.hip.pbr_mode_built(4, 0) == -1 and pbr.hip.pbr_mode_built(0, 2) == -1

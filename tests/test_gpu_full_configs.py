@@ -137,10 +137,10 @@ def test_properties_at_full_size(pbr, oracle, device, name):
     assert after["paths"] - before["paths"] == w * h * 2
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("name", sorted(FULL))
 def test_ray_ordered_walk_at_full_size(pbr, oracle, device, name, mode):
-    """pbr_config.traversal = six / eight orders at the configurations' own size (not a reference mode: the reference walks
+    """pbr_config.traversal = six / eight orders (3: eight orders over compact 64-byte records, the same visits) at the configurations' own size (not a reference mode: the reference walks
     one fixed order, pt_bvh.cl:102,112).  Two claims, whole frame each:
       (1) HIP(ordered) == oracle(ordered) bit for bit — image, debug image (this walk's own counters), launch counters —
           in the state machine, in the two-paths-per-lane plan and in whatever the tuner runs, and 8-way tile shards of it
