@@ -113,7 +113,10 @@ typedef struct {
 	 *            except where two faces tie exactly; the node / face-test counters and the debug image are this walk's own.
 	 *            PBR_WALK_EIGHT_ORDERS (2): likewise with eight successor sets, one per sign octant of the ray direction;
 	 *            every container orders its children along ITS axis (the one their centres spread furthest on).
-	 *            Both cost node memory (6 / 8 streams of 32-byte records instead of one).
+	 *            Both cost node memory (6 / 8 streams of 32-byte records instead of one; they are built by the pbr_configure /
+	 *            pbr_upload_scene call that completes "scene + such a mode" — which is also the call that fails when a tree
+	 *            cannot be walked that way — and freed when another traversal is configured) and ~40 bytes of host memory
+	 *            per node for the copy of the tree they are built from (kept from every upload).
 	 *            PBR_WALK_EIGHT_ORDERS_COMPACT (3, round 6): the eight-order walk — same visits, same counters, same hits —
 	 *            over ONE 64-byte record per node shared by the eight orders (two hit candidates picked by a sign bit,
 	 *            eight `next` words): twice the reference stream's node memory instead of eight times, and scenes up to
@@ -141,7 +144,7 @@ typedef struct { uint64_t nodes, tris, hits, paths; } pbr_counters;
 
 /* Which modes this build of the library carries: 1 if every plan's kernels for ( traversal, arith ) were linked in, 0 if not
  * (a build may leave a mode's translation units out), -1 for values that are no mode.  No device
- * is needed.  pbr_configure accepts any valid mode; a render in a mode that was not built fails with a message. */
+ * is needed.  pbr_configure refuses (PBR_ESTATE, with a message) a mode whose kernels were not built. */
 int pbr_mode_built( uint32_t traversal, uint32_t arith );
 
 /* new CL() — platform / device / context / profiling queue (source/CL.cpp:10-24). */

@@ -46,8 +46,14 @@ int pbr_diag_calibrate( pbr_ctx* ctx, int mode, uint64_t table_bytes, uint64_t r
  * settled on for this scene + configuration, or -1 while it is still measuring (pbr_hip.hip, launch()). */
 int pbr_diag_last_plan( pbr_ctx* ctx, char* name, size_t capacity, int* tuned );
 
+/* pbr_build_bvh: the search radius the clustering builder used in this context's last build — 32 when the context was
+ * configured for the reference's walk (or not configured yet) at the time of the call, 3 when it was configured for a
+ * ray-ordered walk, or the "ploc_radius" knob (0: no build yet).  The protocol: pbr_configure (with the traversal the tree
+ * will be walked in) BEFORE pbr_build_bvh; this call shows which one a build got. */
+int pbr_diag_bvh_build_info( pbr_ctx* ctx, int* radius );
+
 /* Device memory of the uploaded scene's arrays, bytes: [0] the node stream in the reference's order, [1] the streams of
- * the ray-ordered walk (0 until a render in such a mode has built them: six or eight times [0]), [2] the face records. */
+ * the ray-ordered walk (0 unless such a mode is configured: six or eight times [0], compact records twice [0]), [2] the face records. */
 int pbr_diag_scene_bytes( pbr_ctx* ctx, uint64_t out[3] );
 
 /* The kernel behind pbr_diag_last_plan's schedule, as a profiler prints its symbol (without "void " and the argument

@@ -154,7 +154,8 @@ for _name, _args in (
         ("pbr_diag_set_knob", [_vp, ctypes.c_char_p, ctypes.c_int]),                 # absent from round 2's library
         ("pbr_diag_get_tile_order", [_vp, ctypes.c_int, _up, ctypes.c_uint32, _up, _up]),          # round 6
         ("pbr_diag_set_tile_order", [_vp, _up, ctypes.c_uint32]),
-        ("pbr_diag_last_deal", [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)])):
+        ("pbr_diag_last_deal", [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]),
+        ("pbr_diag_bvh_build_info", [_vp, ctypes.POINTER(ctypes.c_int)])):
     if hasattr(hip, _name):
         getattr(hip, _name).argtypes = _args
 hip.pbr_diag_tune_budget.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint32)]
@@ -560,6 +561,12 @@ class Device:
         else:
             order = np.ascontiguousarray(order, np.uint32)
             self._check(hip.pbr_diag_set_tile_order(self._ctx, order.ctypes.data_as(_up), order.size))
+
+    def bvh_build_radius(self):
+        """pbr_diag_bvh_build_info: the clustering radius pbr_build_bvh last used in this context (0: no build yet)."""
+        r = ctypes.c_int(0)
+        self._check(hip.pbr_diag_bvh_build_info(self._ctx, ctypes.byref(r)))
+        return int(r.value)
 
     def last_deal(self):
         """pbr_diag_last_deal: (the order the last render's largest launch was dealt in, whether a cost order has been learnt)."""

@@ -111,6 +111,7 @@ struct pbr_ctx {
 	float costPxDim = 0.0f;
 	uint32_t launchesSinceLearn = 0;
 	char lastDeal[16] = "spatial"; // the order the largest chunk of the last render was dealt in
+	int lastBvhRadius = 0;         // pbr_build_bvh: the clustering's search radius of the last build (0: none yet / the radix-tree builder)
 	bool focusGiven = false;       // pbr_set_focus_depth: the focus pixel's previous-frame distance for the next frame
 	float focusDepth = 0.0f;
 	float4* dFrameBuf = nullptr;   // frame-parallel launches: {finalColor, focus} per frame and local pixel slot
@@ -649,6 +650,31 @@ int applyWalk( pbr_ctx* ctx, DevParams* P, uint32_t* hotAvail ) {
 	P->firstRef = ctx->walkFirst[0];
 	P->walkScheme = (int) scheme;
 	*hotAvail = ctx->walkHotAvail;
+	return PBR_OK;
+}
+
+// What a mode needs beyond valid numbers, checked where the mode is CHOSEN (pbr_configure, and pbr_upload_scene of a
+// configured context) instead of in the middle of a viewer's render loop: the mode's kernels are linked in, and —
+// with a scene present — its node streams can be built (they are, here: a tree that is not properly nested, or too many nodes
+// for 31-bit record references, fails now).  Streams of a traversal that is no longer configured are freed.
+int prepareWalk( pbr_ctx* ctx ) {
+	if( !ctx->configured ) {
+		return PBR_OK;
+	}
+	if( pbr_mode_built( ctx->cfg.traversal, ctx->cfg.arith ) != 1 ) {
+		return fail( ctx, PBR_ESTATE, "this library was built without the kernels of traversal %u / arith %u (pbr_mode_built)", ctx->cfg.traversal, ctx->cfg.arith );
+	}
+	if( ctx->walkBuilt != ctx->cfg.traversal && ctx->dNodesWalk != nullptr ) {
+		HIP_TRY( ctx, hipSetDevice( ctx->device ) );
+		(void) hipFree( ctx->dNodesWalk );
+		ctx->dNodesWalk = nullptr;
+		ctx->walkBuilt = 0;
+		ctx->walkBytes = 0;
+	}
+	if( ctx->hasScene && ctx->cfg.traversal != 0 && ctx->walkBuilt != ctx->cfg.traversal ) {
+		return buildWalkStreams( ctx, ctx->cfg.traversal );
+	}
+
 	return PBR_OK;
 }
 
@@ -1854,7 +1880,7 @@ int pbr_upload_scene( pbr_ctx* ctx, const pbr_scene_desc* s ) {
 	resetTuning( ctx );   // a new scene / configuration is tuned afresh
 	ctx->hasScene = true;
 
-	return PBR_OK;
+	return prepareWalk( ctx );   // a context that is already configured for a ray-ordered walk: its streams, now
 }
 
 int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
@@ -1928,7 +1954,7 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	resetTuning( ctx );   // a new scene / configuration is tuned afresh
 	ctx->configured = true;
 
-	return PBR_OK;
+	return prepareWalk( ctx );
 }
 
 int pbr_write_input( pbr_ctx* ctx, const float* rgba ) {
@@ -2400,6 +2426,7 @@ int buildClustered( pbr_ctx* ctx, const ptb::BuildArrays& A, uint32_t num_faces,
 	}
 
 	radius = std::min( std::max( radius, 1 ), PLOC_MAX_RADIUS );
+	ctx->lastBvhRadius = radius;
 	size_t tempBytes = 0;
 	HIP_TRY( ctx, hipcub::DeviceScan::ExclusiveSum( nullptr, tempBytes, B.flags, B.scan, (int) num_faces, ctx->stream ) );
 	HIP_TRY( ctx, dTemp.alloc( tempBytes ) );
@@ -2811,6 +2838,15 @@ int pbr_diag_last_deal( pbr_ctx* ctx, char* name, size_t capacity, int* learnt )
 		*learnt = ctx->costLearnt ? 1 : 0;
 	}
 
+	return PBR_OK;
+}
+
+int pbr_diag_bvh_build_info( pbr_ctx* ctx, int* radius ) {
+	if( ctx == nullptr || radius == nullptr ) {
+		return fail( ctx, PBR_EINVAL, "diag_bvh_build_info: null argument" );
+	}
+
+	*radius = ctx->lastBvhRadius;
 	return PBR_OK;
 }
 

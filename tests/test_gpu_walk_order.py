@@ -208,3 +208,40 @@ def test_random_configurations_in_an_ordered_mode(pbr, oracle, device, seed):
     assert same_values(got, want), what + ": " + describe_mismatch(got, want)
     assert same_values(device.read_debug(), ref.debug), what
     assert device.counters() == ref.counter_dict(), what
+
+
+def test_a_modes_streams_live_and_die_with_its_configuration(pbr, device):
+    """what a mode needs is prepared by the call that completes "scene + mode" — pbr_configure with a scene
+    present, or pbr_upload_scene into a configured context — so that this call is the one that can fail, not a render in the
+    middle of a viewer's loop; and the streams of a traversal that is no longer configured are freed."""
+    sc = make_scene(pbr, "sponza", 5, 9000)
+    cfg = sc.config(64, 48)
+    device.upload_scene(sc.desc)
+    nodes = 32 * sc.desc.num_nodes
+    for mode, expect in ((2, 8 * (nodes - 32) + 64), (3, 2 * nodes + 32), (0, 0), (1, 6 * (nodes - 32) + 64), (0, 0)):
+        cfg.traversal = mode
+        device.configure(cfg)                                  # no render yet
+        assert device.scene_bytes()["walk_streams"] == expect, (mode, device.scene_bytes())
+    cfg.traversal = 3                                            # configured first, scene second: the upload builds them
+    device.configure(cfg)
+    device.upload_scene(sc.desc)
+    assert device.scene_bytes()["walk_streams"] == 2 * nodes + 32
+
+
+def test_the_device_builder_says_which_radius_it_used(pbr, device):
+    """pbr_build_bvh clusters with radius 3 for a tree that will be walked in ray order and 32 for the reference's
+    walk — by the traversal the context is configured with AT THE TIME OF THE CALL; pbr_diag_bvh_build_info shows which."""
+    sc = make_scene(pbr, "sponza", 5, 6000)
+    a = sc.arrays()
+    assert device.bvh_build_radius() == 0
+    device.build_bvh(a["vertices"], a["facesV"], a["facesN"])    # not configured yet: the reference walk's radius
+    assert device.bvh_build_radius() == 32
+    cfg = sc.config(32, 32)
+    cfg.traversal = 2
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    device.build_bvh(a["vertices"], a["facesV"], a["facesN"])
+    assert device.bvh_build_radius() == 3
+    device.set_knob("ploc_radius", 7)
+    device.build_bvh(a["vertices"], a["facesV"], a["facesN"])
+    assert device.bvh_build_radius() == 7
