@@ -229,8 +229,10 @@ int pbr_denoise( pbr_ctx* ctx, float pxDim, const pbr_camera* cam, const pbr_den
  * (accelstructures/BVH.cpp, replicated on the host in host/bvh_builder.cpp): same format, different tree, so images agree
  * statistically, not bit for bit.  All pointers are host memory; nodes_out needs pbr_bvh_node_capacity( num_faces )
  * entries (2 * num_faces - 1: the count actually used comes back in *num_nodes_out).  Vertices must be finite.
- * The clustering's search radius follows the traversal the context is configured with at the time of the call (32 for the
- * reference's walk, 3 for a ray-ordered one, which such a tree is best walked in: DESIGN.md section 5.4).
+ * The clustering's search radius follows the traversal the context is configured with AT THE TIME OF THE CALL (32 for the
+ * reference's walk or an unconfigured context, 3 for a ray-ordered one, which such a tree is best walked in: DESIGN.md
+ * section 5.4) — so the protocol is pbr_configure( the traversal the tree will be walked in ) BEFORE pbr_build_bvh;
+ * pbr_diag_bvh_build_info (pbr_hip_diag.h) tells which radius a build got, the "ploc_radius" knob sets it outright.
  * pbr_last_kernel_ms then reports the device time of the build. */
 uint32_t pbr_bvh_node_capacity( uint32_t num_faces );
 int pbr_build_bvh( pbr_ctx* ctx, const pbr_float4* vertices, uint32_t num_vertices, const pbr_uint4* facesV, const pbr_uint4* facesN,
@@ -255,7 +257,8 @@ int pbr_get_counters( pbr_ctx* ctx, pbr_counters* out );
 /* CL::getKernelTimes (source/CL.cpp:480-488): device time of the last launch, HIP events. */
 double pbr_last_kernel_ms( const pbr_ctx* ctx );
 
-/* ---- multi-GPU tile exchange (device pointers; the caller runs the RCCL all-gather) ---- */
+/* ---- multi-GPU tile exchange (device pointers; the caller runs the RCCL all-gather — or lets pbr_multi.h do all of it:
+ * N contexts in one process, one host thread each, ncclCommInitAll + one ncclAllGather per render) ---- */
 
 /* Bytes of this rank's compact tile buffer: ceil( tiles / tile_world ) * 1024. */
 uint64_t pbr_tile_bytes( const pbr_ctx* ctx );

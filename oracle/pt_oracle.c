@@ -1421,6 +1421,15 @@ static inline int walkOrderOf( int scheme, v3 d ) {   /* (scheme 3, the analysis
 static uint32_t* g_walk_max = 0;
 void orc_debug_set_walk_max( uint32_t* slot ) { g_walk_max = slot; }
 
+/* Analysis aid (scripts/wave_orders.py, round 6), single-threaded runs only: every closest-hit walk of the ray-ordered mode
+ * appends one word — its order k | depth of the path at that walk << 4 | its node visits << 12 — so that the orders the
+ * paths of a wave would walk can be counted on the CPU. */
+static uint32_t* g_walk_log = 0;
+static uint32_t g_walk_log_cap = 0;
+static uint32_t* g_walk_log_count = 0;
+static uint32_t g_walk_depth = 0;
+void orc_debug_set_walk_log( uint32_t* log, uint32_t cap, uint32_t* count ) { g_walk_log = log; g_walk_log_cap = cap; g_walk_log_count = count; }
+
 static inline void noteWalk( uint32_t visits ) {
 	if( g_walk_max ) {
 		uint32_t seen = __atomic_load_n( g_walk_max, __ATOMIC_RELAXED );
@@ -1553,6 +1562,10 @@ static void traverseOrdered( ctx_t* c, ray4* ray ) {
 		if( node.bbMin.w >= 0.0f ) {
 			intersectFaces( c, ray, &node, tNear, tFar );
 		}
+	}
+
+	if( g_walk_log && *g_walk_log_count < g_walk_log_cap ) {
+		g_walk_log[( *g_walk_log_count )++] = (uint32_t) k | ( ( g_walk_depth & 255u ) << 4 ) | ( visits << 12 );
 	}
 
 	noteWalk( visits );
@@ -1790,6 +1803,7 @@ static void pathTracingPixel(
 		*nPaths += 1;
 
 		for( uint32_t depth = 0; depth < (uint32_t) ( cfg->max_depth + depthAdded ); depth++ ) {
+			g_walk_depth = depth;
 			traverse( c, &ray );
 
 			focus = ( sample + depth == 0 ) ? ray.t : focus;

@@ -125,6 +125,8 @@ int orc_build_walk_orders( const orc_bvh_node* bvh, int numNodes, int scheme, in
 
 /* Analysis aids (not part of any parity claim): longest single closest-hit walk in node visits. */
 void orc_debug_set_walk_max( uint32_t* slot );
+/* analysis aid, single-threaded runs: one word per closest-hit walk of the ray-ordered mode — order | path depth << 4 | node visits << 12 */
+void orc_debug_set_walk_log( uint32_t* log, uint32_t cap, uint32_t* count );
 
 /* Deterministic math layer, elementwise over n values (for ULP tests).
  * op: 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 pow(x,y), 6 rand-hash fract(sin(x)*43758.5453123) */

@@ -103,7 +103,7 @@ def assemble(src, round_name):
         rd = r.get("fabric_read_bytes_per_launch", 0.0); wr = r.get("write_size_bytes", 0.0)
         sq_keys = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS")
         traffic[key] = {"scene": cfg["scene"], "width": cfg["width"], "height": cfg["height"], "max_depth": cfg["max_depth"], "brdf": cfg["brdf"], "steps": b["steps"],
-                        "traversal": {"reference": 0, "six-order": 1, "eight-order": 2}[cfg.get("traversal", "reference")], "arith": {"exact": 0, "native": 1}[cfg.get("arith", "exact")],
+                        "traversal": {"reference": 0, "six-order": 1, "eight-order": 2, "eight-order-compact": 3}[cfg.get("traversal", "reference")], "arith": {"exact": 0, "native": 1}[cfg.get("arith", "exact")],
                         "schedule": b.get("schedule"), "plan": PLAN_NAMES.index(b["schedule"]) if b.get("schedule") in PLAN_NAMES else None,
                         "srchash": r.get("library_srchash"),
                         "fabric_read_bytes_per_launch": rd, "fabric_write_bytes_per_launch": wr,
