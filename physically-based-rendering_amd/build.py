@@ -139,7 +139,7 @@ def build_hip(force=False, guard=False):
 # -DPT_FLAVOUR=f -DPT_GROUP=g, see csrc/pt_instances.hpp / pt_flavour.hpp — next to csrc/pbr_hip.hip (the C ABI, the
 # host side of the launches and every other kernel), in parallel, and linked into one shared library.
 #   flavour bit 0: ray-ordered walk (pbr_config.traversal)     bit 1: native arithmetic (pbr_config.arith)
-#   groups 0-2 pathTracing<.., 4 | 6 | 8>, 3 its Phong-tessellation build (flavour 0 only), 4-6 pathTracingPhased<.., 4 | 6 | 8>,
+#   groups 0-2 pathTracing<.., 4 | 6 | 8>, 3 its Phong-tessellation build (every flavour since round 6), 4-6 pathTracingPhased<.., 4 | 6 | 8>,
 #   7 pathTracingDual (not in PBR_GUARD builds: it has no C++ node phase)
 #   flavour bit 2 (with bit 0): the compact record of the eight-order walk — flavours 5 and 7 (no two-paths kernel: group 7)
 FLAVOURS = (0, 1, 2, 3, 5, 7)
@@ -153,8 +153,6 @@ def instance_units(guard):
     units = []
     for f in FLAVOURS:
         for g in GROUPS:
-            if g == 3 and f != 0:
-                continue                 # Phong tessellation: reference walk + exact arithmetic only
             if g == 7 and (guard or f & 4):
                 continue
             units.append((f, g))

@@ -241,8 +241,8 @@ const size_t kCounterSlots = 16;
 
 // ---- the path-tracing kernels: one translation unit per plan and build flavour (pt_instances.hpp, pt_instance.hip) ----
 // A flavour is a build mode of the same kernel sources (pt_flavour.hpp): bit 0 the ray-ordered walk, bit 1 native
-// arithmetic.  A unit that was not linked in (PBR_GUARD builds have no two-paths-per-lane kernels; the Phong-tessellation
-// kernel exists in flavour 0 only) leaves its picker null.
+// arithmetic, bit 2 the compact record of the eight-order walk.  A unit that was not linked in (PBR_GUARD builds and the compact
+// flavours have no two-paths-per-lane kernels) leaves its picker null.
 #define PTI_DECLARE( f, g ) extern "C" const void* PTI_NAME( f, g )( uint32_t, int, int ) __attribute__( ( weak ) );
 #define PTI_DECLARE_FLAVOUR( f ) \
 	PTI_DECLARE( f, 0 ) PTI_DECLARE( f, 1 ) PTI_DECLARE( f, 2 ) PTI_DECLARE( f, 3 ) PTI_DECLARE( f, 4 ) PTI_DECLARE( f, 5 ) PTI_DECLARE( f, 6 ) PTI_DECLARE( f, 7 )
@@ -1457,9 +1457,8 @@ int pbr_mode_built( uint32_t traversal, uint32_t arith ) {
 	const int flavour = flavourOf( traversal, arith );
 
 	for( int group = 0; group < PTI_GROUPS; group++ ) {
-		// the Phong-tessellation build exists in flavour 0 only; builds without the hand-scheduled node phase, and the compact
-		// record's flavours, have no two-paths kernels
-		if( ( group == PTI_REFILL_PHONG && flavour != 0 ) || ( group == PTI_DUAL && !dualIsDual( flavour ) ) ) {
+		// builds without the hand-scheduled node phase, and the compact record's flavours, have no two-paths kernels
+		if( group == PTI_DUAL && !dualIsDual( flavour ) ) {
 			continue;
 		}
 		if( kPickers[flavour][group] == nullptr ) {
@@ -1904,9 +1903,6 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	}
 	if( cfg->traversal > 3 || cfg->arith > 1 ) {
 		return fail( ctx, PBR_EINVAL, "traversal must be 0 (the reference's walk), 1 (six orders), 2 (eight orders) or 3 (eight orders, compact records); arith 0 (exact) or 1 (native)" );
-	}
-	if( cfg->phong_tessellation > 0.0f && ( cfg->traversal != 0 || cfg->arith != 0 ) ) {
-		return fail( ctx, PBR_EINVAL, "Phong tessellation is built for the reference's walk and the exact arithmetic only" );
 	}
 	if( cfg->tile_world == 0 || cfg->tile_rank >= cfg->tile_world ) {
 		return fail( ctx, PBR_EINVAL, "tile_rank must be < tile_world, tile_world >= 1" );

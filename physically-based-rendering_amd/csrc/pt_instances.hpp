@@ -10,7 +10,7 @@
 #define PTI_REFILL_LEAN 0    // pathTracing<.., 4>            lock step per bounce, <= 128 VGPRs
 #define PTI_REFILL_MID 1     // pathTracing<.., 6>            <= 80
 #define PTI_REFILL_WIDE 2    // pathTracing<.., 8>            <= 64
-#define PTI_REFILL_PHONG 3   // pathTracing<.., 4, PHONG>     Phong tessellation (flavour 0 only)
+#define PTI_REFILL_PHONG 3   // pathTracing<.., 4, PHONG>     Phong tessellation
 #define PTI_PHASED_LEAN 4    // pathTracingPhased<.., 4>      lane state machine
 #define PTI_PHASED_MID 5     // pathTracingPhased<.., 6>
 #define PTI_PHASED_WIDE 6    // pathTracingPhased<.., 8>

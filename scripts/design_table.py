@@ -11,12 +11,12 @@ LABEL = {"cornell": "Cornell-class, depth 8 (`configs[1]`)", "dragon": "Dragon-c
 L2_CEILING = 245e9
 rows = ["| Workload (BRDF 1, depth as configured) | mode | spp | schedule the tuner kept · kernel | **Msamples/s** | nodes / tris / hits per sample | fabric B/sample (read + write) | fabric rate · `frac` of 8 TB/s | L2 hit · requests/s = share of the measured 245 G/s · L1→L2 amplification | vector ALU busy × lanes = useful | waves waiting | `bound_measured` | algorithmic B/sample · `algorithmic_GBs` | CPU oracle (256 threads) | launch: events · rocprofv3 stats avg (calls) |",
         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
-order = sorted(d, key=lambda k: (k.split("_walk")[0].replace("_native", ""), "_walk" in k, "_native" in k))
+order = sorted(d, key=lambda k: (k.split("_walk")[0].replace("_native", ""), "_walk" in k, "_walk8c" in k, "_native" in k))
 for key in order:
     r, b = d[key], d[key]["bench"]
     cfg, ps, roof = b["config"], b["per_sample"], b["roofline"]
-    base = key.replace("_walk8", "").replace("_walk6", "").replace("_native", "")
-    mode = ("eight orders" if cfg["traversal"] == "eight-order" else "six orders" if cfg["traversal"] == "six-order" else "reference order") + (" + native" if cfg["arith"] == "native" else "")
+    base = key.replace("_walk8c", "").replace("_walk8", "").replace("_walk6", "").replace("_native", "")
+    mode = {"eight-order": "eight orders", "eight-order-compact": "eight orders, compact records", "six-order": "six orders"}.get(cfg["traversal"], "reference order") + (" + native" if cfg["arith"] == "native" else "")
     samples = cfg["width"] * cfg["height"] * b["steps"]
     p = r["pmc_timed_launch"]
     rd, wr = r.get("fabric_read_bytes_per_launch", 0.0), r.get("write_size_bytes", 0.0)

@@ -277,3 +277,33 @@ def test_native_arithmetic_at_the_headline_configuration(pbr, device, traversal)
     assert rmse <= 1.05 * rmse_control
     sigma_image = np.sqrt(2.0 * var_t.mean(axis=(0, 1)) / (spp * (w // 8) * (h // 8)))
     assert np.all(np.abs(got.mean(axis=(0, 1)) - mean_px.mean(axis=(0, 1))) <= 3.0 * sigma_image + 1e-6), (got.mean(axis=(0, 1)), mean_px.mean(axis=(0, 1)), sigma_image)
+
+
+@pytest.mark.parametrize("traversal", [0, 2])
+def test_phong_tessellation_in_the_native_arithmetic(pbr, device, tmp_path, traversal):
+    """K19 with arith = native (round 6: the Phong-tessellation kernel is built in every flavour).  No bit-exact checker in
+    this mode: deterministic, finite, every path counted, and the 64-spp image mean within 2 % of the exact mode's on the
+    same seeds; the patches are there (the picture differs from the flat-triangle render of the same mode)."""
+    from test_gpu_parity import smooth_scene
+    sc = smooth_scene(pbr, tmp_path, **{"render.max_depth": 4, "render.brdf": 1, "render.phong_tessellation": 0.6})
+    w, h = 64, 48
+    cfg, cam, px, seeds = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h), pbr.frame_seeds(0, 64)
+    cfg.traversal = traversal
+    device.upload_scene(sc.desc)
+    device.configure(cfg)
+    device.render(0, seeds, px, cam)
+    exact = device.read_output()[..., :3].astype(np.float64)
+    native = _with(pbr, cfg, arith=1)
+    device.configure(native)
+    device.render(0, seeds, px, cam)
+    got, counters = device.read_output(), device.counters()
+    assert device.last_kernel().startswith("ptk_f%d::pathTracing<1, false, false, 4, true>" % (2 | (1 if traversal else 0)))
+    device.reset_accum()
+    device.render(0, seeds, px, cam)
+    assert np.array_equal(got, device.read_output()) and counters == device.counters()
+    assert np.isfinite(got[..., :3]).all() and counters["paths"] == w * h * 64
+    assert abs(got[..., :3].mean() - exact.mean()) <= 0.02 * exact.mean(), (got[..., :3].mean(), exact.mean())
+    flat = _with(pbr, native, phong_tessellation=0.0)
+    device.configure(flat)
+    device.render(0, seeds, px, cam)
+    assert not np.array_equal(device.read_output(), got)

@@ -642,10 +642,12 @@ def smooth_scene(pbr, tmp_path, **cfg):
     return pbr.HostScene.load_obj(str(tmp_path) + "/", "s.obj")
 
 
+@pytest.mark.parametrize("traversal", [0, 1, 2, 3])
 @pytest.mark.parametrize("brdf", [1, 0])
-def test_phong_tessellation_bit_exact(pbr, oracle, device, tmp_path, brdf):
+def test_phong_tessellation_bit_exact(pbr, oracle, device, tmp_path, brdf, traversal):
     """K19 (pt_phongtess.cl, PHONGTESS = 1): curved faces are intersected as Phong-tessellated patches (cubic +
-    quadratics), flat ones as triangles; hits carry the patch normal into the shading."""
+    quadratics), flat ones as triangles; hits carry the patch normal into the shading.  Round 6: in the ray-ordered walks
+    too (six orders, eight orders, eight orders over compact records) — against the oracle in the same walk."""
     sc = smooth_scene(pbr, tmp_path, **{"render.max_depth": 4, "render.brdf": brdf, "render.phong_tessellation": 0.6})
     arr = sc.arrays()
     tri_n = arr["normals"][arr["facesN"][:, :3].astype(np.int64), :3]
@@ -653,14 +655,17 @@ def test_phong_tessellation_bit_exact(pbr, oracle, device, tmp_path, brdf):
     assert curved.sum() > 200 and (~curved).sum() >= 2
     w, h = 64, 48
     cfg = sc.config(w, h)
+    cfg.traversal = traversal
     assert cfg.phong_tessellation == np.float32(0.6)
     got, want, ref = both_render(pbr, oracle, device, sc, w, h, 4, cfg=cfg)
     assert same_values(got, want), describe_mismatch(got, want)
     assert same_values(device.read_debug(), ref.debug)
     assert device.counters() == ref.counter_dict()
     assert device.last_plan()[0] == "refill-lean-phong"
+    assert device.last_kernel().startswith("ptk_f%d::pathTracing<%d, false, false, 4, true>" % ({0: 0, 1: 1, 2: 1, 3: 5}[traversal], brdf))
     # the tessellation changes the picture: the same scene with PHONGTESS off renders differently
     flat = sc.config(w, h)
+    flat.traversal = traversal
     flat.phong_tessellation = 0.0
     plain = oracle.Renderer(sc.desc, flat, threads=8).render(0, pbr.frame_seeds(0, 4), pbr.pixel_dimension(w, h), sc.camera())
     assert not same_values(plain, want)

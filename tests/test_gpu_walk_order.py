@@ -170,8 +170,7 @@ def test_mode_validation(pbr, device, tmp_path):
     with pytest.raises(pbr.PbrError, match="arith"):
         device.configure(cfg)
     cfg.traversal, cfg.arith, cfg.phong_tessellation = 1, 0, 0.5
-    with pytest.raises(pbr.PbrError, match="Phong"):
-        device.configure(cfg)
+    device.configure(cfg)                          # Phong tessellation in a ray-ordered walk: refused up to round 5, a mode like any other since
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PBR_WALK_SOAK_SEEDS", "96"))))
