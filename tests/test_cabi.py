@@ -209,6 +209,35 @@ def test_reference_flavour_kernels_are_round_4s_register_for_register():
     assert ordered_mid["vgpr_count"] <= 80 and ordered_mid["private_segment_fixed_size"] == 0 and ordered_mid["vgpr_spill_count"] == 0
 
 
+def test_round_6_left_the_kernels_in_use_register_for_register():
+    """Round 6 changed one thing inside the path-tracing kernels of the existing flavours: the queue deals its tiles through a
+    table (csrc/pt_kernel.hpp, nextSlot).  In kernels sized to the register that is not free by default — the first two
+    formulations put 32 B of scratch into the 80-register kernels — so the committed code-object metadata is held to it: the
+    kernels of the plans the tuner keeps on scenes without lights (refill-lean / -mid, phased-lean / -mid, phased-dual), in all
+    four flavours of round 5, have round 5's VGPRs, scratch and spills (within a register where no scratch is involved); and
+    the compact record's 6-waves state machine fits 80 registers without scratch like the eight streams' does."""
+    import json
+    r5 = {k["kernel"]: k for k in json.load(open(os.path.join(ROOT, "profiles", "r05", "isa", "kernels.json"))) if "pathTracing" in k["kernel"]}
+    r6 = {k["kernel"]: k for k in json.load(open(os.path.join(ROOT, "profiles", "r06", "isa", "kernels.json"))) if "pathTracing" in k["kernel"]}
+    seen = 0
+    for f in range(4):
+        for brdf in (0, 1):
+            for shape in ("pathTracing<%d, false, false, 4, false>", "pathTracing<%d, false, false, 6, false>", "pathTracingPhased<%d, false, false, 4>",
+                          "pathTracingPhased<%d, false, false, 6>", "pathTracingDual<%d, false, false>"):
+                name = "void ptk_f%d::%s(ptk_f%d::DevParams)" % (f, shape % brdf, f)
+                old, new = r5[name], r6[name]
+                assert new["private_segment_fixed_size"] == old["private_segment_fixed_size"] == 0, (name, old["private_segment_fixed_size"], new["private_segment_fixed_size"])
+                assert new["vgpr_spill_count"] == old["vgpr_spill_count"] == 0, name
+                assert abs(new["vgpr_count"] - old["vgpr_count"]) <= 1, (name, old["vgpr_count"], new["vgpr_count"])
+                seen += 1
+    assert seen == 40
+    flavours = {f: sum(1 for k in r6 if k.startswith("void ptk_f%d::" % f)) for f in range(8)}
+    assert flavours == {0: 48, 1: 48, 2: 48, 3: 48, 4: 0, 5: 42, 6: 0, 7: 42}, flavours       # the Phong unit in every flavour; no two-paths kernel over compact records
+    for f in (1, 5):
+        mid = r6["void ptk_f%d::pathTracingPhased<1, false, false, 6>(ptk_f%d::DevParams)" % (f, f)]
+        assert mid["vgpr_count"] <= 80 and mid["private_segment_fixed_size"] == 0 and mid["vgpr_spill_count"] == 0, f
+
+
 def test_every_mode_is_built_into_the_product_library(pbr):
     """pbr_mode_built: the product library carries all six build flavours (reference / ray-ordered walk / ray-ordered walk over
     compact records x exact / native arithmetic); no device needed to ask."""

@@ -317,7 +317,7 @@ def test_bench_roofline_is_physical_and_cannot_go_stale():
             continue
         line = rec["bench"]
         cfg = line["config"]
-        traversal = {"reference": 0, "six-order": 1, "eight-order": 2}[cfg.get("traversal", "reference")]
+        traversal = {"reference": 0, "six-order": 1, "eight-order": 2, "eight-order-compact": 3}[cfg.get("traversal", "reference")]
         arith = {"exact": 0, "native": 1}[cfg.get("arith", "exact")]
         traffic = bench.recorded_traffic(cfg["scene"], cfg["width"], cfg["height"], cfg["max_depth"], cfg["brdf"], traversal, arith)
         assert traffic is not None and traffic["source"].startswith(os.path.relpath(round_dir, ROOT)), key
@@ -328,7 +328,7 @@ def test_bench_roofline_is_physical_and_cannot_go_stale():
             import csv
             rows = [r for r in csv.DictReader(open(os.path.join(round_dir, key, "kernel_stats.csv"))) if "pathTracing" in r["Name"]]
             assert rows and line["roofline"]["kernel"] + "(" in rows[0]["Name"], (key, line["roofline"]["kernel"], rows[0]["Name"] if rows else None)
-            assert ("ptk_f%d::" % ((1 if traversal else 0) | (2 if arith else 0))) in line["roofline"]["kernel"], key
+            assert ("ptk_f%d::" % ((1 if traversal else 0) | (2 if arith else 0) | (4 if traversal == 3 else 0))) in line["roofline"]["kernel"], key
         samples = cfg["width"] * cfg["height"] * line["steps"]
         seconds = line["roofline"]["launch_ms"] / 1e3
         block = bench.roofline_block(cfg["scene"], traffic["schedule"], traffic, line["per_sample"]["algorithmic_bytes"] * samples, samples, seconds, kernel=line["roofline"].get("kernel"))
