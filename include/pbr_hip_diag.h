@@ -78,7 +78,7 @@ int pbr_diag_launch_fit( pbr_ctx* ctx, double* fixed_ms, double* per_frame_ms );
  *   "face_normals"  0 = recompute the face normal on every hit (takes effect at the next pbr_upload_scene)
  *   "bvh_builder"   pbr_build_bvh: 0 clustering (default), 1 round 1's radix tree; "ploc_radius": its search radius
  *   "tune_log"      1 = the schedule tuner logs its launches to stderr
- *   "deal_order"    the queue's dealing order: 0 always spatial, 1 always cost-ordered (once learnt), -1 by the launch's size
+ *   "deal_order"    the queue's dealing order: 0 always spatial, 1 always cost classes, 2 always expensive last (once learnt), -1 by the render call's size
  * Setting a knob rebuilds the plans and restarts the schedule tuner. */
 int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value );
 
@@ -93,18 +93,20 @@ int pbr_diag_pin_plan( pbr_ctx* ctx, int plan );
  * of rows with one queue head each; band b's tiles are dealt in the order the stretch [band_first[b], band_first[b + 1]) of
  * the table names them (local tile indices; the table has one entry per local tile).
  * Placement is for speed only: every (pixel, frame) unit is handed out exactly once in any order, images and counters
- * do not depend on it (tested).  get: which = 0 the spatial (or pinned) table, 1 the library's cost-ordered table (PBR_ESTATE
- * until one has been learnt); *count = entries, order[] filled when non-null.  set: `order` must hold, per band, a
- * permutation of that band's own tiles (else PBR_EINVAL) and then stays in force until pbr_configure (the library's
- * own cost-ordered dealing is off meanwhile); NULL = back to the library's choice. */
+ * do not depend on it (tested).  get: which = 0 the spatial (or pinned) table, 1 the library's cost-classes table, 2 its
+ * expensive-last table (PBR_ESTATE until they have been learnt); *count = entries, order[] filled when non-null.  set: with band_first = NULL `order` must hold,
+ * per band, a permutation of that band's own tiles; with band_first[9] ANY partition of the local tiles into eight lists
+ * (band_first[0] = 0, non-decreasing, band_first[8] = count; every tile once) — else PBR_EINVAL.  The table then stays in
+ * force until pbr_configure (the library's own choice is off meanwhile); order = NULL: back to the library's choice. */
 int pbr_diag_get_tile_order( pbr_ctx* ctx, int which, uint32_t* order, uint32_t capacity, uint32_t* count, uint32_t band_first[9] );
-int pbr_diag_set_tile_order( pbr_ctx* ctx, const uint32_t* order, uint32_t count );
+int pbr_diag_set_tile_order( pbr_ctx* ctx, const uint32_t* order, uint32_t count, const uint32_t* band_first );
 
-/* The order the (largest launch of the) last render was dealt in: "spatial" — inside a band column by column —, "cost-classes"
- * — per band eight classes of falling cost, spatial inside a class; the library's choice for launches of up to 128 Ki
- * tiles x frames once it has learnt the tiles' costs from a debug image (csrc/pbr_hip.hip, learnTileCosts) — or "pinned"
- * (pbr_diag_set_tile_order).  *learnt = whether a cost order exists.  Knob "deal_order": 0 always spatial, 1 always
- * cost-ordered once learnt, -1 by size. */
+/* The order the last render was dealt in: "spatial" — inside a band column by column —; "cost-classes" — per band eight
+ * classes of falling cost, spatial inside a class: render calls of up to 128 Ki tiles x frames —; "expensive-last" — per band
+ * its most expensive quarter last, spatial inside both parts: calls above 192 Ki —, the two once the library has learnt the
+ * tiles' costs from a debug image (csrc/pbr_hip.hip, learnTileCosts); or "pinned" (pbr_diag_set_tile_order).  *learnt =
+ * whether the cost orders exist.  Knob "deal_order": 0 always spatial, 1 always cost classes, 2 always expensive last (once
+ * learnt), -1 by size. */
 int pbr_diag_last_deal( pbr_ctx* ctx, char* name, size_t capacity, int* learnt );
 
 /* How many frames of the configured size the schedule tuner wants to see before it settles (its launch lengths are

@@ -153,7 +153,7 @@ for _name, _args in (
         ("pbr_diag_launch_fit", [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
         ("pbr_diag_set_knob", [_vp, ctypes.c_char_p, ctypes.c_int]),                 # absent from round 2's library
         ("pbr_diag_get_tile_order", [_vp, ctypes.c_int, _up, ctypes.c_uint32, _up, _up]),          # round 6
-        ("pbr_diag_set_tile_order", [_vp, _up, ctypes.c_uint32]),
+        ("pbr_diag_set_tile_order", [_vp, _up, ctypes.c_uint32, _up]),
         ("pbr_diag_last_deal", [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]),
         ("pbr_diag_bvh_build_info", [_vp, ctypes.POINTER(ctypes.c_int)])):
     if hasattr(hip, _name):
@@ -543,24 +543,26 @@ class Device:
         """Render with schedule `plan` (index into PLAN_NAMES) without tuning; -1 = let the tuner choose."""
         self._check(hip.pbr_diag_pin_plan(self._ctx, int(plan)))
 
-    def tile_order(self, cost_ordered=False):
+    def tile_order(self, cost_ordered=False, which=None):
         """pbr_diag_get_tile_order: (order, band_first) — the local tiles in the order the queue deals them, band b's
-        stretch = order[band_first[b]:band_first[b + 1]]; cost_ordered: the library's learnt cost order instead of the spatial
-        (or pinned) one."""
-        n, first, which = ctypes.c_uint32(), (ctypes.c_uint32 * 9)(), 1 if cost_ordered else 0
+        stretch = order[band_first[b]:band_first[b + 1]]; cost_ordered (which = 1): the library's learnt cost-classes order instead
+        of the spatial (or pinned) one; which = 2: its expensive-last order."""
+        n, first, which = ctypes.c_uint32(), (ctypes.c_uint32 * 9)(), (which if which is not None else (1 if cost_ordered else 0))
         self._check(hip.pbr_diag_get_tile_order(self._ctx, which, None, 0, ctypes.byref(n), first))
         order = np.empty(n.value, np.uint32)
         self._check(hip.pbr_diag_get_tile_order(self._ctx, which, order.ctypes.data_as(_up), n.value, ctypes.byref(n), first))
         return order, np.array(first[:], np.int64)
 
-    def set_tile_order(self, order):
-        """pbr_diag_set_tile_order: deal the tiles in this order (per band a permutation of the band's own tiles) until the next
-        pbr_configure; None hands the order back to the library."""
+    def set_tile_order(self, order, band_first=None):
+        """pbr_diag_set_tile_order: deal the tiles in this order until the next pbr_configure — per band a permutation of the
+        band's own tiles, or with band_first (9 entries) any partition of the local tiles into eight lists; None hands the order
+        back to the library."""
         if order is None:
-            self._check(hip.pbr_diag_set_tile_order(self._ctx, None, 0))
+            self._check(hip.pbr_diag_set_tile_order(self._ctx, None, 0, None))
         else:
             order = np.ascontiguousarray(order, np.uint32)
-            self._check(hip.pbr_diag_set_tile_order(self._ctx, order.ctypes.data_as(_up), order.size))
+            first = None if band_first is None else np.ascontiguousarray(band_first, np.uint32)
+            self._check(hip.pbr_diag_set_tile_order(self._ctx, order.ctypes.data_as(_up), order.size, None if first is None else first.ctypes.data_as(_up)))
 
     def bvh_build_radius(self):
         """pbr_diag_bvh_build_info: the clustering radius pbr_build_bvh last used in this context (0: no build yet)."""

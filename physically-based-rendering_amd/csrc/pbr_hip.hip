@@ -96,7 +96,8 @@ struct pbr_ctx {
 	// the banded queue's dealing order (pt_kernel.hpp, nextSlot): the local tiles as a queueRows x queueWidth grid cut into
 	// PT_BANDS bands of rows; hTileOrder / dTileOrder name, per band, its tiles in the order they are dealt
 	int queueWidth = 1, queueRows = 1;
-	unsigned bandFirst[PT_BANDS + 1] = {};
+	unsigned bandFirst[PT_BANDS + 1] = {};       // of hTileOrder / dTileOrder (the spatial table, or a pinned one)
+	unsigned costBandFirst[PT_BANDS + 1] = {};   // of hCostOrder / dCostOrder
 	std::vector<unsigned> hTileOrder;
 	unsigned* dTileOrder = nullptr;
 	bool orderPinned = false;      // pbr_diag_set_tile_order: the caller's order stays (tests, A/B runs)
@@ -104,13 +105,15 @@ struct pbr_ctx {
 	// falling cost, spatial order inside a class; learnt from the debug image (node visits per pixel of a launch's last frame)
 	std::vector<unsigned> hCostOrder;
 	unsigned* dCostOrder = nullptr;
+	std::vector<unsigned> hLastOrder;   // LONG launches: per band its most expensive quarter last, spatial inside both parts (the spatial bands)
+	unsigned* dLastOrder = nullptr;
 	float* dTileCost = nullptr;    // node visits per local tile
 	std::vector<float> hTileCost;
 	bool costLearnt = false;       // dCostOrder holds an order learnt for costCam
 	pbr_camera costCam = {};       // the camera (and pixel size) the costs were measured with
 	float costPxDim = 0.0f;
 	uint32_t launchesSinceLearn = 0;
-	char lastDeal[16] = "spatial"; // the order the largest chunk of the last render was dealt in
+	char lastDeal[16] = "spatial"; // the order the last render was dealt in
 	int lastBvhRadius = 0;         // pbr_build_bvh: the clustering's search radius of the last build (0: none yet / the radix-tree builder)
 	bool focusGiven = false;       // pbr_set_focus_depth: the focus pixel's previous-frame distance for the next frame
 	float focusDepth = 0.0f;
@@ -213,6 +216,9 @@ void freeImages( pbr_ctx* ctx ) {
 	ctx->frameBufFrames = 0;
 	(void) hipFree( ctx->dTileOrder );
 	(void) hipFree( ctx->dCostOrder );
+	(void) hipFree( ctx->dLastOrder );
+	ctx->dLastOrder = nullptr;
+	ctx->hLastOrder.clear();
 	(void) hipFree( ctx->dTileCost );
 	ctx->dTileOrder = ctx->dCostOrder = nullptr;
 	ctx->dTileCost = nullptr;
@@ -685,14 +691,14 @@ int prepareWalk( pbr_ctx* ctx ) {
 //
 // The spatial order (rounds 1 - 5's only one): inside a band column by column, so that the tiles the waves of one XCD hold
 // at a time form a compact block of the image, not a strip as wide as the frame.
-void spatialTileOrder( pbr_ctx* ctx, std::vector<unsigned>* order ) {
+void spatialTileOrder( const pbr_ctx* ctx, std::vector<unsigned>* order, unsigned first[PT_BANDS + 1] ) {
 	order->clear();
 	order->reserve( (size_t) ctx->numLocalTiles );
 
 	for( int band = 0; band < PT_BANDS; band++ ) {
 		const unsigned row0 = ( (unsigned) band * (unsigned) ctx->queueRows ) / PT_BANDS;
 		const unsigned rows = ( (unsigned) ( band + 1 ) * (unsigned) ctx->queueRows ) / PT_BANDS - row0;
-		ctx->bandFirst[band] = (unsigned) order->size();
+		first[band] = (unsigned) order->size();
 
 		for( unsigned col = 0; col < (unsigned) ctx->queueWidth; col++ ) {
 			for( unsigned row = 0; row < rows; row++ ) {
@@ -705,7 +711,7 @@ void spatialTileOrder( pbr_ctx* ctx, std::vector<unsigned>* order ) {
 		}
 	}
 
-	ctx->bandFirst[PT_BANDS] = (unsigned) order->size();
+	first[PT_BANDS] = (unsigned) order->size();
 }
 
 int uploadTileOrder( pbr_ctx* ctx ) {
@@ -724,17 +730,66 @@ int uploadTileOrder( pbr_ctx* ctx ) {
 // hairball 127.9 -> 131.5) and a single full frame neither gains nor loses.  So the order is chosen per launch by its size:
 // cost classes up to kCostOrderTileFrames tiles x frames, the spatial order above.  Eight classes by the band's own cost
 // octiles — the finer the classes the less locality is left, a full sort is the worst on long launches and no better on short.
+//
+// LONG launches (found late in round 6, profiles/r06/experiments/deal_order_ascending*.txt, band_balance*.txt): the same cost
+// map, the other way round.  A band that deals its most EXPENSIVE quarter LAST — spatial order inside both parts — renders a long
+// launch 1 - 7 % faster than the spatial order: Sponza-class 20 frames 19.37 -> 19.10 ms (two-paths plan), 20.13 -> 19.60 (6 waves);
+// Dragon-class 19.85 -> 18.60 ms, 64 frames 61.1 -> 57.0; hairball 127.7 -> 125.2; Cornell 27.2 -> 26.1; the eight-order walk alike
+// (Dragon-class 49.96 -> 47.14 ms); rank 0 of 8 from ~40 frames on.  The gain is proportional to the launch's length, the opposite
+// direction (expensive first) loses as much, the split point hardly matters (15 / 25 / 40 %), ascending classes do the same and
+// interleaving the classes does not: what counts is that a band's heavy tiles come when the XCDs whose own bands are cheap have
+// run out of them and join in (bands differ by up to 10 x in cost, and an XCD works on its own band until it is empty) — the
+// heavy part of every band is then shared by all eight XCDs, their L2s and their fabric links, instead of being its owner's alone.
+// Equalising the bands' costs by moving their row boundaries gives a fifth of that.  Below ~192 Ki tiles x frames it loses to the
+// spatial order (the long paths start last), hence three orders by the size of the RENDER CALL (all launches of a call — the
+// schedule tuner's chunks too — are dealt alike, so the tuner measures what it decides about):
+//   tiles x frames <= 128 Ki  eight classes of falling cost     <= 192 Ki  spatial     above  expensive quarter last
 const unsigned kCostClasses = 8;
 const size_t kCostOrderTileFrames = 128 * 1024;
+const size_t kSpatialOrderTileFrames = 192 * 1024;
+
+// per band: the spatial order, stably partitioned into [ the cheaper three quarters ][ the most expensive quarter ]
+void expensiveLastTileOrder( const unsigned bandFirst[PT_BANDS + 1], const std::vector<unsigned>& spatial, const std::vector<float>& cost, std::vector<unsigned>* order ) {
+	order->assign( spatial.size(), 0u );
+	std::vector<float> sorted;
+
+	for( int band = 0; band < PT_BANDS; band++ ) {
+		const unsigned first = bandFirst[band], n = bandFirst[band + 1] - first;
+
+		if( n == 0 ) {
+			continue;
+		}
+
+		sorted.resize( n );
+
+		for( unsigned k = 0; k < n; k++ ) {
+			sorted[k] = cost[spatial[first + k]];
+		}
+
+		std::sort( sorted.begin(), sorted.end() );
+		const float edge = sorted[std::min<size_t>( n - 1, ( (size_t) 3 * n ) / 4 )];
+		unsigned at = first;
+
+		for( int pass = 0; pass < 2; pass++ ) {
+			for( unsigned k = 0; k < n; k++ ) {
+				const unsigned tile = spatial[first + k];
+
+				if( ( cost[tile] > edge ) == ( pass == 1 ) ) {
+					( *order )[at++] = tile;
+				}
+			}
+		}
+	}
+}
 
 // per band: the spatial order, stably partitioned into kCostClasses classes of falling cost (class edges = the band's octiles)
-void costTileOrder( pbr_ctx* ctx, const std::vector<unsigned>& spatial, const std::vector<float>& cost, std::vector<unsigned>* order ) {
+void costTileOrder( const unsigned bandFirst[PT_BANDS + 1], const std::vector<unsigned>& spatial, const std::vector<float>& cost, std::vector<unsigned>* order ) {
 	order->assign( spatial.size(), 0u );
 	std::vector<float> sorted;
 	std::vector<unsigned> fill( kCostClasses );
 
 	for( int band = 0; band < PT_BANDS; band++ ) {
-		const unsigned first = ctx->bandFirst[band], n = ctx->bandFirst[band + 1] - first;
+		const unsigned first = bandFirst[band], n = bandFirst[band + 1] - first;
 
 		if( n == 0 ) {
 			continue;
@@ -806,9 +861,11 @@ int learnTileCosts( pbr_ctx* ctx, const pbr_camera* cam, float pxDim ) {
 	HIP_TRY( ctx, hipMemcpyAsync( ctx->hTileCost.data(), ctx->dTileCost, sizeof( float ) * tiles, hipMemcpyDeviceToHost, ctx->stream ) );
 	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
 	std::vector<unsigned> spatial;
-	spatialTileOrder( ctx, &spatial );
-	costTileOrder( ctx, spatial, ctx->hTileCost, &ctx->hCostOrder );
+	spatialTileOrder( ctx, &spatial, ctx->costBandFirst );
+	costTileOrder( ctx->costBandFirst, spatial, ctx->hTileCost, &ctx->hCostOrder );
+	expensiveLastTileOrder( ctx->costBandFirst, spatial, ctx->hTileCost, &ctx->hLastOrder );
 	HIP_TRY( ctx, hipMemcpyAsync( ctx->dCostOrder, ctx->hCostOrder.data(), sizeof( unsigned ) * ctx->hCostOrder.size(), hipMemcpyHostToDevice, ctx->stream ) );
+	HIP_TRY( ctx, hipMemcpyAsync( ctx->dLastOrder, ctx->hLastOrder.data(), sizeof( unsigned ) * ctx->hLastOrder.size(), hipMemcpyHostToDevice, ctx->stream ) );
 	HIP_TRY( ctx, hipStreamSynchronize( ctx->stream ) );
 	ctx->costLearnt = true;
 	ctx->costCam = *cam;
@@ -937,12 +994,7 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	P.tilesX = ctx->tilesX;
 	invariantDivisor( (unsigned) ctx->tilesX, P.tilesXDiv );
 	P.numLocalTiles = ctx->numLocalTiles;
-	P.tileOrder = ctx->dTileOrder;
-
-	for( int band = 0; band < PT_BANDS; band++ ) {
-		P.bandFirst[band] = ctx->bandFirst[band];
-		P.bandTiles[band] = ctx->bandFirst[band + 1] - ctx->bandFirst[band];
-	}
+	P.tileOrder = ctx->dTileOrder;      // (and its band stretches: per launch, below)
 
 	invariantDivisor( 1u, P.framesDiv );   // nextSlot divides by the frames of the launch (set per chunk below)
 	P.tileWorld = (int) ctx->cfg.tile_world;
@@ -1265,6 +1317,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 	double traceMs = 0.0;
 	uint32_t launches = 0, largest = 0;
 
+	int dealt = 0;
+
+	if( !ctx->orderPinned && ctx->costLearnt && knobs.dealOrder != 0 ) {
+		const size_t tileFrames = (size_t) ctx->numLocalTiles * nFrames;
+		dealt = ( knobs.dealOrder > 0 ) ? std::min( knobs.dealOrder, 2 ) : ( tileFrames <= kCostOrderTileFrames ) ? 1 : ( tileFrames <= kSpatialOrderTileFrames ) ? 0 : 2;
+	}
+
+	std::snprintf( ctx->lastDeal, sizeof( ctx->lastDeal ), "%s", ctx->orderPinned ? "pinned" : ( dealt == 1 ) ? "cost-classes" : ( dealt == 2 ) ? "expensive-last" : "spatial" );
 	HIP_TRY( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
 
 	for( uint32_t done = 0; done < nFrames; ) {
@@ -1312,9 +1372,14 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 		P.seeds = ctx->dSeeds + done;
 		// the dealing order, by the launch's size (costTileOrder): short launches end sooner with the expensive tiles first,
 		// long ones are faster in the spatial order
-		const bool costOrdered = !ctx->orderPinned && ctx->costLearnt && knobs.dealOrder != 0 &&
-			( knobs.dealOrder == 1 || (size_t) ctx->numLocalTiles * n <= kCostOrderTileFrames );
-		P.tileOrder = costOrdered ? ctx->dCostOrder : ctx->dTileOrder;
+		// the dealing order, by the size of the render call (costTileOrder / expensiveLastTileOrder): 0 spatial, 1 cost classes, 2 expensive last
+		P.tileOrder = ( dealt == 1 ) ? ctx->dCostOrder : ( dealt == 2 ) ? ctx->dLastOrder : ctx->dTileOrder;
+
+		for( int band = 0; band < PT_BANDS; band++ ) {
+			const unsigned* first = ( dealt != 0 ) ? ctx->costBandFirst : ctx->bandFirst;
+			P.bandFirst[band] = first[band];
+			P.bandTiles[band] = first[band + 1] - first[band];
+		}
 
 
 		HIP_TRY( ctx, hipEventRecord( ctx->evTraceStart, ctx->stream ) );
@@ -1339,7 +1404,6 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 		if( n > largest ) {
 			largest = n;
-			std::snprintf( ctx->lastDeal, sizeof( ctx->lastDeal ), "%s", ctx->orderPinned ? "pinned" : ( costOrdered ? "cost-classes" : "spatial" ) );
 			std::snprintf( ctx->lastPlan, sizeof( ctx->lastPlan ), "%s", plan.name );
 			std::snprintf( ctx->lastKernel, sizeof( ctx->lastKernel ), "%s", plan.kernelName );
 		}
@@ -1933,9 +1997,10 @@ int pbr_configure( pbr_ctx* ctx, const pbr_config* cfg ) {
 	// the local tiles as a grid for the banded queue: its true shape when unsharded, about that when sharded
 	ctx->queueWidth = std::max( 1, ( ctx->tilesX + (int) cfg->tile_world - 1 ) / (int) cfg->tile_world );
 	ctx->queueRows = ( ctx->numLocalTiles + ctx->queueWidth - 1 ) / ctx->queueWidth;
-	spatialTileOrder( ctx, &ctx->hTileOrder );
+	spatialTileOrder( ctx, &ctx->hTileOrder, ctx->bandFirst );
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dTileOrder, sizeof( unsigned ) * ctx->hTileOrder.size() ) );
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dCostOrder, sizeof( unsigned ) * ctx->hTileOrder.size() ) );
+	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dLastOrder, sizeof( unsigned ) * std::max<size_t>( 1, ctx->hTileOrder.size() ) ) );
 	HIP_TRY( ctx, hipMalloc( (void**) &ctx->dTileCost, sizeof( float ) * std::max<size_t>( 1, ctx->hTileOrder.size() ) ) );
 	ctx->costLearnt = false;
 	ctx->launchesSinceLearn = 0;
@@ -2929,7 +2994,7 @@ int pbr_diag_get_tile_order( pbr_ctx* ctx, int which, uint32_t* order, uint32_t 
 		return fail( ctx, PBR_ESTATE, "diag_get_tile_order: no cost order has been learnt yet (it is built after the first render)" );
 	}
 
-	const std::vector<unsigned>& table = ( which != 0 ) ? ctx->hCostOrder : ctx->hTileOrder;
+	const std::vector<unsigned>& table = ( which == 1 ) ? ctx->hCostOrder : ( which == 2 ) ? ctx->hLastOrder : ctx->hTileOrder;
 	const uint32_t n = (uint32_t) table.size();
 
 	if( count != nullptr ) {
@@ -2938,7 +3003,7 @@ int pbr_diag_get_tile_order( pbr_ctx* ctx, int which, uint32_t* order, uint32_t 
 
 	if( band_first != nullptr ) {
 		for( int band = 0; band <= PT_BANDS; band++ ) {
-			band_first[band] = ctx->bandFirst[band];
+			band_first[band] = ( which != 0 ) ? ctx->costBandFirst[band] : ctx->bandFirst[band];
 		}
 	}
 
@@ -2953,17 +3018,19 @@ int pbr_diag_get_tile_order( pbr_ctx* ctx, int which, uint32_t* order, uint32_t 
 	return PBR_OK;
 }
 
-int pbr_diag_set_tile_order( pbr_ctx* ctx, const uint32_t* order, uint32_t count ) {
+int pbr_diag_set_tile_order( pbr_ctx* ctx, const uint32_t* order, uint32_t count, const uint32_t* band_first ) {
 	if( ctx == nullptr || !ctx->configured ) {
 		return fail( ctx, PBR_ESTATE, "diag_set_tile_order before pbr_configure" );
 	}
 
 	HIP_TRY( ctx, hipSetDevice( ctx->device ) );
 	std::vector<unsigned> spatial;
-	spatialTileOrder( ctx, &spatial );
+	unsigned spatialFirst[PT_BANDS + 1];
+	spatialTileOrder( ctx, &spatial, spatialFirst );
 
 	if( order == nullptr ) {
 		ctx->hTileOrder = spatial;
+		std::memcpy( ctx->bandFirst, spatialFirst, sizeof( spatialFirst ) );
 		ctx->orderPinned = false;
 		return uploadTileOrder( ctx );
 	}
@@ -2972,20 +3039,36 @@ int pbr_diag_set_tile_order( pbr_ctx* ctx, const uint32_t* order, uint32_t count
 		return fail( ctx, PBR_EINVAL, "diag_set_tile_order: %u entries, the queue has %zu tiles", count, spatial.size() );
 	}
 
-	// every band's stretch must be a permutation of that band's own tiles: a unit dealt twice or never is a wrong image
-	std::vector<unsigned char> bandOf( spatial.size(), 0 );
+	const uint32_t* first = ( band_first != nullptr ) ? band_first : spatialFirst;
+
+	if( first[0] != 0u || first[PT_BANDS] != count ) {
+		return fail( ctx, PBR_EINVAL, "diag_set_tile_order: the bands' stretches must cover the table: band_first[0] = 0, band_first[8] = %u", count );
+	}
 
 	for( int band = 0; band < PT_BANDS; band++ ) {
-		for( unsigned k = ctx->bandFirst[band]; k < ctx->bandFirst[band + 1]; k++ ) {
-			bandOf[spatial[k]] = (unsigned char) ( band + 1 );
+		if( first[band] > first[band + 1] ) {
+			return fail( ctx, PBR_EINVAL, "diag_set_tile_order: band_first must not decrease (band %d)", band );
+		}
+	}
+
+	// the table must name every local tile exactly once: a unit dealt twice or never is a wrong image.  Without band_first the
+	// bands are the spatial ones and every band's stretch must hold that band's own tiles.
+	std::vector<unsigned char> bandOf( spatial.size(), 1 );
+
+	if( band_first == nullptr ) {
+		for( int band = 0; band < PT_BANDS; band++ ) {
+			for( unsigned k = spatialFirst[band]; k < spatialFirst[band + 1]; k++ ) {
+				bandOf[spatial[k]] = (unsigned char) ( band + 1 );
+			}
 		}
 	}
 
 	for( int band = 0; band < PT_BANDS; band++ ) {
-		for( unsigned k = ctx->bandFirst[band]; k < ctx->bandFirst[band + 1]; k++ ) {
+		for( unsigned k = first[band]; k < first[band + 1]; k++ ) {
 			const uint32_t tile = order[k];
+			const unsigned char want = ( band_first == nullptr ) ? (unsigned char) ( band + 1 ) : (unsigned char) 1;
 
-			if( tile >= (uint32_t) bandOf.size() || bandOf[tile] != (unsigned char) ( band + 1 ) ) {
+			if( tile >= (uint32_t) bandOf.size() || bandOf[tile] != want ) {
 				return fail( ctx, PBR_EINVAL, "diag_set_tile_order: entry %u (tile %u) is not a tile of band %d, or is named twice", k, tile, band );
 			}
 
@@ -2994,6 +3077,7 @@ int pbr_diag_set_tile_order( pbr_ctx* ctx, const uint32_t* order, uint32_t count
 	}
 
 	ctx->hTileOrder.assign( order, order + count );
+	std::memcpy( ctx->bandFirst, first, sizeof( spatialFirst ) );
 	ctx->orderPinned = true;
 	return uploadTileOrder( ctx );
 }

@@ -48,6 +48,20 @@ def cost_order(spatial, first, cost, classes):
             hi, lo = np.quantile(c, 0.9), np.quantile(c, 0.2)
             cls = np.where(c >= hi, 0, np.where(c <= lo, 2, 1))
             out[first[b]:first[b + 1]] = seg[np.argsort(cls, kind="stable")]
+        elif classes >= 300:
+            # 300 + p: the most expensive p % of the band's tiles LAST, the rest first, spatial inside both
+            cut = np.quantile(c, 1.0 - (classes - 300) / 100.0)
+            out[first[b]:first[b + 1]] = seg[np.argsort((c > cut).astype(int), kind="stable")]
+        elif classes >= 200:
+            # 200 + p: the cheapest p % of the band's tiles FIRST, the rest after them, spatial inside both
+            cut = np.quantile(c, (classes - 200) / 100.0)
+            out[first[b]:first[b + 1]] = seg[np.argsort((c > cut).astype(int), kind="stable")]
+        elif classes >= 100:
+            # 100 + n: n classes ASCENDING (cheapest class first), spatial inside a class
+            n = classes - 100
+            edges = np.quantile(c, np.linspace(0, 1, n + 1)[1:-1])
+            cls = np.searchsorted(edges, c, side="right")
+            out[first[b]:first[b + 1]] = seg[np.argsort(cls, kind="stable")]
         else:
             edges = np.quantile(c, np.linspace(0, 1, classes + 1)[1:-1])
             cls = classes - 1 - np.searchsorted(edges, c, side="right")
@@ -59,7 +73,8 @@ def main():
     plans = [int(p) for p in os.environ.get("PBR_PLANS", "6 4").split()]
     worlds = [int(p) for p in os.environ.get("DEAL_WORLDS", "1 8").split()]
     lengths = [int(p) for p in os.environ.get("DEAL_FRAMES", "1 20 64").split()]
-    variants = [("spatial", None), ("3 classes", 3), ("8 classes", 8), ("32 classes", 32), ("sorted", 0), ("ascending", -1)]
+    variants = [("spatial", None), ("3 classes", 3), ("8 classes", 8), ("32 classes", 32), ("sorted", 0), ("ascending", -1), ("asc 2", 102), ("asc 3", 103), ("asc 4", 104), ("asc 8", 108), ("cheap10 first", 210), ("cheap25 first", 225), ("cheap75 first", 275),
+                ("exp10 last", 310), ("exp25 last", 325), ("spatial again", None)]
     if os.environ.get("DEAL_VARIANTS"):
         variants = [v for v in variants if v[0] in os.environ["DEAL_VARIANTS"].split(",")]
     reps = int(os.environ.get("DEAL_REPS", 7))

@@ -1,5 +1,6 @@
 """The ORDER in which the work queue deals its tiles (round 6: cost-ordered dealing, expensive tiles first) is placement
-only: whatever the order — the spatial one, the library's own cost order, a reversed or a shuffled one handed in through
+only: whatever the order — the spatial one, the library's own two cost orders (falling classes for short render calls, the
+expensive quarter last for long ones), a reversed or a shuffled one handed in through
 pbr_diag_set_tile_order — every (pixel, frame) unit is rendered exactly once, and image, debug image and counters are the
 oracle's bit for bit.  Every plan, sharded and unsharded, single-frame and multi-frame launches."""
 import numpy as np
@@ -52,8 +53,14 @@ def test_any_dealing_order_renders_the_oracles_bits(pbr, oracle, gpu_device, pla
         assert sorted(order.tolist()) == list(range(order.size))          # the table names every local tile once
         rng = np.random.default_rng(7)
         results = {}
-        for label, perm in [("library", None)] + list(_orders(order, first, rng).items()):
-            dev.set_tile_order(perm)
+        for label, perm in [("library", None), ("library: cost classes", 1), ("library: expensive last", 2)] + list(_orders(order, first, rng).items()):
+            if isinstance(perm, int):                                      # the library's own two cost orders, forced by the knob
+                dev.set_tile_order(None)
+                dev.set_knob("deal_order", perm)
+                dev.pin_plan(PLANS[plan])                                  # (a knob resets the tuner, not the pin: say it again all the same)
+            else:
+                dev.set_knob("deal_order", -1)
+                dev.set_tile_order(perm)
             dev.reset_accum()
             dev.render(0, seeds, px, cam)                                  # one multi-frame launch
             results[label] = (dev.read_output(), dev.read_debug(), dev.counters())
@@ -123,14 +130,34 @@ def test_the_librarys_cost_order(pbr, oracle, gpu_device, kind, triangles, w, h)
         dev.render(0, seeds, px, cam)
         assert dev.last_deal()[0] == "spatial"
         assert same_values(dev.read_output(), want)
+        # the order of LONG render calls: every band's most expensive quarter last, spatial inside both parts
+        last, first3 = dev.tile_order(which=2)
+        assert np.array_equal(first, first3)
+        for b in range(8):
+            seg, base = last[first[b]:first[b + 1]], spatial[first[b]:first[b + 1]]
+            assert sorted(seg.tolist()) == sorted(base.tolist())
+            place = {int(t): k for k, t in enumerate(base)}
+            breaks = [k for k in range(1, len(seg)) if place[int(seg[k])] < place[int(seg[k - 1])]]
+            assert len(breaks) <= 1, (b, breaks)                                   # two spatial runs
+            if breaks:
+                k = breaks[0]
+                assert cost[seg[:k]].max() <= cost[seg[k:]].min() + 1e-3 * max(1.0, cost.max()) and len(seg) - k <= 0.3 * len(seg) + 1
+        dev.set_knob("deal_order", 2)                           # ... forced onto this short render: the oracle's bits all the same
+        dev.reset_accum()
+        dev.render(0, seeds, px, cam)
+        assert dev.last_deal()[0] == "expensive-last"
+        assert same_values(dev.read_output(), want) and same_values(dev.read_debug(), ref.debug)
         dev.set_knob("deal_order", -1)
         dev.set_knob("chunk_frames", -1)
         tiles = (w // 8) * (h // 8)
-        many = pbr.frame_seeds(0, 1 + (128 * 1024) // tiles + 4)          # a launch above the size limit of the cost order
+        many = pbr.frame_seeds(0, 1 + (128 * 1024) // tiles + 4)          # a render call above the size limit of the cost classes ...
         dev.reset_accum()
         dev.render(0, many[:1], px, cam)
         dev.render(1, many[1:], px, cam)
         assert dev.last_deal()[0] == "spatial"
+        more = pbr.frame_seeds(len(many), (192 * 1024) // tiles + 4)        # ... and one above the spatial order's
+        dev.render(len(many), more, px, cam)
+        assert dev.last_deal()[0] == "expensive-last"
     finally:
         dev.close()
 
