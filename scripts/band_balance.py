@@ -57,6 +57,23 @@ def table(bounds, width, tiles, cost, expensive_last=0.0, interleave=0, first_to
     return np.array(order, np.uint32), np.array(first, np.uint32)
 
 
+def table_global(bounds, width, tiles, cost, share, spread):
+    """The most expensive `share` of ALL tiles (one global cut) last: in their own bands (spread = False), or dealt round-robin
+    to the tails of the eight bands whatever band they lie in (spread = True: every XCD gets an eighth of the heavy work)."""
+    cut = np.quantile(cost, 1.0 - share)
+    light, heavy = [], []
+    for b in range(8):
+        seg = np.array([r * width + c for c in range(width) for r in range(bounds[b], bounds[b + 1]) if r * width + c < tiles], np.int64)
+        light.append(seg[cost[seg] <= cut]); heavy.append(seg[cost[seg] > cut])
+    if spread:
+        every = np.concatenate(heavy)
+        heavy = [every[b::8] for b in range(8)]
+    order, first = [], [0]
+    for b in range(8):
+        order.extend(light[b].tolist()); order.extend(heavy[b].tolist()); first.append(len(order))
+    return np.array(order, np.uint32), np.array(first, np.uint32)
+
+
 def main():
     plans = [int(p) for p in os.environ.get("PBR_PLANS", "6 4").split()]
     worlds = [int(p) for p in os.environ.get("DEAL_WORLDS", "1").split()]
@@ -96,6 +113,12 @@ def main():
                             ("equal + exp40 last", table(equal, width, tiles, cost, 0.40)), ("equal + exp15 last", table(equal, width, tiles, cost, 0.15)),
                             ("balanced + interleave 4", table(balanced, width, tiles, cost, interleave=4)), ("equal + interleave 4", table(equal, width, tiles, cost, interleave=4)),
                             ("equal rows (library) again", None)]
+                if os.environ.get("BAND_GLOBAL"):
+                    variants = [("equal rows (library)", None), ("equal + exp25 last", table(equal, width, tiles, cost, 0.25)),
+                                ("global heavy 25 % last, own band", table_global(equal, width, tiles, cost, 0.25, False)),
+                                ("global heavy 25 % last, spread", table_global(equal, width, tiles, cost, 0.25, True)),
+                                ("global heavy 40 % last, own band", table_global(equal, width, tiles, cost, 0.40, False)),
+                                ("equal rows (library) again", None)]
                 if desc8 is not None:
                     variants = [("equal rows (library)", None), ("8 classes falling", desc8), ("equal + exp25 last", table(equal, width, tiles, cost, 0.25)), ("equal rows (library) again", None)]
                 print("%-8s N=%d: cost share of the eight equal-row bands %s; balanced row bounds %s" % (name, world, " ".join("%.3f" % s for s in share), balanced), flush=True)
