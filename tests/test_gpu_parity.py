@@ -1035,7 +1035,7 @@ def test_bench_runs_the_rccl_leg_with_one_rank(tmp_path):
     assert len(plain.stdout.strip().splitlines()) == 1, plain.stdout[-2000:]
     plain_line = json.loads(plain.stdout.strip())
     assert (plain_line["config"]["traversal"], plain_line["config"]["arith"]) == ("reference", "exact")
-    assert plain_line["roofline"]["kernel"].startswith("ptk_f0::") and plain_line["deal"] in ("spatial", "cost-classes")
+    assert plain_line["roofline"]["kernel"].startswith("ptk_f0::") and plain_line["deal"] in ("spatial", "cost-classes", "expensive-last")
     assert sorted(plain_line["modes"]) == ["eight-order", "eight-order+native"]
     for key, flavour, parity in (("eight-order", "ptk_f1::", "tolerance"), ("eight-order+native", "ptk_f3::", "statistical")):
         leg = plain_line["modes"][key]
