@@ -57,6 +57,20 @@ def table(bounds, width, tiles, cost, expensive_last=0.0, interleave=0, first_to
     return np.array(order, np.uint32), np.array(first, np.uint32)
 
 
+def table_coda(bounds, width, tiles, cost, expensive=0.25, coda=0.10):
+    """Per band: [ the middle ][ the most expensive `expensive` ][ the cheapest `coda` ] — the heavy tiles late (shared by the XCDs that
+    have run out of their own), and the very last paths to start short ones."""
+    order, first = [], [0]
+    for b in range(8):
+        seg = np.array([r * width + c for c in range(width) for r in range(bounds[b], bounds[b + 1]) if r * width + c < tiles], np.int64)
+        if len(seg):
+            lo, hi = np.quantile(cost[seg], coda), np.quantile(cost[seg], 1.0 - expensive)
+            key = np.where(cost[seg] > hi, 1, np.where(cost[seg] <= lo, 2, 0))
+            seg = seg[np.argsort(key, kind="stable")]
+        order.extend(seg.tolist()); first.append(len(order))
+    return np.array(order, np.uint32), np.array(first, np.uint32)
+
+
 def table_global(bounds, width, tiles, cost, share, spread):
     """The most expensive `share` of ALL tiles (one global cut) last: in their own bands (spread = False), or dealt round-robin
     to the tails of the eight bands whatever band they lie in (spread = True: every XCD gets an eighth of the heavy work)."""
@@ -121,6 +135,10 @@ def main():
                                 ("equal rows (library) again", None)]
                 if desc8 is not None:
                     variants = [("equal rows (library)", None), ("8 classes falling", desc8), ("equal + exp25 last", table(equal, width, tiles, cost, 0.25)), ("equal rows (library) again", None)]
+                    if os.environ.get("BAND_CODA"):
+                        variants[3:3] = [("exp25 late + cheapest 10 % coda", table_coda(equal, width, tiles, cost, 0.25, 0.10)),
+                                         ("exp25 late + cheapest 25 % coda", table_coda(equal, width, tiles, cost, 0.25, 0.25)),
+                                         ("exp40 late + cheapest 20 % coda", table_coda(equal, width, tiles, cost, 0.40, 0.20))]
                 print("%-8s N=%d: cost share of the eight equal-row bands %s; balanced row bounds %s" % (name, world, " ".join("%.3f" % s for s in share), balanced), flush=True)
                 for label, tb in variants:
                     if tb is None:
