@@ -57,6 +57,24 @@ def table(bounds, width, tiles, cost, expensive_last=0.0, interleave=0, first_to
     return np.array(order, np.uint32), np.array(first, np.uint32)
 
 
+def table_paired(bounds, width, tiles, cost, expensive_last=0.0):
+    """The eight row ranges assigned to band INDICES so that in the queue's cyclic stealing order (home + 1, home + 2, ...) every
+    light band is followed by a heavy one: ranges sorted by cost c0 <= ... <= c7 take the indices of c0 c7 c1 c6 c2 c5 c3 c4."""
+    segs = []
+    for b in range(8):
+        seg = np.array([r * width + c for c in range(width) for r in range(bounds[b], bounds[b + 1]) if r * width + c < tiles], np.int64)
+        if expensive_last > 0 and len(seg):
+            cut = np.quantile(cost[seg], 1.0 - expensive_last)
+            seg = seg[np.argsort((cost[seg] > cut).astype(int), kind="stable")]
+        segs.append(seg)
+    by_cost = sorted(range(8), key=lambda b: cost[segs[b]].sum())
+    arrangement = [by_cost[0], by_cost[7], by_cost[1], by_cost[6], by_cost[2], by_cost[5], by_cost[3], by_cost[4]]
+    order, first = [], [0]
+    for b in arrangement:
+        order.extend(segs[b].tolist()); first.append(len(order))
+    return np.array(order, np.uint32), np.array(first, np.uint32)
+
+
 def table_coda(bounds, width, tiles, cost, expensive=0.25, coda=0.10):
     """Per band: [ the middle ][ the most expensive `expensive` ][ the cheapest `coda` ] — the heavy tiles late (shared by the XCDs that
     have run out of their own), and the very last paths to start short ones."""
@@ -132,6 +150,11 @@ def main():
                                 ("global heavy 25 % last, own band", table_global(equal, width, tiles, cost, 0.25, False)),
                                 ("global heavy 25 % last, spread", table_global(equal, width, tiles, cost, 0.25, True)),
                                 ("global heavy 40 % last, own band", table_global(equal, width, tiles, cost, 0.40, False)),
+                                ("equal rows (library) again", None)]
+                if os.environ.get("BAND_PAIRED"):
+                    variants = [("equal rows (library)", None), ("equal + exp25 last", table(equal, width, tiles, cost, 0.25)),
+                                ("light next to heavy, spatial", table_paired(equal, width, tiles, cost)),
+                                ("light next to heavy + exp25 last", table_paired(equal, width, tiles, cost, 0.25)),
                                 ("equal rows (library) again", None)]
                 if desc8 is not None:
                     variants = [("equal rows (library)", None), ("8 classes falling", desc8), ("equal + exp25 last", table(equal, width, tiles, cost, 0.25)), ("equal rows (library) again", None)]
