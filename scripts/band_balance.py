@@ -75,6 +75,23 @@ def table_paired(bounds, width, tiles, cost, expensive_last=0.0):
     return np.array(order, np.uint32), np.array(first, np.uint32)
 
 
+def table_stripes(rows, width, tiles, cost, g, expensive_last=0.0):
+    """Stripes of g tile rows dealt round-robin to the eight bands (band b holds stripes b, b + 8, ...), column by column inside a
+    stripe: every XCD gets a sample of the whole image (balanced at all times) at the price of its L2 seeing all of the scene."""
+    segs = [[] for _ in range(8)]
+    for k, r0 in enumerate(range(0, rows, g)):
+        seg = [r * width + c for c in range(width) for r in range(r0, min(rows, r0 + g)) if r * width + c < tiles]
+        segs[k % 8].extend(seg)
+    order, first = [], [0]
+    for b in range(8):
+        seg = np.array(segs[b], np.int64)
+        if expensive_last > 0 and len(seg):
+            cut = np.quantile(cost[seg], 1.0 - expensive_last)
+            seg = seg[np.argsort((cost[seg] > cut).astype(int), kind="stable")]
+        order.extend(seg.tolist()); first.append(len(order))
+    return np.array(order, np.uint32), np.array(first, np.uint32)
+
+
 def table_coda(bounds, width, tiles, cost, expensive=0.25, coda=0.10):
     """Per band: [ the middle ][ the most expensive `expensive` ][ the cheapest `coda` ] — the heavy tiles late (shared by the XCDs that
     have run out of their own), and the very last paths to start short ones."""
@@ -150,6 +167,12 @@ def main():
                                 ("global heavy 25 % last, own band", table_global(equal, width, tiles, cost, 0.25, False)),
                                 ("global heavy 25 % last, spread", table_global(equal, width, tiles, cost, 0.25, True)),
                                 ("global heavy 40 % last, own band", table_global(equal, width, tiles, cost, 0.40, False)),
+                                ("equal rows (library) again", None)]
+                if os.environ.get("BAND_STRIPES"):
+                    variants = [("equal rows (library)", None), ("equal + exp25 last", table(equal, width, tiles, cost, 0.25)),
+                                ("stripes of 2 rows", table_stripes(rows, width, tiles, cost, 2)), ("stripes of 4 rows", table_stripes(rows, width, tiles, cost, 4)),
+                                ("stripes of 8 rows", table_stripes(rows, width, tiles, cost, 8)), ("stripes of 4 rows + exp25 last", table_stripes(rows, width, tiles, cost, 4, 0.25)),
+                                ("stripes of 8 rows + exp25 last", table_stripes(rows, width, tiles, cost, 8, 0.25)),
                                 ("equal rows (library) again", None)]
                 if os.environ.get("BAND_PAIRED"):
                     variants = [("equal rows (library)", None), ("equal + exp25 last", table(equal, width, tiles, cost, 0.25)),
