@@ -727,9 +727,9 @@ int uploadTileOrder( pbr_ctx* ctx ) {
 // heaviest_tiles_first.txt): rank 0's share of a 20-frame render split 8 ways -3.5 ... -8 % (Sponza-class 3.14 -> 3.00 ms,
 // Dragon-class 3.85 -> 3.72, hairball 6.97 -> 6.72, Cornell 1.50 -> 1.42), its single frame -2 ... -10 %; but a long launch
 // LOSES 1 - 8 % because the tiles an XCD holds at one time are no longer neighbours (Sponza-class 64 frames 60.5 -> 61.1 ms,
-// hairball 127.9 -> 131.5) and a single full frame neither gains nor loses.  So the order is chosen per launch by its size:
-// cost classes up to kCostOrderTileFrames tiles x frames, the spatial order above.  Eight classes by the band's own cost
-// octiles — the finer the classes the less locality is left, a full sort is the worst on long launches and no better on short.
+// hairball 127.9 -> 131.5) and a single full frame neither gains nor loses.  So falling classes only up to kCostOrderTileFrames
+// tiles x frames (what is dealt above that: next paragraph).  Eight classes by the band's own cost octiles — the finer the
+// classes the less locality is left, a full sort is the worst on long launches and no better on short.
 //
 // LONG launches (found late in round 6, profiles/r06/experiments/deal_order_ascending*.txt, band_balance*.txt): the same cost
 // map, the other way round.  A band that deals its most EXPENSIVE quarter LAST — spatial order inside both parts — renders a long
@@ -740,7 +740,9 @@ int uploadTileOrder( pbr_ctx* ctx ) {
 // interleaving the classes does not: what counts is that a band's heavy tiles come when the XCDs whose own bands are cheap have
 // run out of them and join in (bands differ by up to 10 x in cost, and an XCD works on its own band until it is empty) — the
 // heavy part of every band is then shared by all eight XCDs, their L2s and their fabric links, instead of being its owner's alone.
-// Equalising the bands' costs by moving their row boundaries gives a fifth of that.  Below ~192 Ki tiles x frames it loses to the
+// Equalising the bands' costs by moving their row boundaries gives a fifth of that; and the heavy tiles have to be the VERY last a
+// band deals: a coda of its cheapest 10 % behind them gives the whole gain back (band_balance_cheap_coda.txt), which the reading
+// above does not explain.  Below ~192 Ki tiles x frames it loses to the
 // spatial order (the long paths start last), hence three orders by the size of the RENDER CALL (all launches of a call — the
 // schedule tuner's chunks too — are dealt alike, so the tuner measures what it decides about):
 //   tiles x frames <= 128 Ki  eight classes of falling cost     <= 192 Ki  spatial     above  expensive quarter last

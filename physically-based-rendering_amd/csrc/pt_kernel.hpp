@@ -2070,14 +2070,16 @@ PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, La
 }
 
 // ---- the pixel-slot queue ----------------------------------------------------------------
-// Work is handed out in pixel slots (64 per 8x8 tile).  The local tiles form a grid of
-// queueRows x queueWidth tiles, cut into PT_BANDS horizontal bands with one queue head each; a
-// wave prefers the band of the XCD it runs on (HW_REG_XCC_ID) and moves on to the other bands once
-// its own is empty.  So the 8 XCDs — each with a private 4 MiB L2 — work on 8 different parts of
-// the image instead of all on the same strip, and the rays in flight on one XCD (primary rays and
-// the first bounces that start where they hit) share that L2 with 1/8 of the scene's hot lines
-// instead of all of them.  Inside a band, tiles are dealt column by column, so the tiles that the
-// waves of one XCD hold at a time form a compact block, not a 1920-pixel-wide strip.
+// Work is handed out in pixel slots (64 per 8x8 tile).  The local tiles are partitioned into PT_BANDS
+// lists — bands of tile rows — with one queue head each; a wave prefers the band of the XCD it runs on
+// (HW_REG_XCC_ID) and moves on to the other bands once its own is empty.  So the 8 XCDs — each with a
+// private 4 MiB L2 — work on 8 different parts of the image instead of all on the same strip, and the rays
+// in flight on one XCD (primary rays and the first bounces that start where they hit) share that L2 with 1/8
+// of the scene's hot lines instead of all of them.  WHICH tile a band deals next is a table the host writes
+// (DevParams.tileOrder; pbr_hip.hip, "the dealing order"): column by column inside the band — the tiles the
+// waves of one XCD hold at a time form a compact block, not a 1920-pixel-wide strip — or, once the host knows
+// what the tiles cost, by cost (expensive tiles first in short render calls, the expensive quarter last in
+// long ones); the kernel only follows the table.
 // Frame-parallel launches deal a PIXEL THROUGH ALL ITS FRAMES before the next pixel of the tile: the 64 units a
 // wave fetches together are 64 frames of one pixel — camera rays that differ only by their jitter, the same nodes,
 // the same leaf, the same material — and a lane that finishes takes another frame of a pixel nearby.  Against frame
