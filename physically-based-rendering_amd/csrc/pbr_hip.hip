@@ -743,8 +743,8 @@ int uploadTileOrder( pbr_ctx* ctx ) {
 // Equalising the bands' costs by moving their row boundaries gives a fifth of that; and the heavy tiles have to be the VERY last a
 // band deals: a coda of its cheapest 10 % behind them gives the whole gain back (band_balance_cheap_coda.txt), which the reading
 // above does not explain.  Below ~192 Ki tiles x frames it loses to the
-// spatial order (the long paths start last), hence three orders by the size of the RENDER CALL (all launches of a call — the
-// schedule tuner's chunks too — are dealt alike, so the tuner measures what it decides about):
+// spatial order (the long paths start last), hence three orders by the size of the RENDER CALL (all launches of a call alike;
+// while the schedule tuner is still measuring, everything is dealt spatially: launch()):
 //   tiles x frames <= 128 Ki  eight classes of falling cost     <= 192 Ki  spatial     above  expensive quarter last
 const unsigned kCostClasses = 8;
 const size_t kCostOrderTileFrames = 128 * 1024;
@@ -1321,7 +1321,12 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	int dealt = 0;
 
-	if( !ctx->orderPinned && ctx->costLearnt && knobs.dealOrder != 0 ) {
+	// While the schedule tuner is still measuring, everything is dealt spatially: its chunks are short launches whatever the call's
+	// length, the cost orders are made for one length each (expensive-last costs a 2-frame launch 6 %), and a plan's fitted fixed cost
+	// must not depend on which of them its chunks happened to run in (seen: the 6-waves plan kept over the two-paths one, -3.6 %).
+	const bool stillTuning = ( forcedPlan < 0 && ctx->tunedPlan < 0 );
+
+	if( !ctx->orderPinned && ctx->costLearnt && knobs.dealOrder != 0 && ( !stillTuning || knobs.dealOrder > 0 ) ) {
 		const size_t tileFrames = (size_t) ctx->numLocalTiles * nFrames;
 		dealt = ( knobs.dealOrder > 0 ) ? std::min( knobs.dealOrder, 2 ) : ( tileFrames <= kCostOrderTileFrames ) ? 1 : ( tileFrames <= kSpatialOrderTileFrames ) ? 0 : 2;
 	}
