@@ -11,7 +11,9 @@
  * same time and vote; depth of field's one cross-pixel value is handed from its owner to every context.
  * (bench.py --gpus N does the same with one PROCESS per GPU through torch.distributed; this is the form a C++ host links.)
  *
- * Status codes and error convention: pbr_hip.h's (0 = PBR_OK; pbr_multi_last_error names the rank that failed).
+ * Status codes and error convention: pbr_hip.h's (0 = PBR_OK; pbr_multi_last_error names the rank that failed).  A rank that fails
+ * before the exchange tells the others at a meeting point in front of the collective, and then NO rank enters it (a collective one
+ * rank never joins would hang the rest): the call returns the failing rank's status.
  * Threading: calls on one pbr_multi are not re-entrant; the library's own threads are internal.
  */
 #ifndef PBR_MULTI_H

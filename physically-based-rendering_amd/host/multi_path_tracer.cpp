@@ -222,14 +222,19 @@ int MultiPathTracer::onEveryRank( const std::function<int( int )>& job ) {
 		} );
 	}
 
+	// the first rank that failed ON ITS OWN: a rank that only skipped the exchange because another one had failed reports
+	// that, and is passed over as long as the one that caused it is there to name
 	int first = PBR_OK;
+	bool firstIsConsequence = false;
 
 	for( size_t r = 0; r < mRanks.size(); r++ ) {
 		mRanks[r].worker.wait();
+		const bool consequence = ( mRanks[r].message.find( "another rank failed" ) != std::string::npos );
 
-		if( mRanks[r].status != PBR_OK && first == PBR_OK ) {
+		if( mRanks[r].status != PBR_OK && ( first == PBR_OK || ( firstIsConsequence && !consequence ) ) ) {
 			first = mRanks[r].status;
 			mError = mRanks[r].message;
+			firstIsConsequence = consequence;
 		}
 	}
 
@@ -368,12 +373,17 @@ int MultiPathTracer::exchange( int r ) {
 	int status = pbr_export_tiles( rank.ctx, rank.dSend );
 	hipError_t err = ( status == PBR_OK ) ? hipSetDevice( rank.device ) : hipSuccess;
 
-	// peer copies: every rank passes both meeting points whatever happened to it, so that no rank waits for one that gave up
-	if( peer ) {
-		mBarrier.arrive();      // every send buffer is written (pbr_export_tiles has waited for its copy)
+	// First meeting point, both transports: every send buffer is written (pbr_export_tiles has waited for its copy) — and every rank
+	// knows whether ALL ranks got this far.  A collective that one rank never enters would hang the others; a rank that has failed
+	// (its render or its export) says so here, and then nobody enters it.
+	if( status != PBR_OK || err != hipSuccess ) {
+		mFailedRanks.fetch_add( 1 );
 	}
 
-	if( status == PBR_OK && err == hipSuccess ) {
+	mBarrier.arrive();
+	const bool everyoneHere = ( mFailedRanks.load() == 0 );
+
+	if( status == PBR_OK && err == hipSuccess && everyoneHere ) {
 		if( peer ) {
 			for( size_t other = 0; other < mRanks.size() && err == hipSuccess; other++ ) {
 				err = hipMemcpyPeerAsync( (char*) rank.dRecv + other * mTileBytes, rank.device, mRanks[other].dSend, mRanks[other].device, mTileBytes, rank.stream );
@@ -392,19 +402,37 @@ int MultiPathTracer::exchange( int r ) {
 		}
 	}
 
-	if( peer ) {
-		mBarrier.arrive();      // nobody overwrites a send buffer (the next export) while somebody still reads it
+	// Second meeting point: nobody overwrites a send buffer (the next export) while somebody still reads it; the failure count is
+	// reset for the next exchange by the last rank to pass.
+	mBarrier.arrive();
+
+	if( r == 0 ) {
+		mFailedRanks.store( 0 );
 	}
+
+	mBarrier.arrive();      // ... and nobody starts the next exchange before it is
+
 	if( status != PBR_OK ) {
 		return status;
 	}
 	if( err != hipSuccess ) {
 		return failed( r, PBR_EDEVICE, hipWhat( "tile exchange", err ) );
 	}
+	if( !everyoneHere ) {
+		return failed( r, PBR_ESTATE, "the tile exchange was skipped: another rank failed before it" );
+	}
 
 	status = pbr_import_tiles( rank.ctx, rank.dRecv );
 	rank.gatherMs = nowMs() - t0;
 	return status;
+}
+
+// A rank whose render failed does not exchange, but the others must not wait for it: it passes the meeting points as a failed rank.
+void MultiPathTracer::skipExchange() {
+	mFailedRanks.fetch_add( 1 );
+	mBarrier.arrive();
+	mBarrier.arrive();
+	mBarrier.arrive();
 }
 
 int MultiPathTracer::gather() {
@@ -430,9 +458,8 @@ int MultiPathTracer::render( uint32_t firstSampleCount, uint32_t nFrames, const 
 		rank.gatherMs = 0.0;
 
 		if( status != PBR_OK ) {
-			if( withGather && mTransport == PBR_MULTI_PEER_COPY ) {
-				mBarrier.arrive();
-				mBarrier.arrive();
+			if( withGather ) {
+				skipExchange();
 			}
 
 			return status;
@@ -494,9 +521,8 @@ int MultiPathTracer::renderFrame( float seed, float pixelWeight, float pxDim, co
 		if( status == PBR_OK && withGather ) {
 			status = exchange( r );
 		}
-		else if( withGather && mTransport == PBR_MULTI_PEER_COPY ) {
-			mBarrier.arrive();
-			mBarrier.arrive();
+		else if( withGather ) {
+			skipExchange();
 		}
 
 		if( status == PBR_OK && accumulate ) {

@@ -3,6 +3,7 @@
 // counterpart (one CL* per PathTracer on one device: source/PathTracer.cpp:150-153, source/CL.cpp:355,521).
 #pragma once
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <functional>
@@ -97,12 +98,14 @@ class MultiPathTracer {
 		// `job( rank )` on every rank's thread at the same time; the first failing rank's status (its message in mError)
 		int onEveryRank( const std::function<int( int )>& job );
 		int exchange( int rank );
+		void skipExchange();
 		int failed( int rank, int status, const std::string& what );
 		void freeBuffers();
 		void release();
 
 		std::vector<Rank> mRanks;
 		RankBarrier mBarrier;
+		std::atomic<int> mFailedRanks{ 0 };   // of the exchange in progress (exchange / skipExchange)
 		int mTransport;
 		uint64_t mTileBytes = 0;
 		bool mConfigured = false;

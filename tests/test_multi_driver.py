@@ -169,3 +169,36 @@ def test_depth_of_field_across_ranks_frame_by_frame(pbr, gpu_device):
         assert same_values(got, want), describe_mismatch(got, want)
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+def test_a_rank_that_fails_does_not_hang_the_others(pbr, gpu_device):
+    """One rank's render fails (its context is reconfigured behind the driver's back with the other BRDF than the uploaded
+    materials'): the call returns that rank's error, NO rank enters the exchange — a collective one rank never joins would hang the
+    rest —, and once the rank is repaired the next render gathers the unsharded frame again."""
+    from importlib import import_module
+    multi = import_module(pbr.__name__ + ".multi")
+    sc = _scene(pbr, "cornell", 0, depth=3)
+    w, h = 64, 48
+    cfg, cam, px, seeds = sc.config(w, h), sc.camera(), pbr.pixel_dimension(w, h), pbr.frame_seeds(0, 3)
+    want, _ = _single(pbr, sc, cfg, cam, px, seeds)
+    m = multi.MultiDevice([gpu_device] * 3, multi.PEER_COPY)
+    try:
+        m.upload_scene(sc.desc)
+        m.configure(cfg)
+        broken = pbr.Config.from_buffer_copy(cfg)
+        broken.tile_world, broken.tile_rank, broken.brdf = 3, 1, 1 - int(cfg.brdf)
+        m.context(1).configure(broken)
+        with pytest.raises(pbr.PbrError, match="rank 1 .*BRDF"):
+            m.render(0, seeds, px, cam)
+        with pytest.raises(pbr.PbrError, match="rank 1 .*BRDF"):          # and again: the meeting points are in step
+            m.render_frame(float(seeds[0]), 0.0, px, cam)
+        repaired = pbr.Config.from_buffer_copy(cfg)
+        repaired.tile_world, repaired.tile_rank = 3, 1
+        m.context(1).configure(repaired)
+        m.reset_accum()
+        m.render(0, seeds, px, cam)
+        got = m.read_full(2)
+        assert same_values(got, want), describe_mismatch(got, want)
+    finally:
+        m.close()
