@@ -90,8 +90,9 @@ int pbr_diag_set_knob( pbr_ctx* ctx, const char* name, int value );
 int pbr_diag_pin_plan( pbr_ctx* ctx, int plan );
 
 /* The dealing order of the work queue (csrc/pt_kernel.hpp, nextSlot).  The local tiles form a grid that is cut into 8 bands
- * of rows with one queue head each; band b's tiles are dealt in the order the stretch [band_first[b], band_first[b + 1]) of
- * the table names them (local tile indices; the table has one entry per local tile).
+ * of rows; band b's tiles are dealt in the order the stretch [band_first[b], band_first[b + 1]) of the table names them (local
+ * tile indices; the table has one entry per local tile) — by four queue heads side by side, head s taking entries s, s + 4, ... of
+ * the stretch.
  * Placement is for speed only: every (pixel, frame) unit is handed out exactly once in any order, images and counters
  * do not depend on it (tested).  get: which = 0 the spatial (or pinned) table, 1 the library's cost-classes table, 2 its
  * expensive-last table (PBR_ESTATE until they have been learnt); *count = entries, order[] filled when non-null.  set: with band_first = NULL `order` must hold,
@@ -102,8 +103,9 @@ int pbr_diag_get_tile_order( pbr_ctx* ctx, int which, uint32_t* order, uint32_t 
 int pbr_diag_set_tile_order( pbr_ctx* ctx, const uint32_t* order, uint32_t count, const uint32_t* band_first );
 
 /* The order the last render was dealt in: "spatial" — inside a band column by column —; "cost-classes" — per band eight
- * classes of falling cost, spatial inside a class: render calls of up to 128 Ki tiles x frames —; "expensive-last" — per band
- * its most expensive quarter last, spatial inside both parts: calls above 192 Ki —, the two once the library has learnt the
+ * classes of falling cost, spatial inside a class: render calls of up to 128 Ki tiles x frames, of a shard (tile_world > 1) up
+ * to 1 Mi —; "expensive-last" — per band its most expensive quarter last, spatial inside both parts: calls above 192 Ki (1 Mi) —,
+ * the two once the library has learnt the
  * tiles' costs from a debug image (csrc/pbr_hip.hip, learnTileCosts); or "pinned" (pbr_diag_set_tile_order).  *learnt =
  * whether the cost orders exist.  Knob "deal_order": 0 always spatial, 1 always cost classes, 2 always expensive last (once
  * learnt), -1 by size. */

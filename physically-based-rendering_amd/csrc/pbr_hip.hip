@@ -235,8 +235,8 @@ bool integral( float w, double lo, double hi ) {
 	return ( w == std::floor( w ) ) && ( (double) w >= lo ) && ( (double) w <= hi );
 }
 
-// queue heads of the pixel-slot queue, one 128-B line per band (pt_kernel.hpp, nextSlot)
-const size_t kWorkBytes = sizeof( unsigned int ) * PT_BANDS * PT_BAND_STRIDE;
+// queue heads of the pixel-slot queue, one 128-B line each, PT_SUB per band (pt_kernel.hpp, nextSlot)
+const size_t kWorkBytes = sizeof( unsigned int ) * PT_HEADS * PT_BAND_STRIDE;
 
 // frame-parallel launches: cap of the per-frame result buffer (16 B per local pixel and frame)
 const size_t kFrameBufBytes = (size_t) 16 << 30;
@@ -741,13 +741,24 @@ int uploadTileOrder( pbr_ctx* ctx ) {
 // run out of them and join in (bands differ by up to 10 x in cost, and an XCD works on its own band until it is empty) — the
 // heavy part of every band is then shared by all eight XCDs, their L2s and their fabric links, instead of being its owner's alone.
 // Equalising the bands' costs by moving their row boundaries gives a fifth of that; and the heavy tiles have to be the VERY last a
-// band deals: a coda of its cheapest 10 % behind them gives the whole gain back (band_balance_cheap_coda.txt), which the reading
-// above does not explain.  Below ~192 Ki tiles x frames it loses to the
+// band deals: a coda of its cheapest 10 % behind them gives the whole gain back (band_balance_cheap_coda.txt).  That was the clue:
+// most of it was the QUEUE HEADS.  The XCDs that have run dry all draw from the one head of the band they help, a head hands out
+// ~90 draws / us, and cheap tiles are drawn the fastest — expensive-last merely made sure that the shared part of a launch draws
+// slowly.  With four heads per band and the helpers spread over them (pt_kernel.hpp, nextSlot; experiments/queue_heads_*.txt,
+// queue_subheads_*.txt) the SPATIAL order is as fast as expensive-last was (Sponza-class 64 frames 2165 -> 2211 Msamples/s against
+// 2196; Dragon-class 2132 -> 2317 against 2290; Cornell 4832 -> 5148 against 5053) and expensive-last still adds 1.3 % on the
+// Dragon-class scene and Cornell, nothing on the other two.  Below ~192 Ki tiles x frames it loses to the
 // spatial order (the long paths start last), hence three orders by the size of the RENDER CALL (all launches of a call alike;
 // while the schedule tuner is still measuring, everything is dealt spatially: launch()):
 //   tiles x frames <= 128 Ki  eight classes of falling cost     <= 192 Ki  spatial     above  expensive quarter last
+// A SHARD (tile_world > 1) deals falling classes up to 1 Mi tiles x frames: its tiles are every N-th of the image, the spatial order
+// has little locality to lose there, and with the heads out of the way the shorter end is what is left to gain — rank 0's share at
+// 20 frames, N = 2 / 4: Sponza-class 10.24 -> 10.07 ms, 5.54 -> 5.40; Dragon-class 10.67 -> 10.58, 6.23 -> 6.09; N = 8 at 64 frames
+// 8.29 -> 8.13, 8.97 -> 8.80 (queue_subheads_orders_by_launch_length.txt).  Small UNSHARDED images do not share that: 1280x720 ...
+// 640x360 behave like 1080p (queue_subheads_orders_small_and_4k_images.txt).
 const unsigned kCostClasses = 8;
 const size_t kCostOrderTileFrames = 128 * 1024;
+const size_t kCostOrderShardTileFrames = 1024 * 1024;
 const size_t kSpatialOrderTileFrames = 192 * 1024;
 
 // per band: the spatial order, stably partitioned into [ the cheaper three quarters ][ the most expensive quarter ]
@@ -1328,7 +1339,8 @@ int launch( pbr_ctx* ctx, uint32_t firstCount, uint32_t nFrames, const float* se
 
 	if( !ctx->orderPinned && ctx->costLearnt && knobs.dealOrder != 0 && ( !stillTuning || knobs.dealOrder > 0 ) ) {
 		const size_t tileFrames = (size_t) ctx->numLocalTiles * nFrames;
-		dealt = ( knobs.dealOrder > 0 ) ? std::min( knobs.dealOrder, 2 ) : ( tileFrames <= kCostOrderTileFrames ) ? 1 : ( tileFrames <= kSpatialOrderTileFrames ) ? 0 : 2;
+		const size_t costLimit = ( ctx->cfg.tile_world > 1u ) ? kCostOrderShardTileFrames : kCostOrderTileFrames;
+		dealt = ( knobs.dealOrder > 0 ) ? std::min( knobs.dealOrder, 2 ) : ( tileFrames <= costLimit ) ? 1 : ( tileFrames <= kSpatialOrderTileFrames ) ? 0 : 2;
 	}
 
 	std::snprintf( ctx->lastDeal, sizeof( ctx->lastDeal ), "%s", ctx->orderPinned ? "pinned" : ( dealt == 1 ) ? "cost-classes" : ( dealt == 2 ) ? "expensive-last" : "spatial" );

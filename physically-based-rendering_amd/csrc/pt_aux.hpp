@@ -18,7 +18,7 @@ __global__ __launch_bounds__( 256 ) void foldFrames( const DevParams P, const fl
 	const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
 
 	// the path-tracing launch before this one has drained the queue: leave its heads at zero for the next launch
-	if( slot < (unsigned) PT_BANDS ) {
+	if( slot < (unsigned) PT_HEADS ) {
 		P.workCounter[slot * PT_BAND_STRIDE] = 0u;
 	}
 

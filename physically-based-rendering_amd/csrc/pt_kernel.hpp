@@ -69,6 +69,11 @@ using namespace ptm;
 #ifndef PT_BANDS
 #define PT_BANDS 8
 #endif
+// queue heads per band (nextSlot); a power of two
+#ifndef PT_SUB
+#define PT_SUB 4
+#endif
+#define PT_HEADS ( PT_BANDS * PT_SUB )
 
 // A leaf's second face record is requested before the first face is tested (testLeaf, EAGER: 12 more registers during the
 // leaf phase, one memory latency less per two-face leaf) in kernels of up to this many waves / SIMD: the state machine /
@@ -103,7 +108,7 @@ struct DevParams {
 	float4* frameBuf;       // frame-parallel launches: {finalColor, focus} of frame k, pixel slot s at frameBufIndex( s, k )
 	unsigned frameStride;   // = numLocalTiles * 64: the pixel slots of this launch
 	unsigned long long* counters;  // nodes, tris, hits, paths
-	unsigned int* workCounter;  // PT_BANDS heads, one per band of the pixel-slot queue, PT_BAND_STRIDE words apart (nextSlot)
+	unsigned int* workCounter;  // PT_HEADS heads, PT_SUB per band of the pixel-slot queue, PT_BAND_STRIDE words apart (nextSlot)
 	unsigned int* guard;    // [0] tile-loop, [1] path-loop, [2] traversal trips (PBR_GUARD builds only)
 
 	float eye[3], cw[3], cu[3], cv[3];
@@ -2071,7 +2076,7 @@ PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, La
 
 // ---- the pixel-slot queue ----------------------------------------------------------------
 // Work is handed out in pixel slots (64 per 8x8 tile).  The local tiles are partitioned into PT_BANDS
-// lists — bands of tile rows — with one queue head each; a wave prefers the band of the XCD it runs on
+// lists — bands of tile rows; a wave prefers the band of the XCD it runs on
 // (HW_REG_XCC_ID) and moves on to the other bands once its own is empty.  So the 8 XCDs — each with a
 // private 4 MiB L2 — work on 8 different parts of the image instead of all on the same strip, and the rays
 // in flight on one XCD (primary rays and the first bounces that start where they hit) share that L2 with 1/8
@@ -2080,6 +2085,13 @@ PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, La
 // waves of one XCD hold at a time form a compact block, not a 1920-pixel-wide strip — or, once the host knows
 // what the tiles cost, by cost (expensive tiles first in short render calls, the expensive quarter last in
 // long ones); the kernel only follows the table.
+// A band has PT_SUB = 4 HEADS: head s deals tiles s, s + 4, s + 8 ... of the band's order, so the four advance through the same
+// neighbourhood side by side.  A wave draws from the head of its wave index in the block (mod 4) and, once it has left its own
+// band, from the same sub-head of the band it helps — the thieves of a band spread over its four heads.  A head is one address
+// that every XCD's atomics must reach in memory: it hands out ≈ 90 draws / µs, and the launch draws 250 – 600 / µs.  With one head
+// per band the end of a launch, when the XCDs that have run dry converge on the few bands that still hold tiles, was bound by
+// that: 64-frame launches dealt spatially +6.5 % (Cornell), +2.1 % (Sponza-class), +8.6 % (Dragon-class), +0.9 % (hairball)
+// with four heads; eight heads per band are slower again (profiles/r06/experiments/queue_subheads_4_8.txt).
 // Frame-parallel launches deal a PIXEL THROUGH ALL ITS FRAMES before the next pixel of the tile: the 64 units a
 // wave fetches together are 64 frames of one pixel — camera rays that differ only by their jitter, the same nodes,
 // the same leaf, the same material — and a lane that finishes takes another frame of a pixel nearby.  Against frame
@@ -2090,8 +2102,8 @@ PT_DEV bool stepPixel( const DevParams& P, const float4* lds, PixelState& st, La
 #define PT_NO_WORK 0xFFFFFFFFu
 
 struct WorkCursor {
-	unsigned exhausted;   // bit b: this lane has seen band b empty
-	int home;             // preferred band
+	unsigned exhausted;   // bit p: this lane has seen the p-th head of its wave's visiting order empty (PT_HEADS <= 32)
+	int home;             // preferred head: ( band of the wave's XCD ) * PT_SUB + ( wave index in the block mod PT_SUB )
 };
 
 PT_DEV WorkCursor beginWork() {
@@ -2099,14 +2111,16 @@ PT_DEV WorkCursor beginWork() {
 	asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"( xcc ) );
 	WorkCursor wc;
 	wc.exhausted = 0u;
-	wc.home = (int) ( xcc & ( PT_BANDS - 1 ) );
+	// (wave-uniform by construction; said so, or everything derived from it is vector arithmetic and the 96-register kernel needs 97)
+	wc.home = (int) ( ( xcc & ( PT_BANDS - 1 ) ) * PT_SUB + ( (unsigned) __builtin_amdgcn_readfirstlane( (int) ( threadIdx.x >> 6 ) ) & ( PT_SUB - 1 ) ) );
 	return wc;
 }
 
 // Next unit of work: a pixel slot (local tile * 64 + position in tile) — and, for frame-parallel
 // launches (frames > 1 units per pixel), which frame of it — or PT_NO_WORK.  Per-lane control flow on
-// purpose ("Toolchain notes"); the band index is made wave-uniform before the atomic so
+// purpose ("Toolchain notes"); the head index is made wave-uniform before the atomic so
 // that hipcc still folds the adds of the active lanes into one wave-level add.
+// Visiting order of a wave: band after band starting at its own, inside every band the PT_SUB heads starting at its own sub-head.
 // n / d for a divisor that is fixed per launch, without dividing (Granlund & Montgomery 1994, the round-up variant:
 // exact for every 32-bit n): the host derives {magic, shifts} from d (pbr_hip.hip, invariantDivisor).  A 32-bit
 // division by a run-time value is ~20 instructions, and nextSlot runs whenever any lane of a wave takes a new unit.
@@ -2116,26 +2130,32 @@ PT_DEV unsigned divInvariant( unsigned n, unsigned magic, unsigned shifts ) {
 }
 
 PT_DEV unsigned nextSlot( const DevParams& P, WorkCursor& wc, unsigned frames, unsigned& frame ) {
-	while( wc.exhausted != ( 1u << PT_BANDS ) - 1u ) {
-		// first band, starting at home, that this lane has not seen empty
-		const unsigned rotated = ( ( wc.exhausted >> wc.home ) | ( wc.exhausted << ( PT_BANDS - wc.home ) ) ) & ( ( 1u << PT_BANDS ) - 1u );
-		const int mine = ( wc.home + __builtin_ctz( ~rotated ) ) & ( PT_BANDS - 1 );
-		const int band = __builtin_amdgcn_readfirstlane( mine );
-		const unsigned q = atomicAdd( P.workCounter + band * PT_BAND_STRIDE, 1u );
+	static_assert( PT_HEADS <= 32 && ( PT_SUB & ( PT_SUB - 1 ) ) == 0 && ( PT_BANDS & ( PT_BANDS - 1 ) ) == 0, "WorkCursor::exhausted is one 32-bit mask" );
 
-		// frame-parallel launches: `frames` units per pixel slot of the band
-		const unsigned bandSlots = P.bandTiles[band] * 64u;
+	while( wc.exhausted != (unsigned) ( ( 1ull << PT_HEADS ) - 1ull ) ) {
+		// first head of this wave's visiting order that this lane has not seen empty
+		const unsigned pos = (unsigned) __builtin_ctz( ~wc.exhausted );
+		const unsigned homeBand = (unsigned) wc.home / PT_SUB, homeSub = (unsigned) wc.home & ( PT_SUB - 1 );
+		const int mine = (int) ( ( ( homeBand + pos / PT_SUB ) & ( PT_BANDS - 1 ) ) * PT_SUB + ( ( homeSub + pos ) & ( PT_SUB - 1 ) ) );
+		const int head = __builtin_amdgcn_readfirstlane( mine );
+		const int band = head / PT_SUB;
+		const unsigned sub = (unsigned) head & ( PT_SUB - 1 );
+		const unsigned q = atomicAdd( P.workCounter + head * PT_BAND_STRIDE, 1u );
+
+		// the head's share of the band: tiles sub, sub + PT_SUB ... of its order; frame-parallel launches: `frames` units per pixel slot
+		const unsigned bandSlots = ( ( P.bandTiles[band] + ( PT_SUB - 1 ) - sub ) / PT_SUB ) * 64u;
 
 		if( q >= bandSlots * frames ) {
-			wc.exhausted |= 1u << band;
+			// (the head of the wave's first active lane, at ITS place in this lane's order)
+			wc.exhausted |= 1u << ( ( ( (unsigned) band - homeBand ) & ( PT_BANDS - 1 ) ) * PT_SUB + ( ( sub - homeSub ) & ( PT_SUB - 1 ) ) );
 			continue;
 		}
 
-		// unit q of the band = frame ( q mod frames ) of its pixel slot q / frames: a pixel through all frames, then the next pixel
+		// unit q of the head = frame ( q mod frames ) of its pixel slot q / frames: a pixel through all frames, then the next pixel
 		const unsigned qf = ( frames > 1u ) ? divInvariant( q, P.framesDiv[0], P.framesDiv[1] ) : q;
 		frame = q - qf * frames;
 		// (a 32-bit byte offset from a scalar base: one global_load_dword with an SGPR pair, no 64-bit address in vector registers)
-		const unsigned tile = *(const unsigned*) ( (const char*) P.tileOrder + ( ( P.bandFirst[band] + ( qf >> 6 ) ) << 2 ) );
+		const unsigned tile = *(const unsigned*) ( (const char*) P.tileOrder + ( ( P.bandFirst[band] + ( qf >> 6 ) * PT_SUB + sub ) << 2 ) );
 		return tile * 64u + ( qf & 63u );
 	}
 

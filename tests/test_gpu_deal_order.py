@@ -162,6 +162,33 @@ def test_the_librarys_cost_order(pbr, oracle, gpu_device, kind, triangles, w, h)
         dev.close()
 
 
+def test_a_shard_deals_falling_classes_for_longer(pbr, gpu_device):
+    """A rank's share (tile_world > 1) is dealt in falling cost classes up to 1 Mi tiles x frames, the whole frame up to 128 Ki:
+    the same render call, sharded and not."""
+    sc = _scene(pbr, "cornell", 0, depth=3)
+    w = h = 256
+    cam, px = sc.camera(), pbr.pixel_dimension(w, h)
+    for world, expected in ((1, "spatial"), (2, "cost-classes")):
+        cfg = sc.config(w, h)
+        cfg.tile_world, cfg.tile_rank = world, 0
+        dev = pbr.Device(gpu_device)
+        try:
+            dev.pin_plan(PLANS["phased-mid"])
+            dev.upload_scene(sc.desc)
+            dev.configure(cfg)
+            tiles = len(dev.tile_order()[0])
+            dev.render(0, pbr.frame_seeds(0, 1), px, cam)
+            frames = (128 * 1024) // tiles + 40                  # above 128 Ki, below 192 Ki tiles x frames
+            assert 128 * 1024 < tiles * frames <= 192 * 1024
+            dev.render(1, pbr.frame_seeds(1, frames), px, cam)
+            assert dev.last_deal() == (expected, True), (world, dev.last_deal())
+            if world > 1:
+                dev.render(1 + frames, pbr.frame_seeds(1 + frames, (1024 * 1024) // tiles + 8), px, cam)
+                assert dev.last_deal()[0] == "expensive-last"
+        finally:
+            dev.close()
+
+
 def test_a_table_that_is_not_a_permutation_is_refused(pbr, gpu_device):
     sc = _scene(pbr, "cornell", 0)
     dev = pbr.Device(gpu_device)
