@@ -95,22 +95,27 @@ def library_stamp():
         return None
 
 
-def recorded_traffic(scene, w, h, depth, brdf, traversal=0, arith=0):
+def recorded_traffic(scene, w, h, depth, brdf, traversal=0, arith=0, schedule=None):
     """Fabric-side bytes PER SAMPLE from the committed PMC passes (profiles/rNN/pmc_traffic.json: rocprofv3 --pmc in
     separate runs; read = 128 x TCC_EA0_RDREQ_128B + 64 x _64B + 32 x _32B = 2 x FETCH_SIZE[KB] x 1024 on gfx950,
     write = WRITE_SIZE, calibrated with scripts/calibrate.py) of the newest round that profiled exactly this workload;
     None otherwise (PMC counters cannot be read from inside this run).  Every record carries the digest of the library
-    it profiled (`srchash`) and the schedule: roofline_block refuses a record of another build or another schedule."""
+    it profiled (`srchash`) and the schedule: roofline_block refuses a record of another build or another schedule.
+    Where the tuner's call between two schedules is close the round profiled both (keys <workload>_pN): the record of
+    `schedule` is preferred, else the workload's first."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         try:
             records = json.load(open(path))
         except (OSError, ValueError):
             continue
-        for key, rec in records.items():      # keys: the scene, or scene_suffix for another size of it ("hairball_4k")
-            if rec.get("scene", key.split("_")[0]) == scene and (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) == (w, h, depth, brdf) \
-                    and (rec.get("traversal", 0), rec.get("arith", 0)) == (traversal, arith):
-                return dict(rec, source=os.path.relpath(path, ROOT))
+        found = [(key, rec) for key, rec in records.items()      # keys: the scene, or scene_suffix for another size / mode / schedule of it
+                 if rec.get("scene", key.split("_")[0]) == scene and (rec["width"], rec["height"], rec["max_depth"], rec["brdf"]) == (w, h, depth, brdf)
+                 and (rec.get("traversal", 0), rec.get("arith", 0)) == (traversal, arith)]
+        if found:
+            # this run's schedule if it was profiled; else the schedule the tuner kept in the profiling run (the key without _pN)
+            found.sort(key=lambda kr: (kr[1].get("schedule") != schedule, kr[0].rsplit("_p", 1)[-1].isdigit()))
+            return dict(found[0][1], source=os.path.relpath(path, ROOT))
     return None
 
 
@@ -416,7 +421,7 @@ def mode_leg(pbr, scene, base_cfg, cam, px, args, device, depth, traversal, arit
         assert counters["paths"] == samples, (counters, samples)
         algo = algorithmic_bytes(counters, w * h * args.steps)
         plan = dev.last_plan()[0]
-        traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), traversal, arith)
+        traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), traversal, arith, schedule=plan)
         return {
             "value": samples / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed * 1e3 / args.steps,
             "repeats": len(runs), "ms_per_step_all": [round(r[0] * 1e3 / args.steps, 5) for r in runs],
@@ -674,7 +679,7 @@ def main():
         # per launch of the dominant kernel (the path-tracing kernel the auto-tuner settled on): each rank runs
         # trace_launches of them per render; the slowest rank's average launch duration
         algo_launch = algo / world / trace_launches          # SURVEY 8(d)'s per-sample figure x the samples one launch processes
-        traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), int(cfg.traversal), int(cfg.arith))
+        traffic = recorded_traffic(args.scene, w, h, depth, int(cfg.brdf), int(cfg.traversal), int(cfg.arith), schedule=plan)
         roofline = roofline_block(args.scene, plan, traffic, algo_launch, samples / world / trace_launches, kernel_s, stamp=library_stamp(), kernel=kernel_name)
         out = {
             "metric": "Msamples/s (paths/s) @1080p fixed seed; 1/2/4/8 MI355X scaling",

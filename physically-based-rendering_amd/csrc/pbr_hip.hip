@@ -235,8 +235,8 @@ bool integral( float w, double lo, double hi ) {
 	return ( w == std::floor( w ) ) && ( (double) w >= lo ) && ( (double) w <= hi );
 }
 
-// queue heads of the pixel-slot queue, one 128-B line each, PT_SUB per band (pt_kernel.hpp, nextSlot)
-const size_t kWorkBytes = sizeof( unsigned int ) * PT_HEADS * PT_BAND_STRIDE;
+// queue heads of the pixel-slot queue, one 128-B line each, PT_SUB per band, + the line of the word of heads seen empty (pt_kernel.hpp, nextSlot)
+const size_t kWorkBytes = sizeof( unsigned int ) * ( PT_HEADS + 1 ) * PT_BAND_STRIDE;
 
 // frame-parallel launches: cap of the per-frame result buffer (16 B per local pixel and frame)
 const size_t kFrameBufBytes = (size_t) 16 << 30;

@@ -17,8 +17,9 @@ namespace ptk {
 __global__ __launch_bounds__( 256 ) void foldFrames( const DevParams P, const float4* src, float4* dst ) {
 	const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
 
-	// the path-tracing launch before this one has drained the queue: leave its heads at zero for the next launch
-	if( slot < (unsigned) PT_HEADS ) {
+	// the path-tracing launch before this one has drained the queue: leave its heads (and the word of the heads seen empty behind
+	// them) at zero for the next launch
+	if( slot <= (unsigned) PT_HEADS ) {
 		P.workCounter[slot * PT_BAND_STRIDE] = 0u;
 	}
 

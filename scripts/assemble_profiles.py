@@ -40,7 +40,11 @@ def library_stamp():
 
 
 def collect(out, loads):
-    summary = {}
+    # a second pass over the same directory (more workloads, or one of them again) adds to what the first one found
+    try:
+        summary = json.load(open(out + "/summary.json"))
+    except (OSError, ValueError):
+        summary = {}
     for key in loads:
         rec = {"library_srchash": library_stamp()}
         try:

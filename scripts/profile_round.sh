@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the round's measurements on the GPU box: bench lines, rocprofv3 kernel stats and the PMC passes (each in its
 # own run, each under a timeout; --pmc never together with a trace domain other than --kernel-trace).
-# usage: scripts/profile_round.sh <outdir> [workload ...]     workloads: <scene>[_4k][_walk6|_walk8|_walk8c][_native], scene = cornell sponza dragon hairball
+# usage: scripts/profile_round.sh <outdir> [workload ...]     workloads: <scene>[_4k][_walk6|_walk8|_walk8c][_native][_pN], scene = cornell sponza dragon hairball
 #        (_4k: 3840x2160; _walk6 / _walk8: pbr_config.traversal six / eight orders, _walk8c: eight orders over compact records; _native: pbr_config.arith native)
 out=${1:-gpurun_out/round}; shift
 loads=${@:-cornell sponza dragon hairball hairball_4k}
@@ -16,7 +16,11 @@ for key in $loads; do
   case $key in *_walk6*) mode="$mode --traversal six-order";; *_walk8c*) mode="$mode --traversal eight-order-compact";; *_walk8*) mode="$mode --traversal eight-order";; esac
   case $key in *_native*) mode="$mode --arith native";; esac
   size="$size $mode"
-  timeout 600 python3 bench.py --scene $s $size --steps $steps --modes off > $out/bench_$key.json 2> $out/bench_$key.err
+  # <workload>_pN: the same workload with schedule N pinned — the runner-up where the tuner's call is close, so that a bench line
+  # finds counters of whichever schedule it ran (bench.py, recorded_traffic)
+  pin=""
+  case $key in *_p[0-6]) pin="--plan ${key##*_p}";; esac
+  timeout 600 python3 bench.py --scene $s $size --steps $steps --modes off $pin > $out/bench_$key.json 2> $out/bench_$key.err
   # the profiled runs pin the schedule the tuner settled on in the plain run (--plan: no tuning launches under the profiler)
   plan=$(python3 -c "import json,sys; n=json.loads(open('$out/bench_$key.json').read().strip().splitlines()[-1]).get('schedule','refill-lean'); print(['refill-lean','refill-wide','phased-lean','phased-wide','phased-mid','refill-mid','phased-dual'].index(n))")
   cd /tmp

@@ -185,9 +185,10 @@ def test_bench_parent_ends_its_ranks_on_sigterm_and_on_the_deadline():
         import importlib.util, subprocess, sys
         spec = importlib.util.spec_from_file_location("bench_under_test", %r)
         bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+        previous = bench.arm_signals()      # as bench.py's parent does: armed BEFORE the ranks exist (and before this test may signal)
         procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"], start_new_session=True) for _ in range(3)]
         print(" ".join(str(p.pid) for p in procs), flush=True)
-        sys.exit(bench.wait_ranks(procs, limit_s=float(sys.argv[1])))
+        sys.exit(bench.wait_ranks(procs, limit_s=float(sys.argv[1]), previous=previous))
     """ % os.path.join(ROOT, "bench.py"))
 
     def alive(pid):
