@@ -23,4 +23,4 @@ PBR_SOAK_SEEDS=6000 timeout 900 python3 -m pytest tests/test_gpu_parity.py -q -m
 PBR_WALK_SOAK_SEEDS=9000 timeout 900 python3 -m pytest tests/test_gpu_walk_order.py -q -m gpu -k random_configurations_in_an_ordered_mode > $out/soak_walk.txt 2>&1
 PBR_NATIVE_SOAK_SEEDS=2000 timeout 600 python3 -m pytest tests/test_gpu_native_arith.py -q -m gpu -k random_configurations_in_the_native > $out/soak_native.txt 2>&1
 timeout 1500 python3 -m pytest tests -q -m gpu > $out/pytest_gpu.txt 2>&1
-tail -3 $out/pytest_gpu.txt $out/soak.txt $out/soak_walk.txt $out/soak_native.txt $out/smoke.txt
+for f in pytest_gpu soak soak_walk soak_native smoke; do tail -n 3 $out/$f.txt; done
