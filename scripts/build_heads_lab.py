@@ -1,3 +1,4 @@
+# (patches the csrc of commit d8000ff — one queue head per band; later trees have the sub-heads built in and the patch strings no longer match)
 # lab: the library (default flavour) with N queue heads, N/8 per XCD, from a patched COPY of csrc -> lab/libpbrhip_headsN[g].so
 # (scripts/heads_ab.sh runs it against the product).
 #   python scripts/build_heads_lab.py 16            two heads per XCD, a block's waves alternate; thieves walk the heads in cyclic order

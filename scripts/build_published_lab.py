@@ -1,3 +1,4 @@
+# (patches the csrc of commit 2e5f632 — four heads per band, nothing published; the product has had this since 2f234ff)
 # lab: the product's queue + a PUBLISHED mask of the heads that have been seen empty (one word behind the heads): a wave that finds
 # a head empty ORs its bit in and takes what the others have published from the returned value — the end of a launch costs a wave
 # two round trips instead of one per head (32).  From a patched COPY of csrc -> lab/libpbrhip_published.so

@@ -1,3 +1,4 @@
+# (patches the csrc of commit d8000ff — one queue head per band; later trees have the sub-heads built in and the patch strings no longer match)
 # lab: the product candidate of the sub-head queue, from a patched COPY of csrc -> lab/libpbrhip_sub<S>.so.  The eight bands and
 # their tables stay as they are; every band gets S heads, head s deals the band's tiles s, s + S, s + 2 S ... (of its order, whatever it
 # is); a wave's home is (its XCD's band, its wave index mod S); a wave that steals goes band by band and starts, inside a band, at its

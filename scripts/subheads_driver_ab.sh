@@ -1,4 +1,4 @@
-# one head per band (lab/libpbrhip_sub1.so = the product's sources with -DPT_SUB=1) vs four (the product), same box, alternating:
+# one head per band (lab/libpbrhip_sub1.so = the sources of commit 8583261 with -DPT_SUB=1) vs four (the product), same box, alternating:
 # the driver's command, then the 8-way share at --steps 20 (scripts/shard_scaling.py)
 for rep in 1 2 3 4 5; do
   for lib in lab/libpbrhip_sub1.so physically-based-rendering_amd/csrc/libpbrhip.so; do
