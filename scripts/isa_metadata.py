@@ -24,7 +24,8 @@ def code_objects(lib, workdir):
     """Every gfx950 code object of the library: since round 5 it is linked from one translation unit per plan and build
     flavour (build.py), each with its own offload bundle in .hip_fatbin."""
     fat = os.path.join(workdir, "fat.bin")
-    subprocess.check_call([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, lib])
+    # (with an explicit output file: without one llvm-objcopy rewrites its INPUT in place — same contents, new layout and mtime)
+    subprocess.check_call([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, lib, os.path.join(workdir, "copy.so")])
     blob = open(fat, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
     starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
