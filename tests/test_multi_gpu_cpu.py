@@ -44,7 +44,7 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))      # a rendezvous that stalls fails, it does not hang
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))      # a rendezvous that stalls fails, it does not hang
     try:
         mine, _ = _render_rows(pbr, orc, world, rank)
         local = torch.from_numpy(pbr.tiles.pack_rank_tiles(mine, world, rank).copy()).reshape(-1)
